@@ -1,0 +1,598 @@
+"""CPU oracle for the VIOLETv2 pretraining step  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch *functional* restatement (plain torch CPU, fp32 or
+fp64) of the reference algorithm on the hot path.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
+product package (`pytorch_empirical_mvm_amd`) never does and fails loudly when
+its HIP library is missing.
+
+Pinning: the reference ships no tests / golden vectors, so
+the oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF, produced in the
+build container by `tools/gen_goldens.py` (imports /root/reference with module
+stubs) and committed as `tests/golden/*.npz`; `tests/test_oracle_golden.py`
+re-checks the oracle against them on every run.  The BERT arithmetic lives in
+the third-party `transformers` package (README pins 4.26; container has 5.x,
+layer math unchanged) -- pinned through the same fixtures.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+"""
+import math
+import zlib
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# architecture table  (visbackbone/swin_tiny.py:2-24, swin_base.py:3-6,
+# swin_large.py:3-6, swin_*_patch244_*.py:4 ; get_vidswin_model video_swin.py:573-639)
+# ----------------------------------------------------------------------------
+ARCH = {
+    "tiny": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(8, 7, 7)),
+    "small": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window=(8, 7, 7)),
+    "base": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window=(8, 7, 7)),
+    "large": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=(8, 7, 7)),
+    "large384": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=(8, 12, 12)),
+}
+PATCH = (2, 4, 4)
+BERT = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512, types=2, eps=1e-12)
+
+
+def make_cfg(size="base", T=8, img=224, n_txt=32, max_size_frame=None, max_size_patch=14,
+             size_patch=32, temp=0.05, bert_layers=12, mvm_target="pixel", arch=None, vocab=None):
+    a = dict(ARCH[size]) if arch is None else dict(arch)
+    cfg = dict(a)
+    cfg.update(size=size, T=T, img=img, n_txt=n_txt, max_size_frame=max_size_frame or max(T, 6),
+               max_size_patch=max_size_patch, size_patch=size_patch, temp=temp,
+               bert_layers=bert_layers, mvm_target=mvm_target, hidden=BERT["hidden"],
+               vocab=vocab or BERT["vocab"])
+    return cfg
+
+
+# ----------------------------------------------------------------------------
+# parameter inventory with the reference's state_dict key names
+# ----------------------------------------------------------------------------
+def param_shapes(cfg):
+    """Ordered {key: shape} of every learnable tensor of VIOLET_Pretrain (pixel target)."""
+    E, depths, heads, win = cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"]
+    H, V = cfg["hidden"], cfg["vocab"]
+    s = {}
+    # EncTxt (model.py:81-94) -> HF BertEmbeddings
+    s["enc_txt.emb_txt.word_embeddings.weight"] = (V, H)
+    s["enc_txt.emb_txt.position_embeddings.weight"] = (BERT["max_pos"], H)
+    s["enc_txt.emb_txt.token_type_embeddings.weight"] = (BERT["types"], H)
+    s["enc_txt.emb_txt.LayerNorm.weight"] = (H,)
+    s["enc_txt.emb_txt.LayerNorm.bias"] = (H,)
+    # fusion encoder (model.py:124-133) -> HF BertEncoder
+    for l in range(cfg["bert_layers"]):
+        p = f"trsfr.layer.{l}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (BERT["ffn"], H)
+        s[p + "intermediate.dense.bias"] = (BERT["ffn"],)
+        s[p + "output.dense.weight"] = (H, BERT["ffn"])
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    # EncVideo (model.py:9-30)
+    C_out = E * 8
+    s["enc_img.emb_cls"] = (1, 1, 1, H)
+    s["enc_img.emb_pos"] = (1, 1, 1 + cfg["max_size_patch"] ** 2, H)
+    s["enc_img.emb_len"] = (1, cfg["max_size_frame"], 1, H)
+    s["enc_img.emb_odr"] = (1, 1, 1, H)
+    if C_out != H:
+        s["enc_img.fc.weight"] = (H, C_out)
+        s["enc_img.fc.bias"] = (H,)
+    s["enc_img.norm.weight"] = (H,)
+    s["enc_img.norm.bias"] = (H,)
+    # Video-Swin (video_swin.py:410-468)
+    sw = "enc_img.swin."
+    s[sw + "patch_embed.proj.weight"] = (E, 3) + PATCH
+    s[sw + "patch_embed.proj.bias"] = (E,)
+    s[sw + "patch_embed.norm.weight"] = (E,)
+    s[sw + "patch_embed.norm.bias"] = (E,)
+    ntab = (2 * win[0] - 1) * (2 * win[1] - 1) * (2 * win[2] - 1)
+    for i, (d, nh) in enumerate(zip(depths, heads)):
+        C = E * 2 ** i
+        for b in range(d):
+            p = sw + f"layers.{i}.blocks.{b}."
+            s[p + "norm1.weight"] = (C,)
+            s[p + "norm1.bias"] = (C,)
+            s[p + "attn.relative_position_bias_table"] = (ntab, nh)
+            s[p + "attn.qkv.weight"] = (3 * C, C)
+            s[p + "attn.qkv.bias"] = (3 * C,)
+            s[p + "attn.proj.weight"] = (C, C)
+            s[p + "attn.proj.bias"] = (C,)
+            s[p + "norm2.weight"] = (C,)
+            s[p + "norm2.bias"] = (C,)
+            s[p + "mlp.fc1.weight"] = (4 * C, C)
+            s[p + "mlp.fc1.bias"] = (4 * C,)
+            s[p + "mlp.fc2.weight"] = (C, 4 * C)
+            s[p + "mlp.fc2.bias"] = (C,)
+        if i < len(depths) - 1:
+            p = sw + f"layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,)
+            s[p + "norm.bias"] = (4 * C,)
+    s[sw + "norm.weight"] = (C_out,)
+    s[sw + "norm.bias"] = (C_out,)
+    # heads (main_pretrain.py:146-151,178-179)
+    s["fc.1.weight"] = (2 * H, H)
+    s["fc.1.bias"] = (2 * H,)
+    s["fc.3.weight"] = (1, 2 * H)
+    s["fc.3.bias"] = (1,)
+    s["fc_mtm.predictions.bias"] = (V,)
+    s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
+    s["fc_mtm.predictions.transform.dense.bias"] = (H,)
+    s["fc_mtm.predictions.transform.LayerNorm.weight"] = (H,)
+    s["fc_mtm.predictions.transform.LayerNorm.bias"] = (H,)
+    s["fc_mtm.predictions.decoder.weight"] = (V, H)
+    if "pixel" in cfg["mvm_target"]:
+        s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
+        s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    return s
+
+
+def closed_form(key, shape, dtype=torch.float32):
+    """Deterministic closed-form tensor: amp*sin(i*phi + k*1.7) (+1 for norm gains).
+
+    Re-creatable bit-identically anywhere (float64 numpy sin, then cast); golden
+    fixtures therefore store outputs only (SURVEY 8c 'Golden-vector policy')."""
+    n = int(np.prod(shape))
+    k = zlib.crc32(key.encode()) % 997
+    i = np.arange(n, dtype=np.float64)
+    is_norm_w = key.endswith("weight") and ("norm" in key.lower()) and len(shape) == 1
+    is_bias = key.endswith("bias") and len(shape) == 1
+    if is_norm_w:
+        v = 1.0 + 0.05 * np.sin(i * 0.37 + k * 1.7)
+    elif is_bias:
+        v = 0.02 * np.sin(i * 0.61 + k * 1.7)
+    elif "emb_" in key or "embeddings" in key:
+        v = 0.05 * np.sin(i * 0.7310 + k * 1.7)
+    elif "relative_position_bias_table" in key:
+        v = 0.2 * np.sin(i * 0.913 + k * 1.7)
+    else:
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else n
+        v = (1.2 / math.sqrt(fan_in)) * np.sin(i * 0.7853 + k * 1.7)
+    return torch.from_numpy(v.reshape(shape)).to(dtype)
+
+
+def make_state_dict(cfg, dtype=torch.float32):
+    return {k: closed_form(k, shp, dtype) for k, shp in param_shapes(cfg).items()}
+
+
+def make_batch(cfg, B, dtype=torch.float32):
+    """Closed-form synthetic batch (collate schema main_pretrain_yaml.py:69-80)."""
+    T, S, X = cfg["T"], cfg["img"], cfg["n_txt"]
+    n = B * T * 3 * S * S
+    img = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(B, T, 3, S, S) * 1.5).to(dtype)
+    txt = torch.zeros(B, X, dtype=torch.long)
+    for b in range(B):
+        ln = 6 + (5 * b) % (X - 8)
+        ids = 1000 + (np.arange(ln) * 7919 + b * 104729) % (cfg["vocab"] - 1000)
+        txt[b, 0] = 101
+        txt[b, 1:1 + ln] = torch.from_numpy(ids)
+        txt[b, 1 + ln] = 102
+    mask = (txt != 0).long()
+    return img, txt, mask
+
+
+# ----------------------------------------------------------------------------
+# Video-Swin helpers
+# ----------------------------------------------------------------------------
+def get_window_size(x_size, window_size, shift_size=None):
+    """video_swin.py:95-108"""
+    uw = list(window_size)
+    us = list(shift_size) if shift_size is not None else None
+    for i in range(len(x_size)):
+        if x_size[i] <= window_size[i]:
+            uw[i] = x_size[i]
+            if us is not None:
+                us[i] = 0
+    return tuple(uw) if us is None else (tuple(uw), tuple(us))
+
+
+def window_partition(x, ws):
+    """video_swin.py:84-88   (B,D,H,W,C) -> (B*nW, wd*wh*ww, C)"""
+    B, D, H, W, C = x.shape
+    x = x.reshape(B, D // ws[0], ws[0], H // ws[1], ws[1], W // ws[2], ws[2], C)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, ws[0] * ws[1] * ws[2], C)
+
+
+def window_reverse(w, ws, B, D, H, W):
+    """video_swin.py:90-93"""
+    x = w.reshape(B, D // ws[0], H // ws[1], W // ws[2], ws[0], ws[1], ws[2], -1)
+    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, -1)
+
+
+def compute_mask(D, H, W, ws, ss, dtype=torch.float32):
+    """video_swin.py:292-307   (nW, N, N) with 0 / -100"""
+    img_mask = torch.zeros((1, D, H, W, 1), dtype=dtype)
+    cnt = 0
+    for d in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
+        for h in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
+            for w in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
+                img_mask[:, d, h, w, :] = cnt
+                cnt += 1
+    mw = window_partition(img_mask, ws).squeeze(-1)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am))
+
+
+@lru_cache(maxsize=None)
+def relative_position_index(win):
+    """video_swin.py:123-137  (built for the CONFIGURED window, sliced [:N,:N] at use :155)"""
+    cd, ch, cw = torch.arange(win[0]), torch.arange(win[1]), torch.arange(win[2])
+    coords = torch.stack(torch.meshgrid(cd, ch, cw, indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += win[0] - 1
+    rel[:, :, 1] += win[1] - 1
+    rel[:, :, 2] += win[2] - 1
+    rel[:, :, 0] *= (2 * win[1] - 1) * (2 * win[2] - 1)
+    rel[:, :, 1] *= 2 * win[2] - 1
+    return rel.sum(-1)
+
+
+def layer_norm(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def window_attention(sd, p, x, mask, nh, win):
+    """WindowAttention3D.forward video_swin.py:147-172"""
+    B_, N, C = x.shape
+    qkv = F.linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(B_, N, 3, nh, C // nh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = q * (C // nh) ** -0.5
+    attn = q @ k.transpose(-2, -1)
+    idx = relative_position_index(tuple(win))[:N, :N].reshape(-1)
+    bias = sd[p + "relative_position_bias_table"][idx].reshape(N, N, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = attn.view(B_ // nW, nW, nh, N, N) + mask.to(attn.dtype).unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, nh, N, N)
+    attn = attn.softmax(-1)
+    x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    return F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def swin_block(sd, p, x, mask_matrix, nh, win_cfg, shift_cfg, dp_scale=None):
+    """SwinTransformerBlock3D.forward video_swin.py:206-263 ; dp_scale: (B,) DropPath scale or None (eval)."""
+    B, D, H, W, C = x.shape
+    ws, ss = get_window_size((D, H, W), win_cfg, shift_cfg)
+    shortcut = x
+    x = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    pd = (ws[0] - D % ws[0]) % ws[0]
+    pb = (ws[1] - H % ws[1]) % ws[1]
+    pr = (ws[2] - W % ws[2]) % ws[2]
+    x = F.pad(x, (0, 0, 0, pr, 0, pb, 0, pd))
+    _, Dp, Hp, Wp, _ = x.shape
+    if any(i > 0 for i in ss):
+        sx = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+        am = mask_matrix
+    else:
+        sx, am = x, None
+    xw = window_partition(sx, ws)
+    aw = window_attention(sd, p + "attn.", xw, am, nh, win_cfg)
+    sx = window_reverse(aw.view(-1, *(ws + (C,))), ws, B, Dp, Hp, Wp)
+    if any(i > 0 for i in ss):
+        x = torch.roll(sx, shifts=(ss[0], ss[1], ss[2]), dims=(1, 2, 3))
+    else:
+        x = sx
+    x = x[:, :D, :H, :W, :]
+    if dp_scale is not None:
+        x = x * dp_scale.view(B, 1, 1, 1, 1)
+    x = shortcut + x
+    y = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    y = F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+    y = F.gelu(y)
+    y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    if dp_scale is not None:
+        y = y * dp_scale.view(B, 1, 1, 1, 1)
+    return x + y
+
+
+def patch_merging(sd, p, x):
+    """PatchMerging.forward video_swin.py:273-289"""
+    B, D, H, W, C = x.shape
+    if H % 2 == 1 or W % 2 == 1:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x0 = x[:, :, 0::2, 0::2, :]
+    x1 = x[:, :, 1::2, 0::2, :]
+    x2 = x[:, :, 0::2, 1::2, :]
+    x3 = x[:, :, 1::2, 1::2, :]
+    x = torch.cat([x0, x1, x2, x3], -1)
+    x = layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    return F.linear(x, sd[p + "reduction.weight"])
+
+
+def patch_embed(sd, p, x):
+    """PatchEmbed3D.forward video_swin.py:390-407 ; x (B,3,D,H,W) -> channels-last (B,D,H/4,W/4,E)"""
+    _, _, D, H, W = x.shape
+    if W % PATCH[2] != 0:
+        x = F.pad(x, (0, PATCH[2] - W % PATCH[2]))
+    if H % PATCH[1] != 0:
+        x = F.pad(x, (0, 0, 0, PATCH[1] - H % PATCH[1]))
+    x = F.pad(x, (0, 0, 0, 0, 0, 1))                     # one zero frame at the END of D (:398)
+    x = F.conv3d(x, sd[p + "proj.weight"], sd[p + "proj.bias"], stride=(1, 4, 4))
+    x = x.permute(0, 2, 3, 4, 1)
+    return layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+
+
+def swin_forward(sd, cfg, x, dp_scales=None, prefix="enc_img.swin."):
+    """SwinTransformer3D.forward video_swin.py:470-482 + BasicLayer.forward :352-370.
+    x (B,3,T,H,W) -> channels-last (B,T,H/32,W/32,8E).  dp_scales: list per block of (B,) or None."""
+    win = tuple(cfg["window"])
+    shift = tuple(i // 2 for i in win)
+    x = patch_embed(sd, prefix + "patch_embed.", x)
+    blk = 0
+    for i, (d, nh) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        B, D, H, W, C = x.shape
+        ws, ss = get_window_size((D, H, W), win, shift)
+        Dp = int(np.ceil(D / ws[0])) * ws[0]
+        Hp = int(np.ceil(H / ws[1])) * ws[1]
+        Wp = int(np.ceil(W / ws[2])) * ws[2]
+        am = compute_mask(Dp, Hp, Wp, ws, ss, x.dtype)
+        for b in range(d):
+            x = swin_block(sd, prefix + f"layers.{i}.blocks.{b}.", x, am, nh, win,
+                           (0, 0, 0) if b % 2 == 0 else shift,
+                           None if dp_scales is None else dp_scales[blk])
+            blk += 1
+        if i < len(cfg["depths"]) - 1:
+            x = patch_merging(sd, prefix + f"layers.{i}.downsample.", x)
+    return layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)
+
+
+# ----------------------------------------------------------------------------
+# EncVideo / EncTxt / fusion encoder / heads
+# ----------------------------------------------------------------------------
+def enc_video(sd, cfg, img, dp_scales=None):
+    """EncVideo.forward model.py:32-78 ; img (B,T,3,H,W) -> feat (B,T*(1+hw),768), mask ones"""
+    B, T, _, H, W = img.shape
+    h, w = H // 32, W // 32
+    f = swin_forward(sd, cfg, img.transpose(1, 2), dp_scales)          # (B,T,h,w,8E)
+    f = f.reshape(B, T, h * w, -1)
+    if "enc_img.fc.weight" in sd:
+        f = F.linear(f, sd["enc_img.fc.weight"], sd["enc_img.fc.bias"])
+    f = torch.cat([sd["enc_img.emb_cls"].expand(B, T, -1, -1), f], dim=2)
+    f = f + sd["enc_img.emb_pos"][:, :, :1 + h * w, :]
+    f = f + sd["enc_img.emb_len"][:, :T, :, :]
+    f = layer_norm(f, sd["enc_img.norm.weight"], sd["enc_img.norm.bias"], 1e-5).reshape(B, T * (1 + h * w), -1)
+    m = torch.ones(B, T * (1 + h * w), dtype=torch.long)
+    return f, m
+
+
+def enc_txt(sd, txt):
+    """EncTxt.forward model.py:106-115 (embed_only) == HF BertEmbeddings (eval: no dropout)"""
+    B, X = txt.shape
+    p = "enc_txt.emb_txt."
+    e = sd[p + "word_embeddings.weight"][txt] + sd[p + "token_type_embeddings.weight"][0] \
+        + sd[p + "position_embeddings.weight"][:X].unsqueeze(0)
+    return layer_norm(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], BERT["eps"])
+
+
+def bert_layer(sd, p, x, add_mask):
+    """HF BertLayer (post-LN), eval mode; call site model.py:213"""
+    B, L, H = x.shape
+    nh, hd = BERT["heads"], H // BERT["heads"]
+    q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
+    k = F.linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"])
+    v = F.linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"])
+    q, k, v = (t.view(B, L, nh, hd).transpose(1, 2) for t in (q, k, v))
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd) + add_mask
+    a = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, L, H)
+    a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+    x = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], BERT["eps"])
+    y = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+    y = F.linear(y, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    return layer_norm(y + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT["eps"])
+
+
+def go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask_txt):
+    """VIOLET_Base.go_cross model.py:204-214 ; mask -> (1-m)*finfo.min, broadcast (B,1,1,L)"""
+    feat = torch.cat([feat_img, feat_txt], dim=1)
+    mask = torch.cat([mask_img, mask_txt], dim=1)
+    add = (1.0 - mask[:, None, None, :].to(feat.dtype)) * torch.finfo(feat.dtype).min
+    for l in range(cfg["bert_layers"]):
+        feat = bert_layer(sd, f"trsfr.layer.{l}.", feat, add)
+    return feat
+
+
+def mlm_head(sd, x):
+    """HF BertOnlyMLMHead ; call site main_pretrain.py:236"""
+    p = "fc_mtm.predictions."
+    x = F.gelu(F.linear(x, sd[p + "transform.dense.weight"], sd[p + "transform.dense.bias"]))
+    x = layer_norm(x, sd[p + "transform.LayerNorm.weight"], sd[p + "transform.LayerNorm.bias"], BERT["eps"])
+    return F.linear(x, sd[p + "decoder.weight"], sd[p + "bias"])
+
+
+def vtm_head(sd, x, temp):
+    """main_pretrain.py:146-147,260  Dropout(eval)->Linear->ReLU->Linear, /temp"""
+    x = F.relu(F.linear(x, sd["fc.1.weight"], sd["fc.1.bias"]))
+    return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"]) / temp
+
+
+def vtm_negatives_default(B):
+    """Deterministic stand-in for np.random.permutation (main_pretrain.py:250): negatives (B, O-1)."""
+    O = min(B, 4)
+    neg = np.zeros((B, max(O - 1, 0)), dtype=np.int64)
+    for i in range(B):
+        others = [j for j in range(B) if j != i]
+        for k in range(O - 1):
+            neg[i, k] = others[(i + k) % len(others)]
+    return neg
+
+
+def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None):
+    """VIOLET_Pretrain.forward main_pretrain.py:226-267 (eval mode / explicit negatives)."""
+    B, T, _, H, W = img.shape
+    h, w = H // cfg["size_patch"], W // cfg["size_patch"]
+    O = min(B, 4)
+    Lv = (1 + h * w) * T
+    feat_img, mask_img = enc_video(sd, cfg, img, dp_scales)
+    feat_txt = enc_txt(sd, txt)
+    out = go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask)
+    out_mtm = mlm_head(sd, out[:, Lv:])
+    out_mvm = out[:, :Lv]
+    if negatives is None:
+        negatives = vtm_negatives_default(B)
+    ii, jj = [], []
+    for i in range(B):
+        ii.append(i); jj.append(i)
+        for k in range(O - 1):
+            ii.append(i); jj.append(int(negatives[i][k]))
+    out2 = go_cross(sd, cfg, feat_img[ii], mask_img[ii], feat_txt[jj], mask[jj])
+    out_vtm = vtm_head(sd, out2[:, Lv, :], cfg["temp"]).reshape(B, O)
+    return dict(out_vtm=out_vtm, out_mvm=out_mvm, out_mtm=out_mtm, feat_img=feat_img, feat_txt=feat_txt,
+                ans_vtm=torch.zeros(B, dtype=torch.long))
+
+
+def pixel_loss(sd, cfg, out_mvm, unmask_img, mvm_mask):
+    """calc_mvm_loss pixel branch main_pretrain.py:420-432"""
+    B, T, Cin, H, W = unmask_img.shape
+    ps = cfg["size_patch"]
+    h, w = H // ps, W // ps
+    _, L, C = out_mvm.shape
+    l = L // T
+    x = torch.cat([out_mvm[:, l * t + 1:l * (t + 1), :] for t in range(T)], dim=1)     # drop per-frame cls
+    x = x.permute(0, 2, 1).reshape(B, C, T, h, w).permute(0, 2, 1, 3, 4).reshape(B * T, C, h, w)
+    x = F.conv2d(x, sd["decoder_pixel.0.weight"], sd["decoder_pixel.0.bias"])
+    x = F.pixel_shuffle(x, ps).view(B, T, Cin, H, W)
+    ls = (x - unmask_img).abs()
+    return (ls.float() * mvm_mask.float()).sum() / (mvm_mask.float().sum() + 1e-5) / Cin
+
+
+def cross_entropy_ignore(logits, target):
+    """T.nn.CrossEntropyLoss(ignore_index=-1) agent.py:57 (mean over non-ignored; NaN if none)"""
+    return F.cross_entropy(logits, target, ignore_index=-1)
+
+
+def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
+    """Agent_Pretrain.step main_pretrain.py:555-567 : ls = mtm + vtm + mvm"""
+    out = pretrain_forward(sd, cfg, batch["img"], batch["txt"], batch["mask"], negatives, dp_scales)
+    ls_mtm = cross_entropy_ignore(out["out_mtm"].flatten(0, 1), batch["ans_mtm"].flatten())
+    ls_vtm = cross_entropy_ignore(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = pixel_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"])
+    return dict(mtm=ls_mtm, vtm=ls_vtm, mvm=ls_mvm, total=ls_mtm + ls_vtm + ls_mvm, out=out)
+
+
+# ----------------------------------------------------------------------------
+# masking with explicit draws (Agent_Pretrain.masking main_pretrain.py:276-372)
+# ----------------------------------------------------------------------------
+SPECIAL = dict(cls=101, sep=102, pad=0, mask=103)
+
+
+def apply_masking(img, txt, mask, txt_sel, cov, size_patch=32):
+    """Deterministic core of masking(): given the random draws, build the batch dict.
+
+    txt_sel : (B,X) bool  -- rand(_X)<p_mask draw (special tokens are excluded here, :305/:346)
+    cov     : (B,T,h,w) {0,1} -- covered patches (from 'bm' cuboids :308-317 or 'rm' Bernoulli :348-352)
+    The x32 expansion is hard-coded in the reference (:362)."""
+    img = img.clone(); txt = txt.clone()
+    B, T, _, H, W = img.shape
+    orig = img.clone()
+    spc = (txt == SPECIAL["cls"]) | (txt == SPECIAL["sep"]) | (txt == SPECIAL["pad"]) | (txt == SPECIAL["mask"])
+    sel = txt_sel & ~spc
+    ans_mtm = torch.where(sel, txt, torch.full_like(txt, -1))
+    txt = torch.where(sel, torch.full_like(txt, SPECIAL["mask"]), txt)
+    c = cov.to(img.dtype)
+    full = c[:, :, None, :, None, :, None].expand(-1, -1, 3, -1, 32, -1, 32).reshape(B, T, 3, c.shape[2] * 32, c.shape[3] * 32)
+    img = img * (1.0 - full)
+    h, w = H // size_patch, W // size_patch
+    ans_mvm = torch.full((B, T * (1 + h * w)), -1, dtype=torch.long)
+    return dict(img=img, txt=txt, mask=mask, ans_mtm=ans_mtm, ans_mvm=ans_mvm, mvm_mask=full, unmask_img=orig)
+
+
+def bm_cover(T, h, w, draws):
+    """'bm' block masking: draws = list of T tuples (t,hh,ww,t1,h1,w1) (:308-317)."""
+    cov = torch.zeros(T, h, w)
+    for (t, hh, ww, t1, h1, w1) in draws:
+        cov[t1:t1 + t, h1:h1 + hh, w1:w1 + ww] = 1.0
+    return cov
+
+
+def default_masking(cfg, img, txt, mask, seed=0, p_mask=0.15):
+    """Seeded masking with the reference's distributions ('rm' for even samples, 'bm' for odd)."""
+    g = np.random.RandomState(seed)
+    B, T, _, H, W = img.shape
+    h, w = H // cfg["size_patch"], W // cfg["size_patch"]
+    X = txt.shape[1]
+    sel = torch.from_numpy(g.rand(B, X) < p_mask)
+    cov = torch.zeros(B, T, h, w)
+    for b in range(B):
+        if b % 2 == 0:
+            cov[b] = torch.from_numpy((g.rand(T, h, w) < p_mask).astype(np.float32))
+        else:
+            draws = []
+            for _ in range(T):
+                t = g.randint(1, T) if T > 1 else 1
+                hh, ww = g.randint(1, h * 2 // 3), g.randint(1, w * 2 // 3)
+                draws.append((t, hh, ww, g.randint(0, T - t + 1), g.randint(0, h - hh + 1), g.randint(0, w - ww + 1)))
+            cov[b] = bm_cover(T, h, w, draws)
+    return apply_masking(img, txt, mask, sel, cov, cfg["size_patch"])
+
+
+# ----------------------------------------------------------------------------
+# optimizer / schedule (agent.py:13-32, 84-113, 181-193)
+# ----------------------------------------------------------------------------
+def param_group_of(name):
+    """agent.py:86-95 : (is_swin, no_decay) by SUBSTRING match."""
+    no_decay = any(nd in name for nd in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
+    return ("swin." in name), no_decay
+
+
+def lr_factor(step, max_iter, warmup_ratio=0.1):
+    """WarmupLinearLR.get_lr_factor agent.py:22-28 (step = scheduler.last_epoch)"""
+    warm = int(warmup_ratio * max_iter)
+    if step < warm:
+        return max(0.0, step / warm)
+    step = min(step, max_iter)
+    return max(0.0, (max_iter - step) / (max_iter - warm))
+
+
+def lr_at(step, base_lr, max_iter, min_lr=1e-8):
+    return max(min_lr, base_lr * lr_factor(step, max_iter))
+
+
+def clip_coef(total_norm, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (agent.py:188): coef = clamp(max_norm/(norm+1e-6), max=1)"""
+    return min(1.0, max_norm / (total_norm + 1e-6))
+
+
+def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.98, eps=1e-8):
+    """torch.optim.AdamW single-tensor math (agent.py:111-112); step is 1-based. In-place on p,m,v."""
+    p.mul_(1.0 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+    return p
+
+
+def train_step(sd, cfg, batch, opt_state, step, max_iter, negatives=None, lr=5e-5, decay=1e-3,
+               lr_mul=1.0, max_grad_norm=1.0):
+    """One full optimizer step in the reference's order (agent.py:181-193, fp32, no GradScaler):
+    forward -> loss -> backward -> clip -> AdamW at lr(step-1 scheduler state) -> returns losses."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    ls = pretrain_losses(params, cfg, batch, negatives)
+    ls["total"].backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for k, g in grads.items() if params[k].grad is not None))
+    coef = clip_coef(tot, max_grad_norm) if max_grad_norm > 0 else 1.0
+    cur = lr_at(step - 1, lr, max_iter)            # scheduler ctor did step 0
+    for k in sd:
+        if params[k].grad is None:
+            continue
+        is_swin, nd = param_group_of(k)
+        st = opt_state.setdefault(k, dict(m=torch.zeros_like(sd[k]), v=torch.zeros_like(sd[k])))
+        adamw_step(sd[k], grads[k] * coef, st["m"], st["v"], step, cur * (lr_mul if is_swin else 1.0), 0.0 if nd else decay)
+    return dict(mtm=float(ls["mtm"]), vtm=float(ls["vtm"]), mvm=float(ls["mvm"]), grad_norm=tot, grads=grads)

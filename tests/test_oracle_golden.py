@@ -1,0 +1,150 @@
+"""Pin the CPU oracle (oracle/violet_ref.py) against outputs of the REFERENCE itself
+(tests/golden/*.npz, produced by tools/gen_goldens.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import violet_ref as R
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def check_samp(d, name, t, rtol=2e-4, atol=2e-5):
+    f = t.detach().double().flatten().numpy()
+    assert tuple(d[f"{name}.shape"]) == tuple(t.shape), name
+    np.testing.assert_allclose(f[d[f"{name}.idx"]], d[f"{name}.val"], rtol=rtol, atol=atol, err_msg=name)
+    asum = float(d[f"{name}.asum"])
+    assert abs(np.abs(f).sum() - asum) <= 2e-4 * asum + 1e-4, (name, np.abs(f).sum(), asum)
+
+
+def test_helpers_known_answers():
+    d = load("helpers.npz")
+    x = torch.arange(1 * 8 * 14 * 14 * 2, dtype=torch.float32).view(1, 8, 14, 14, 2)
+    w = R.window_partition(x, (8, 7, 7))
+    assert tuple(w.shape) == tuple(d["wp_shape"]) == (4, 392, 2)
+    assert w[1, 0].tolist() == [14.0, 15.0] and w[2, 5].tolist() == [206.0, 207.0]
+    np.testing.assert_array_equal(w.numpy().astype(np.int32), d["wp_full"])
+    assert torch.equal(R.window_reverse(w, (8, 7, 7), 1, 8, 14, 14), x)
+    for name, (D, H, W, ws, ss) in dict(a=(8, 14, 14, (8, 7, 7), (0, 3, 3)), b=(16, 12, 12, (8, 12, 12), (4, 0, 0)),
+                                        c=(16, 28, 21, (8, 7, 7), (4, 3, 3))).items():
+        m = R.compute_mask(D, H, W, ws, ss)
+        assert tuple(m.shape) == tuple(d[f"mask_{name}_shape"])
+        assert int((m == -100).sum()) == int(d[f"mask_{name}_n100"])
+        np.testing.assert_array_equal((m == -100).sum(-1).numpy(), d[f"mask_{name}_rowsum"])
+    assert int(d["mask_a_n100"]) == 264192 and int(d["mask_b_n100"]) == 663552     # SURVEY section 4 probes
+    assert R.get_window_size((4, 56, 56), (8, 7, 7), (4, 3, 3)) == ((4, 7, 7), (0, 3, 3))
+    np.testing.assert_array_equal(np.array(R.get_window_size((16, 12, 12), (8, 12, 12), (4, 6, 6))), d["gws_b"])
+    np.testing.assert_array_equal(R.relative_position_index((8, 7, 7)).numpy(), d["rpi_877"])
+    np.testing.assert_array_equal(R.relative_position_index((2, 3, 3)).numpy(), d["rpi_233"])
+
+
+def test_reduced_swin_fwd_and_grads():
+    d = load("reduced_swin.npz")
+    arch = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    cfg = R.make_cfg("tiny", T=12, arch=arch)
+    sd = {k: R.closed_form(k, s).requires_grad_(True) for k, s in R.param_shapes(cfg).items() if k.startswith("enc_img.swin.")}
+    n = 1 * 3 * 12 * 96 * 80
+    x = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(1, 3, 12, 96, 80) * 1.5).float()
+    y = R.swin_forward(sd, cfg, x)                      # channels-last (B,D,H,W,C)
+    check_samp(d, "y", y)
+    yc = y.permute(0, 4, 1, 2, 3).contiguous()         # the reference weights the NCDHW tensor
+    (yc * torch.cos(torch.arange(yc.numel(), dtype=torch.float32).view_as(yc) * 0.01)).sum().backward()
+    for k, p in sd.items():
+        check_samp(d, "g." + k[len("enc_img.swin."):], p.grad, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.timeout(600)
+def test_c1_end_to_end_losses_and_grads():
+    """Config C1: Swin-tiny, T=4, 224^2, B=2, pixel target, eval mode, explicit masks + negatives."""
+    d = load("c1.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    sd = R.make_state_dict(cfg)
+    nparam = sum(v.numel() for v in sd.values())
+    assert nparam == int(d["nparam"])
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 2)
+    batch = R.default_masking(cfg, img, txt, mask, seed=3)
+    ls = R.pretrain_losses(params, cfg, batch, negatives=d["neg"])
+    np.testing.assert_allclose(float(ls["mtm"]), float(d["ls_mtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["vtm"]), float(d["ls_vtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["mvm"]), float(d["ls_mvm"]), rtol=1e-5)
+    np.testing.assert_allclose(ls["out"]["out_vtm"].detach().numpy(), d["out_vtm"], rtol=1e-4, atol=1e-4)
+    check_samp(d, "out_mtm", ls["out"]["out_mtm"])
+    check_samp(d, "out_mvm", ls["out"]["out_mvm"])
+    ls["total"].backward()
+    gsq = 0.0
+    nograd = []
+    for k, p in params.items():
+        if p.grad is None:
+            nograd.append(k)
+            continue
+        gsq += float((p.grad.double() ** 2).sum())
+        check_samp(d, "g." + k, p.grad, rtol=5e-3, atol=1e-5)
+    assert nograd == list(d["nograd"]) == ["enc_img.emb_odr"]
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
+
+
+def test_masking_geometry():
+    """Replays the reference's global-RNG draw ORDER for 'rm' and 'bm' (main_pretrain.py:303-352)."""
+    import random
+    d = load("masking.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    img, txt, mask = R.make_batch(cfg, 3)
+    B, T, h, w, X = 3, 4, 7, 7, 32
+    for name in ("rm", "bm"):
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        sel = torch.zeros(B, X, dtype=torch.bool)
+        cov = torch.zeros(B, T, h, w)
+        for b in range(B):
+            random.choice([name])
+            sel[b] = torch.rand(X) < 0.15
+            if name == "bm":
+                draws = []
+                for _ in range(T):
+                    t, hh, ww = np.random.randint(1, T), np.random.randint(1, h * 2 // 3), np.random.randint(1, w * 2 // 3)
+                    draws.append((t, hh, ww, np.random.randint(0, T - t + 1), np.random.randint(0, h - hh + 1), np.random.randint(0, w - ww + 1)))
+                cov[b] = R.bm_cover(T, h, w, draws)
+            else:
+                r = torch.rand((1 + h * w) * T) < 0.15
+                cov[b] = r.view(T, 1 + h * w)[:, 1:].reshape(T, h, w).float()
+        o = R.apply_masking(img, txt, mask, sel, cov)
+        np.testing.assert_array_equal(cov.numpy().astype(np.uint8), d[f"{name}.cov"])
+        np.testing.assert_array_equal(o["txt"].numpy(), d[f"{name}.txt"])
+        np.testing.assert_array_equal(o["ans_mtm"].numpy(), d[f"{name}.ans_mtm"])
+        np.testing.assert_array_equal(o["ans_mvm"].numpy(), d[f"{name}.ans_mvm"])
+        np.testing.assert_allclose(float(o["img"].double().sum()), float(d[f"{name}.img_sum"]), rtol=1e-9)
+        np.testing.assert_allclose(float(o["mvm_mask"].double().sum()), float(d[f"{name}.mask_sum"]), rtol=0)
+        assert torch.equal(o["unmask_img"], img)
+
+
+def test_optimizer_groups_schedule_adamw():
+    d = load("optimizer.npz")
+    names = [str(n) for n in d["names"]]
+    # group membership: [decay_swin, decay_other, nodecay_swin, nodecay_other]
+    for n, row in zip(names, d["groups"]):
+        sw, nd = R.param_group_of(n)
+        assert int(np.argmax(row)) == (2 if nd else 0) + (0 if sw else 1), n
+    assert R.param_group_of("enc_img.swin.layers.0.blocks.0.norm1.weight") == (True, False)      # Swin norm weight IS decayed
+    assert R.param_group_of("enc_img.swin.layers.0.blocks.0.attn.relative_position_bias_table") == (True, True)
+    for k, lr in d["lr_table"]:
+        np.testing.assert_allclose(R.lr_at(int(k), 5e-5, 1000), lr, rtol=1e-9)
+    ps = [R.closed_form(n, (6,)) * 10 for n in names]
+    ms = [torch.zeros(6) for _ in names]
+    vs = [torch.zeros(6) for _ in names]
+    for step in range(1, 4):
+        gs = [R.closed_form(n + f".g{step}", (6,)) * 30 for n in names]
+        tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gs)))
+        np.testing.assert_allclose(tot, float(d[f"norm{step}"]), rtol=1e-6)
+        coef = R.clip_coef(tot, 1.0)
+        for i, n in enumerate(names):
+            sw, nd = R.param_group_of(n)
+            lr = R.lr_at(step - 1, 5e-5 * (2.0 if sw else 1.0), 20)
+            np.testing.assert_allclose(lr, d["lrs"][step - 1][(2 if nd else 0) + (0 if sw else 1)], rtol=1e-9)
+            R.adamw_step(ps[i], gs[i] * coef, ms[i], vs[i], step, lr, 0.0 if nd else 1e-3)
+        np.testing.assert_allclose(torch.stack(ps).numpy(), d[f"p{step}"], rtol=1e-6, atol=1e-7)

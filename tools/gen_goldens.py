@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (CPU, fp32).
+
+Runs ONLY in the build container (needs /root/reference); the reference never
+travels to the GPU box -- only the small output fixtures written here do.
+Import recipe = SURVEY.md section 8(c).  Weights/inputs are the closed-form tensors of
+oracle/violet_ref.py, so fixtures hold outputs only.
+
+    python tools/gen_goldens.py            # writes tests/golden/*.npz
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import transformers  # noqa: F401  (must be imported before the stubs)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import violet_ref as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ stubs
+class _AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _stub(name, **attrs):
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class Dict(dict):  # addict.Dict: nested attr dict
+        def __init__(self, *a, **k):
+            super().__init__()
+            for kk, vv in dict(*a, **k).items():
+                self[kk] = vv
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, Dict):
+                v = Dict(v)
+            super().__setitem__(k, v)
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def to_dict(self):
+            return {k: (v.to_dict() if isinstance(v, Dict) else v) for k, v in self.items()}
+
+    _stub("addict", Dict=Dict)
+    _stub("yapf"); _stub("yapf.yapflib"); _stub("yapf.yapflib.yapf_api", FormatCode=lambda s, **k: (s, True))
+    _stub("easydict", EasyDict=_AttrDict)
+    _stub("skimage"); _stub("skimage.feature", hog=None); _stub("skimage.transform")
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", Normalize=object, Compose=object)
+    tv.models = _stub("torchvision.models")
+    _stub("torchvision.models.optical_flow", raft_large=None)
+    _stub("cv2")
+    _stub("fairscale"); _stub("fairscale.nn"); _stub("fairscale.nn.misc", checkpoint_wrapper=lambda m, **k: m)
+    _stub("toolz"); _stub("toolz.sandbox", unzip=None)
+    _stub("deepspeed")
+    _stub("tensorboardX", SummaryWriter=object)
+    _stub("timm"); _stub("timm.models"); _stub("timm.models.layers", DropPath=object, to_2tuple=None, trunc_normal_=None)
+    _stub("wandb")
+    _stub("dataset", Dataset_Base=object, get_dl=None, move_to_cuda=lambda b: b, get_tsv_dls=None,
+          MetaLoader=object, PrefetchLoader=object)
+    os.environ["WANDB_ENABLE"] = "0"
+
+
+def import_reference():
+    import transformers as tr
+    from transformers import BertConfig, BertForMaskedLM, BertModel  # noqa: F401
+    _ = (tr.AutoModel, tr.AutoModelForMaskedLM, tr.AutoTokenizer, tr.AutoConfig, tr.RobertaForMaskedLM)
+    install_stubs()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    from transformers import BertConfig, BertForMaskedLM, BertModel
+    import transformers as tr
+    mk = lambda cls: (lambda *a, **k: cls(BertConfig(attn_implementation="eager")))
+    tr.AutoModel.from_pretrained = staticmethod(mk(BertModel))
+    tr.AutoModelForMaskedLM.from_pretrained = staticmethod(mk(BertForMaskedLM))
+
+
+def ref_args(size, T, mvm_target="pixel"):
+    a = _AttrDict(json.load(open(os.path.join(REF, "_args/args_pretrain.json"))))
+    a.update(mvm_target=[mvm_target], vis_backbone_size=size, vis_backbone_init="random", size_patch=32,
+             max_size_frame=max(T, 6), max_size_patch=14, temporal_fusion="vidswin", fusion_encoder_rand_init=False,
+             use_checkpoint=False, deepspeed=False, tokenizer="bert-base-uncased", dalle_model_path="",
+             max_iter=100, enable_task_token=False, enable_prompt=False, size_frame=T, kinetics=600)
+    return a
+
+
+def samp(t, n=64):
+    """n deterministic sample positions of a tensor + its sum and abs-sum."""
+    f = t.detach().double().flatten()
+    idx = np.unique((np.arange(n, dtype=np.int64) * 7919 + 13) % f.numel())
+    return dict(idx=idx, val=f[idx].numpy(), sum=float(f.sum()), asum=float(f.abs().sum()), shape=np.array(t.shape))
+
+
+def put(d, name, t, n=64):
+    for k, v in samp(t, n).items():
+        d[f"{name}.{k}"] = v
+
+
+# ------------------------------------------------------------------ golden sets
+def gold_helpers(vs):
+    d = {}
+    x = torch.arange(1 * 8 * 14 * 14 * 2, dtype=torch.float32).view(1, 8, 14, 14, 2)
+    w = vs.window_partition(x, (8, 7, 7))
+    d["wp_shape"] = np.array(w.shape); d["wp_1_0"] = w[1, 0].numpy(); d["wp_2_5"] = w[2, 5].numpy()
+    d["wp_full"] = w.numpy().astype(np.int32)
+    r = vs.window_reverse(w, (8, 7, 7), 1, 8, 14, 14)
+    d["wr_equal"] = np.array(int(torch.equal(r, x)))
+    for name, (D, H, W, ws, ss) in dict(a=(8, 14, 14, (8, 7, 7), (0, 3, 3)), b=(16, 12, 12, (8, 12, 12), (4, 0, 0)),
+                                        c=(16, 28, 21, (8, 7, 7), (4, 3, 3))).items():
+        m = vs.compute_mask(D, H, W, ws, ss, "cpu")
+        d[f"mask_{name}_shape"] = np.array(m.shape)
+        d[f"mask_{name}_n100"] = np.array(int((m == -100).sum()))
+        d[f"mask_{name}_rowsum"] = (m == -100).sum(-1).numpy().astype(np.int32)
+    d["gws_a"] = np.array(vs.get_window_size((4, 56, 56), (8, 7, 7), (4, 3, 3)))
+    d["gws_b"] = np.array(vs.get_window_size((16, 12, 12), (8, 12, 12), (4, 6, 6)))
+    att = vs.WindowAttention3D(32, (8, 7, 7), 1)
+    d["rpi_877"] = att.relative_position_index.numpy().astype(np.int32)
+    att = vs.WindowAttention3D(32, (2, 3, 3), 1)
+    d["rpi_233"] = att.relative_position_index.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "helpers.npz"), **d)
+    print("helpers ok")
+
+
+def gold_reduced_swin(vs):
+    """Reduced Swin: exercises D-pad 12->16, temporal shift 4, H/W pad 24x20 -> 28x21."""
+    arch = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    cfg = R.make_cfg("tiny", T=12, arch=arch)
+    m = vs.SwinTransformer3D(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                             patch_size=(2, 4, 4)).eval()
+    shapes = {k: v for k, v in R.param_shapes(cfg).items() if k.startswith("enc_img.swin.")}
+    sd = {k[len("enc_img.swin."):]: R.closed_form(k, s) for k, s in shapes.items()}
+    own = {k: v.shape for k, v in m.state_dict().items() if "relative_position_index" not in k}
+    assert {k: tuple(v) for k, v in own.items()} == {k: tuple(v.shape) for k, v in sd.items()}, "key/shape mismatch"
+    m.load_state_dict(sd, strict=False)
+    n = 1 * 3 * 12 * 96 * 80
+    x = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(1, 3, 12, 96, 80) * 1.5).float()
+    y = m(x)
+    d = {}
+    put(d, "y", y.permute(0, 2, 3, 4, 1).contiguous(), 256)
+    (y * torch.cos(torch.arange(y.numel(), dtype=torch.float32).view_as(y) * 0.01)).sum().backward()
+    for k, p in m.named_parameters():
+        put(d, "g." + k, p.grad, 16)
+    np.savez_compressed(os.path.join(OUT, "reduced_swin.npz"), **d)
+    print("reduced swin ok", tuple(y.shape))
+
+
+def build_ref_model(size, T):
+    import main_pretrain as mp
+    args = ref_args(size, T)
+    model = mp.VIOLET_Pretrain(args, None).eval()
+    # 4.26 semantics for the two API-drift points
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc = model.trsfr
+    class _Wrap(torch.nn.Module):
+        def __init__(s, e):
+            super().__init__(); s.e = e
+        def forward(s, feat, mask, output_attentions=False):
+            o = s.e(feat, attention_mask=mask)
+            return {"last_hidden_state": o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state, "attentions": ()}
+    object.__setattr__(model, "_enc_wrap", _Wrap(enc))
+    model.__dict__["trsfr_call"] = model._enc_wrap
+    return mp, args, model
+
+
+def gold_c1(size="tiny", T=4, B=2, tag="c1"):
+    mp, args, model = build_ref_model(size, T)
+    cfg = R.make_cfg(size, T=T)
+    sd = R.make_state_dict(cfg)
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss
+    extra = [k for k in own if k not in sd and "relative_position_index" not in k and "position_ids" not in k
+             and "token_type_ids" not in k and k != "fc_mtm.predictions.decoder.bias"]
+    assert not extra, extra
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+    model.load_state_dict(sd, strict=False)
+    nparam = sum(p.numel() for p in model.parameters())
+    # route trsfr through the wrapper without renaming parameters
+    wrap = model._enc_wrap
+    orig_go_cross = model.go_cross
+    def go_cross(feat_img, mask_img, feat_txt, mask_txt, **kw):
+        feat = torch.cat([feat_img, feat_txt], dim=1)
+        mask = model.get_attn_mask(mask_img, mask_txt)
+        mask = model.mask_ext(mask)
+        out = wrap(feat, mask)
+        return out["last_hidden_state"], out["attentions"]
+    model.go_cross = go_cross
+
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=3)
+    neg = R.vtm_negatives_default(B)
+    # make np.random.permutation return our explicit negatives (main_pretrain.py:250)
+    calls = {"i": 0}
+    def fake_perm(lst):
+        i = calls["i"]; calls["i"] += 1
+        rest = [j for j in lst if j not in list(neg[i])]
+        return np.array(list(neg[i]) + rest)
+    mp.np.random.permutation = fake_perm
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    batch = dict(mb)
+    out = model(batch)
+    ls_mtm = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    ls_vtm = agent.loss_func(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = agent.calc_mvm_loss(batch, out["out_mvm"], is_train=True)
+    ls = ls_mtm + ls_vtm + ls_mvm
+    ls.backward()
+    d = dict(nparam=np.array(nparam), ls_mtm=np.array(float(ls_mtm)), ls_vtm=np.array(float(ls_vtm)),
+             ls_mvm=np.array(float(ls_mvm)), out_vtm=out["out_vtm"].detach().numpy(), neg=neg)
+    put(d, "out_mtm", out["out_mtm"], 256)
+    put(d, "out_mvm", out["out_mvm"], 256)
+    gsq = 0.0
+    nograd = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(k); continue
+        gsq += float((p.grad.double() ** 2).sum())
+        put(d, "g." + k, p.grad, 8)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    d["nograd"] = np.array(nograd)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "ok nparam", nparam, "losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5, "nograd", nograd)
+    return mp, agent
+
+
+def gold_masking(mp, agent):
+    """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
+    import random
+    cfg = R.make_cfg("tiny", T=4)
+    img, txt, mask = R.make_batch(cfg, 3)
+    agent.cls_token_id, agent.sep_token_id, agent.pad_token_id, agent.mask_token_id = 101, 102, 0, 103
+    d = {}
+    for name, masks in (("rm", ["rm"]), ("bm", ["bm"])):
+        agent.args.pretrain_masks = masks
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        o = agent.masking(img.clone(), txt.clone(), mask.clone(), None)
+        cov = o["mvm_mask"][:, :, 0, ::32, ::32]
+        d[f"{name}.cov"] = cov.numpy().astype(np.uint8)
+        d[f"{name}.txt"] = o["txt"].numpy(); d[f"{name}.ans_mtm"] = o["ans_mtm"].numpy()
+        d[f"{name}.ans_mvm"] = o["ans_mvm"].numpy()
+        d[f"{name}.img_sum"] = np.array(float(o["img"].double().sum()))
+        d[f"{name}.mask_sum"] = np.array(float(o["mvm_mask"].double().sum()))
+        d[f"{name}.unmask_equal"] = np.array(int(torch.equal(o["unmask_img"], img)))
+    np.savez_compressed(os.path.join(OUT, "masking.npz"), **d)
+    print("masking ok")
+
+
+def gold_optimizer():
+    """3 AdamW + WarmupLinearLR steps on a toy with one name from each of the 4 groups (agent.py:84-113)."""
+    import agent as ag
+    names = ["enc_img.swin.layers.0.blocks.0.mlp.fc1.weight", "trsfr.layer.0.output.dense.weight",
+             "enc_img.swin.layers.0.blocks.0.attn.relative_position_bias_table", "trsfr.layer.0.output.LayerNorm.weight",
+             "enc_img.swin.layers.0.blocks.0.norm1.weight"]
+    class Toy(torch.nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.ps = torch.nn.ParameterDict()
+        def named_parameters(s, *a, **k):
+            return [(n, s.ps[n.replace(".", "_")]) for n in names]
+        def parameters(s, *a, **k):
+            return [p for _, p in s.named_parameters()]
+    toy = Toy()
+    for n in names:
+        toy.ps[n.replace(".", "_")] = torch.nn.Parameter(R.closed_form(n, (6,)) * 10)
+    A = ag.Agent_Base.__new__(ag.Agent_Base)
+    A.args = _AttrDict(decay=1e-3, vis_backbone_lr_mul=2.0, lr=5e-5, max_grad_norm=1.0, deepspeed=False)
+    A.model = toy
+    A.optzr = A.build_optimizer()
+    sched = ag.WarmupLinearLR(A.optzr, 20)
+    d = {"names": np.array(names)}
+    d["groups"] = np.array([[any(p is q for q in g["params"]) for g in A.optzr.param_groups] for _, p in toy.named_parameters()])
+    lrs = []
+    for step in range(1, 4):
+        for i, (n, p) in enumerate(toy.named_parameters()):
+            p.grad = R.closed_form(n + f".g{step}", (6,)) * 30
+        tot = torch.nn.utils.clip_grad_norm_(toy.parameters(), 1.0)
+        lrs.append([g["lr"] for g in A.optzr.param_groups])
+        A.optzr.step(); sched.step(); A.optzr.zero_grad()
+        d[f"norm{step}"] = np.array(float(tot))
+        d[f"p{step}"] = np.stack([p.detach().numpy() for _, p in toy.named_parameters()])
+    d["lrs"] = np.array(lrs)
+    s2 = ag.WarmupLinearLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=5e-5), 1000)
+    tab = []
+    for k in range(0, 1001):
+        if k in (0, 1, 50, 100, 101, 500, 999, 1000):
+            tab.append((k, s2.get_last_lr()[0]))
+        s2.optimizer.step(); s2.step()
+    d["lr_table"] = np.array(tab)
+    np.savez_compressed(os.path.join(OUT, "optimizer.npz"), **d)
+    print("optimizer ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import_reference()
+    from visbackbone import video_swin as vs
+    gold_helpers(vs)
+    gold_reduced_swin(vs)
+    mp, agent = gold_c1("tiny", 4, 2, "c1")
+    gold_masking(mp, agent)
+    gold_optimizer()
