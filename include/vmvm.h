@@ -1,0 +1,215 @@
+/* vmvm.h -- C ABI of libvmvm.so: the MI355X (gfx950) kernels of the VIOLETv2 pretraining step.
+ *
+ * The reference (tsujuifu/pytorch_empirical-mvm) is 100% Python/ATen and has no FFI; the
+ * boundary below is the one SURVEY.md section 8(b).4 defines.  Each entry point names the reference
+ * code whose arithmetic it replaces (file:line relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers / sizes only, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - returns 0 on success or a negative VMVM_E* code; never throws;
+ *   - never allocates or frees device memory; never synchronises; enqueues on `stream`
+ *     (a hipStream_t passed as void*) and returns;
+ *   - re-entrant, no mutable globals; RNG = Philox4x32-7 keyed by (seed, offset) arguments;
+ *   - bf16 = raw uint16 storage ("bf16" in comments), f32 = float.
+ */
+#ifndef VMVM_H
+#define VMVM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMVM_OK 0
+#define VMVM_EINVAL (-1)
+#define VMVM_ENOSUPPORT (-2)
+#define VMVM_EHIP (-3)
+
+/* library version, (major<<16)|minor */
+int vmvm_version(void);
+/* last hipError_t seen by this thread's failing launch (diagnostics only) */
+int vmvm_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )   bf16 x bf16 -> f32 accumulate (MFMA).
+ * Replaces every nn.Linear / 1x1 conv forward, dgrad and wgrad on the path:
+ *   video_swin.py:75-81 (Mlp), :147-172 (qkv/proj), :285-287 (PatchMerging.reduction),
+ *   :401 (PatchEmbed3D.proj as im2col GEMM), model.py:39 (EncVideo.fc), HF BertLayer dense layers
+ *   (call site model.py:213), main_pretrain.py:146-147 (fc), :178 (decoder_pixel 1x1 conv),
+ *   HF BertOnlyMLMHead (call site main_pretrain.py:236).
+ * Operand layouts:  a_kmajor=1: A is [M][lda] (k contiguous);  a_kmajor=0: A is [K][lda] (m contiguous)
+ *                   b_kmajor=1: B is [N][ldb] (k contiguous);  b_kmajor=0: B is [K][ldb] (n contiguous)
+ *   forward  Y=X W^T : (1,1)      dgrad dX=dY W : (1,0)      wgrad dW=dY^T X : (0,0)
+ * Every contiguous extent (K for k-major, M/N for m/n-major, ld*) must be a multiple of 8; N%4==0.
+ * Epilogue order: v = acc; v *= col_scale (n < col_scale_n); v += bias[n];
+ *   act (0 none, 1 GELU-erf [C2 receives the pre-activation], 2 ReLU, 3 multiply by GELU'(aux[m,n]),
+ *        4 multiply by (aux[m,n] > 0));
+ *   v *= row_scale[m/rows_per_scale] ; dropout(p, Philox(seed, offset + m*N+n)) ; + resid[dst,n] ; store at row dst where
+ *   dst = row_map ? row_map[m % map_len] + (m / map_len) * map_stride : m   (dst < 0 -> row skipped).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int32_t M, N, K, lda, ldb, ldc;
+  int32_t a_kmajor, b_kmajor;
+  const float* bias;
+  const float* row_scale; int32_t rows_per_scale;
+  int32_t scale_bias_only;  /* 1: row_scale multiplies the bias only (DropPath 'producer' form: A rows are pre-scaled) */
+  int32_t act;
+  const void* aux; int32_t ldaux;
+  void* C2; int32_t ldc2;
+  const void* resid; int32_t ldr;
+  const int32_t* row_map; int32_t map_len, map_stride;
+  int32_t out_fp32;       /* C is f32 (else bf16) */
+  int32_t accumulate;     /* C += (f32 output only) */
+  float col_scale; int32_t col_scale_n;
+  float dropout_p; uint64_t seed, offset;
+  int32_t variant;        /* 0 = default; 1 = force scalar (non-transposing-read) LDS path */
+} vmvm_gemm_desc;
+int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
+
+/* column sums  out[n] (+)= sum_m scale[m/rows_per_scale] * X[m,n]   (bias gradients)  X bf16 [M][ldx], out f32 */
+int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale,
+                     int32_t rows_per_scale, float* out, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather-LayerNorm.  Output row m (width C = nseg*Cseg) = LN( concat_s  X[src[m*nseg+s], 0:Cseg] ).
+ *   src == NULL -> identity (plain LayerNorm: video_swin.py:404,478; HF BertLayer LayerNorms; model.py:71)
+ *   nseg=1, src = window map  -> norm1 + pad + roll + window_partition   (video_swin.py:206-229,84-88);
+ *                                 src<0 rows are written as ZEROS (F.pad happens after norm1, :216)
+ *   nseg=4, src = 2x2 map     -> PatchMerging gather+cat+norm (video_swin.py:273-286);
+ *                                 src<0 segments enter the LN as zeros (F.pad before norm, :277)
+ * `rows_in_per_batch`/`rows_out_per_batch`: src is given for one clip and re-based per clip.
+ * Saves mean/rstd (f32 [M]) for the backward.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* X; int32_t ldx;            /* bf16 input rows */
+  void* Y; int32_t ldy;                  /* bf16 output [M][C] */
+  const float* gamma; const float* beta; float eps;
+  int32_t M, C, nseg;
+  const int32_t* src; int32_t rows_out_per_batch, rows_in_per_batch;
+  int32_t pad_mode;                      /* 0: src<0 -> zero OUTPUT row ; 1: src<0 -> zero INPUT segment */
+  float* mean; float* rstd;
+} vmvm_ln_fwd_desc;
+int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream);
+
+typedef struct {
+  const void* dY; int32_t lddy;          /* bf16 [M][C] */
+  const void* X; int32_t ldx;            /* the forward input rows (gathered the same way) */
+  const float* gamma; const float* mean; const float* rstd;
+  void* dX; int32_t lddx;                /* bf16, scattered to the source rows (each written once) */
+  float* dgamma; float* dbeta;           /* f32 [C], ACCUMULATED (atomics) */
+  int32_t M, C, nseg;
+  const int32_t* src; int32_t rows_out_per_batch, rows_in_per_batch;
+  int32_t pad_mode;
+  const void* dX_add; int32_t ldadd;     /* optional bf16, indexed like dX (source rows): dX = LNbwd + dX_add (residual gradient) */
+  /* optional second output dX2 = dropout_mask(seed, offset + m*C+c) * dX / (1-p)  (HF hidden dropout backward) */
+  void* dX2; int32_t lddx2; float dropout_p; uint64_t seed, offset;
+} vmvm_ln_bwd_desc;
+int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention over short sequences (whole K/V of one (sequence, head) resident in LDS).
+ *   mode 0: Video-Swin window attention  (WindowAttention3D.forward video_swin.py:147-172):
+ *           S = q k^T (q pre-scaled by the qkv GEMM epilogue) + table[rc[i]-rc[j]+rc0][h]
+ *               + (region[w][i] != region[w][j] ? -100 : 0) ; softmax ; P v.   head_dim 32.
+ *   mode 1: BERT self-attention (HF BertSelfAttention, call site model.py:213):
+ *           S = q k^T * scale + (keymask[b][j] ? 0 : -inf) ; softmax ; dropout(p) ; P v.   head_dim 64.
+ * qkv: bf16 [nseq*L][ld_qkv], q at column q_off + h*hd, k at k_off + h*hd, v at v_off + h*hd.
+ * out: bf16 [nseq*L][ld_out] column h*hd.   lse: f32 [nseq][heads][L] (log-sum-exp per query row).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* qkv; int32_t ld_qkv, q_off, k_off, v_off;
+  void* out; int32_t ld_out;
+  float* lse;
+  int32_t nseq, L, heads, head_dim, mode;
+  float scale;
+  /* mode 0 */
+  const float* bias_table; int32_t table_len;   /* [table_len][heads] f32 */
+  const int32_t* rc; int32_t rc0;               /* [L] coordinate code, idx(i,j) = rc[i]-rc[j]+rc0 */
+  const uint8_t* region; int32_t n_win;         /* [n_win][L] region id or NULL ; window = seq % n_win */
+  /* mode 1 */
+  const uint8_t* keymask;                       /* [nseq][L] 1 = attend, or NULL */
+  float dropout_p; uint64_t seed, offset;
+  /* DropPath 'producer' form: out rows of sequence s are multiplied by seq_scale[s / seqs_per_scale] (or NULL) */
+  const float* seq_scale; int32_t seqs_per_scale;
+} vmvm_attn_fwd_desc;
+int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
+
+typedef struct {
+  vmvm_attn_fwd_desc f;        /* same problem description (out = forward output O, lse = saved) */
+  const void* dout; int32_t ld_dout;   /* bf16 [nseq*L][ld_dout] */
+  void* dqkv; int32_t ld_dqkv;         /* bf16, same column layout as qkv */
+  float* dbias_table;                  /* mode 0: f32 [table_len][heads], ACCUMULATED (atomics) */
+  float* delta;                        /* workspace f32 [nseq][heads][L] */
+} vmvm_attn_bwd_desc;
+int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small fused kernels
+ * ------------------------------------------------------------------------------------------ */
+/* PatchEmbed3D im2col (video_swin.py:390-401): img f32 (B,T,3,H,W) [the reference transposes to (B,3,T,H,W)
+ * first, model.py:39] -> cols bf16 [B*T*(H/4)*(W/4)][96], k = c*32 + dt*16 + dy*4 + dx ; frame T is the zero pad. */
+int vmvm_patch_im2col(const float* img, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream);
+
+/* EncVideo token assembly (model.py:58-71): pre[b,t,0,:]=cls, pre[b,t,1+p,:]=fc_out[b,t,p,:]; + pos[p] + len[t].
+ * out bf16 [B*T*(1+hw)][Hd] (the following LayerNorm is vmvm_layernorm_fwd). */
+int vmvm_encvideo_assemble(const void* fc_out, const float* cls, const float* pos, const float* len,
+                           void* out, int32_t B, int32_t T, int32_t hw, int32_t Hd, void* stream);
+/* backward: d_fc_out (bf16) = dpre rows 1.. ; dcls/dpos/dlen f32 accumulated */
+int vmvm_encvideo_assemble_bwd(const void* dpre, void* d_fc_out, float* dcls, float* dpos, float* dlen,
+                               int32_t B, int32_t T, int32_t hw, int32_t Hd, void* stream);
+
+/* BERT embeddings sum (HF BertEmbeddings.forward, call site model.py:107): out = word[txt]+pos[x]+type[0] (bf16) */
+int vmvm_bert_embed(const int64_t* txt, const float* word, const float* pos, const float* type0,
+                    void* out, int32_t B, int32_t X, int32_t Hd, void* stream);
+int vmvm_bert_embed_bwd(const int64_t* txt, const void* dsum, float* dword, float* dpos, float* dtype0,
+                        int32_t B, int32_t X, int32_t Hd, void* stream);
+
+/* Cross entropy with ignore_index=-1 (agent.py:57; main_pretrain.py:560-561), fused forward + dlogits.
+ * logits f32 [M][ld] (first V columns valid); target i64 [M]; loss_sum/count f32 scalars ACCUMULATED;
+ * dlogits bf16 [M][ld_d] = (softmax - onehot) / max(*n_valid,1) (columns >= V get 0; ignored rows get 0);
+ * loss_sum += sum_rows (lse - logit[target]) / max(*n_valid,1); n_valid = device f32 from vmvm_count_valid. */
+int vmvm_count_valid(const int64_t* target, int32_t M, float* n_valid, void* stream);
+int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, int32_t V, const int64_t* target,
+                       const float* n_valid, float* loss_sum, void* dlogits, int32_t ld_d, void* stream);
+
+/* MVM pixel loss (main_pretrain.py:420-432): pred bf16 [B*T*hw][3*ps*ps] (1x1-conv output, channel = c*ps*ps+dy*ps+dx,
+ * PixelShuffle(ps) video order), target = unmask_img f32 (B,T,3,H,W), mask = cov u8 (B,T,h,w) patch cover.
+ * loss_sum += sum |pred-img|*mask ; dpred bf16 = sign(pred-img)*mask*coef with coef = 1/((3*ps*ps*sum(cov))+1e-5)/3 */
+int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum,
+                  float* loss_sum, void* dpred, int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, void* stream);
+
+/* VTM head tail (main_pretrain.py:147,260): logit[m] = (dot(hid[m,:], w) + b) / temp ; hid bf16 [M][K] */
+int vmvm_rowdot(const void* hid, int32_t M, int32_t K, const float* w, const float* b, float inv_temp,
+                float* out, void* stream);
+int vmvm_rowdot_bwd(const void* hid, int32_t M, int32_t K, const float* w, const float* dout, float inv_temp,
+                    void* dhid, float* dw, float* db, void* stream);
+
+/* generic helpers */
+int vmvm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[m,:] = src[idx'(m),:] (zeros when idx < 0); with rows_out_per_batch > 0 the map is per clip:
+ * idx'(m) = idx[m % rows_out_per_batch] + (m / rows_out_per_batch) * rows_in_per_batch  (window_partition of a gradient) */
+int vmvm_gather_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, void* dst, int32_t ld_dst,
+                          int32_t M, int32_t C, int32_t rows_out_per_batch, int32_t rows_in_per_batch, void* stream);
+int vmvm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer (agent.py:84-113,181-193): fused global grad-norm + clip + AdamW over a flat f32 arena,
+ * also refreshing the bf16 compute copy.  seg_* describe contiguous segments (4 param groups).
+ * ------------------------------------------------------------------------------------------ */
+int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* stream);
+typedef struct {
+  float* param; const float* grad; float* m; float* v; void* param_bf16;
+  int64_t n;
+  float lr, weight_decay, beta1, beta2, eps, bias_corr1, bias_corr2;
+  const float* sumsq; float max_grad_norm;     /* clip coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) ; <=0 disables */
+  float grad_scale;                            /* multiply grads (e.g. 1/world_size) before everything */
+} vmvm_adamw_desc;
+int vmvm_adamw(const vmvm_adamw_desc* d, void* stream);
+
+/* hardware probe used by tests: dumps the lane mapping of ds_read_b64_tr_b16 (out: 64*4 int32) */
+int vmvm_probe_tr16(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

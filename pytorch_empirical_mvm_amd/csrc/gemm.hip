@@ -1,0 +1,267 @@
+// gemm.hip -- bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+// C[M,N] = epilogue( sum_k A(m,k) B(n,k) ), f32 accumulate on v_mfma_f32_16x16x32_bf16.
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
+// Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile; the
+// global loads of tile t+1 are in flight while tile t is multiplied).  k-major operand tiles are
+// stored [128][64] with a 16-byte-chunk XOR swizzle ((row>>1)&7) so the ds_read_b128 fragment
+// reads are conflict free; m/n-major operand tiles ([64 k][128]) are read with the gfx950
+// transposing LDS read ds_read_b64_tr_b16 (32-byte slot swizzle), so wgrad/dgrad need no
+// transposed copies of activations or weights in HBM.
+// The MFMA is issued with swapped operands (D' = B_frag x A_frag) so each lane owns 4 CONSECUTIVE
+// output columns of one row -> 8-byte bf16 / 16-byte f32 stores and vector bias/residual loads.
+// Block -> tile mapping is XCD-aware: the 8 XCDs get contiguous runs of the tile list, and all
+// N-tiles of one M-panel are neighbours, so an activation panel is fetched into one L2 only.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;       // A,B x double buffer = 64 KiB
+
+__device__ __forceinline__ int swz_m(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+// ---- global -> register staging of one operand tile (4 x 16B chunks per thread) ----------------
+template <bool KMAJOR>
+__device__ __forceinline__ void load_tile(const u16* __restrict__ P, int ld, int rows_total, int K,
+                                          int row0, int k0, int tid, uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (KMAJOR) {
+      const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
+      if (row < rows_total && k < K) v = *reinterpret_cast<const uint4*>(P + (size_t)row * ld + k);
+    } else {
+      const int k = k0 + (c >> 4), x = row0 + (c & 15) * 8;
+      if (k < K && x < rows_total) v = *reinterpret_cast<const uint4*>(P + (size_t)k * ld + x);
+    }
+    r[i] = v;
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    int off;
+    if (KMAJOR) {
+      const int row = c >> 3, kc = c & 7;
+      off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+    } else {
+      const int krow = c >> 4, xc = c & 15;
+      off = krow * 256 + ((((xc >> 1) ^ swz_m(krow)) & 7) << 5) + ((xc & 1) << 4);
+    }
+    *reinterpret_cast<uint4*>(lds + off) = r[i];
+  }
+}
+
+// ---- LDS -> MFMA fragment (8 bf16 along k for row/col `x` of the tile), k-step s (32 wide) ------
+template <bool KMAJOR, bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int x16, int s, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if (KMAJOR) {
+    const int row = x16 * 16 + r, kc = s * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else if (TR) {
+    // two transposing reads: block rows k = 32s+8g+{0..3} and +{4..7}, 16 columns of slot x16
+    const int krow = s * 32 + g * 8 + (r >> 2);
+    const int o1 = krow * 256 + (((x16 ^ swz_m(krow)) & 7) << 5) + (r & 3) * 8;
+    const int krow2 = krow + 4;
+    const int o2 = krow2 * 256 + (((x16 ^ swz_m(krow2)) & 7) << 5) + (r & 3) * 8;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int krow = s * 32 + g * 8 + e;
+      const int off = krow * 256 + (((x16 ^ swz_m(krow)) & 7) << 5) + r * 2;
+      v[e] = *reinterpret_cast<const short*>(lds + off);
+    }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool AK, bool BKM, bool TR>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+  const int nb = nbm * nbn;
+  // XCD-aware bijective remap (block b runs on XCD b%8)
+  const int bid = blockIdx.x;
+  const int q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  const int tm = logical / nbn, tn = logical - tm * nbn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const u16* A = reinterpret_cast<const u16*>(p.A);
+  const u16* B = reinterpret_cast<const u16*>(p.B);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nk = (K + BK - 1) / BK;
+  load_tile<AK>(A, p.lda, M, K, m0, 0, tid, ra);
+  load_tile<BKM>(B, p.ldb, N, K, n0, 0, tid, rb);
+  store_tile<AK>(smem, tid, ra);
+  store_tile<BKM>(smem + TILE_BYTES, tid, rb);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const unsigned char* la = smem + cur * 2 * TILE_BYTES;
+    const unsigned char* lb = la + TILE_BYTES;
+    if (kt + 1 < nk) {
+      load_tile<AK>(A, p.lda, M, K, m0, (kt + 1) * BK, tid, ra);
+      load_tile<BKM>(B, p.ldb, N, K, n0, (kt + 1) * BK, tid, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK, TR>(la, wm * 4 + i, s, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKM, TR>(lb, wn * 4 + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      store_tile<AK>(na, tid, ra);
+      store_tile<BKM>(na + TILE_BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------- epilogue -------------------------------
+  const int r = lane & 15, g = lane >> 4;
+  const bool has_drop = p.dropout_p > 0.f;
+  const uint32_t thr = dropout_threshold(p.dropout_p);
+  const float keep_scale = has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r;
+    if (m >= M) continue;
+    long dst = m;
+    if (p.row_map) {
+      const int within = m % p.map_len;
+      const int mapped = p.row_map[within];
+      if (mapped < 0) continue;
+      dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
+    }
+    const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + g * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (n < p.col_scale_n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.col_scale;
+      }
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        const float bs = p.scale_bias_only ? rs : 1.0f;   // DropPath producer form: A rows already carry the scale
+        v[0] += b.x * bs; v[1] += b.y * bs; v[2] += b.z * bs; v[3] += b.w * bs;
+      }
+      if (p.act == 1) {
+        if (p.C2) {
+          uint2 pre = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+          *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pre;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 3 || p.act == 4) {
+        const uint2 a2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+        float u[4] = {__uint_as_float(a2.x << 16), __uint_as_float(a2.x & 0xffff0000u),
+                      __uint_as_float(a2.y << 16), __uint_as_float(a2.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= (p.act == 3) ? gelu_grad_f(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
+      }
+      if (p.row_scale && !p.scale_bias_only) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+      }
+      if (has_drop) {
+        const uint64_t e4 = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
+        const uint4 bits = dropout_bits(p.seed, p.offset, e4);
+        v[0] = bits.x < thr ? 0.f : v[0] * keep_scale;
+        v[1] = bits.y < thr ? 0.f : v[1] * keep_scale;
+        v[2] = bits.z < thr ? 0.f : v[2] * keep_scale;
+        v[3] = bits.w < thr ? 0.f : v[3] * keep_scale;
+      }
+      if (p.resid) {
+        const uint2 r2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.resid) + (size_t)dst * p.ldr + n);
+        v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+        v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+      }
+      if (p.out_fp32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+        if (p.accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(c);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) =
+            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+  }
+}
+
+template <bool AK, bool BKM, bool TR>
+int launch(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int nb = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AK, BKM, TR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<AK, BKM, TR>), dim3(nb), dim3(256), SMEM_BYTES, st, d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
+}  // namespace
+
+extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
+  if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7)) return VMVM_EINVAL;
+  if (d->a_kmajor ? (d->K & 7) : (d->M & 7)) return VMVM_EINVAL;
+  if (d->b_kmajor ? (d->K & 7) : (d->N & 7)) return VMVM_EINVAL;
+  if (d->out_fp32 ? (d->ldc & 3) : (d->ldc & 3)) return VMVM_EINVAL;
+  if (d->accumulate && !d->out_fp32) return VMVM_EINVAL;
+  if ((d->act == 3 || d->act == 4) && !d->aux) return VMVM_EINVAL;
+  if (d->row_map && d->map_len <= 0) return VMVM_EINVAL;
+  if (d->row_scale && d->rows_per_scale <= 0) return VMVM_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool tr = d->variant != 1;
+  if (d->a_kmajor && d->b_kmajor) return launch<true, true, true>(*d, st);
+  if (d->a_kmajor && !d->b_kmajor) return tr ? launch<true, false, true>(*d, st) : launch<true, false, false>(*d, st);
+  if (!d->a_kmajor && !d->b_kmajor) return tr ? launch<false, false, true>(*d, st) : launch<false, false, false>(*d, st);
+  return tr ? launch<false, true, true>(*d, st) : launch<false, true, false>(*d, st);
+}

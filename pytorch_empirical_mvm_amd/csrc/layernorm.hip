@@ -1,0 +1,236 @@
+// layernorm.hip -- gather-LayerNorm forward/backward for gfx950 (HBM-bound, one wave per row).
+//
+// One 64-lane wave owns one output row; each lane holds its 16-byte chunks (8 bf16) of the row in
+// registers (NCH chunks per lane), so the row is read from HBM exactly once, statistics are f32
+// (two-pass in registers), and the window-shift/partition gather (Video-Swin norm1) or the 2x2
+// patch-merging gather is pure address arithmetic on the read side (`src` map) -- no rolled,
+// padded or concatenated tensor is ever materialised.
+// Backward: a fixed grid of waves walks rows grid-stride, keeps dgamma/dbeta partials in registers,
+// reduces them across the block in LDS and issues one f32 atomic per column per block.
+#include "common.h"
+
+namespace {
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * 4 + wave;
+  if (m >= p.M) return;
+  const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
+  const u16* X = reinterpret_cast<const u16*>(p.X);
+  u16* Y = reinterpret_cast<u16*>(p.Y) + (size_t)m * p.ldy;
+  long b = 0, ml = m;
+  if (p.src) { b = m / p.rows_out_per_batch; ml = m - b * p.rows_out_per_batch; }
+
+  float x[NCH][8];
+  float s = 0.f;
+  bool any_valid = (p.src == nullptr);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[i][e] = 0.f;
+    if (c < nch) {
+      const int col = c * 8;
+      long srow = m; int within = col;
+      if (p.src) {
+        const int seg = col / cseg; within = col - seg * cseg;
+        const int sr = p.src[ml * p.nseg + seg];
+        srow = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
+      }
+      if (srow >= 0) {
+        any_valid = true;
+        const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)srow * p.ldx + within);
+        unpack_bf8(v, x[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[i][e];
+    }
+  }
+  if (p.src && p.pad_mode == 0) {
+    // window map: the row is either fully valid or a pad slot (zero OUTPUT row)
+    const bool valid = __any(any_valid);
+    if (!valid) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) *reinterpret_cast<uint4*>(Y + c * 8) = make_uint4(0, 0, 0, 0);
+      }
+      if (lane == 0) { p.mean[m] = 0.f; p.rstd[m] = 0.f; }
+      return;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+  if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      const int col = c * 8;
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.beta + col), b1 = *reinterpret_cast<const float4*>(p.beta + col + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (x[i][e] - mean) * rstd * gg[e] + bb[e];
+      *reinterpret_cast<uint4*>(Y + col) = pack_bf8(o);
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][C] partial dgamma/dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
+  const u16* X = reinterpret_cast<const u16*>(p.X);
+  const u16* dY = reinterpret_cast<const u16*>(p.dY);
+  u16* dX = reinterpret_cast<u16*>(p.dX);
+  const u16* ADD = reinterpret_cast<const u16*>(p.dX_add);
+  u16* dX2 = reinterpret_cast<u16*>(p.dX2);
+  const bool has_drop = dX2 != nullptr && p.dropout_p > 0.f;
+  const uint32_t thr = dropout_threshold(p.dropout_p);
+  const float keep_scale = has_drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+
+  float dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+
+  const long stride = (long)gridDim.x * 4;
+  for (long m = (long)blockIdx.x * 4 + wave; m < p.M; m += stride) {
+    const float mean = p.mean[m], rstd = p.rstd[m];
+    long b = 0, ml = m;
+    if (p.src) { b = m / p.rows_out_per_batch; ml = m - b * p.rows_out_per_batch; }
+    if (p.src && p.pad_mode == 0 && p.src[ml] < 0) continue;     // pad slot: constant zero output
+    float xh[NCH][8], gdy[NCH][8];
+    long srow[NCH]; int within[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      srow[i] = -1; within[i] = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; gdy[i][e] = 0.f; }
+      if (c < nch) {
+        const int col = c * 8;
+        srow[i] = m; within[i] = col;
+        if (p.src) {
+          const int seg = col / cseg; within[i] = col - seg * cseg;
+          const int sr = p.src[ml * p.nseg + seg];
+          srow[i] = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
+        }
+        float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
+        if (srow[i] >= 0) unpack_bf8(*reinterpret_cast<const uint4*>(X + (size_t)srow[i] * p.ldx + within[i]), xv);
+        unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col), dyv);
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xv[e] - mean) * rstd;
+          gdy[i][e] = dyv[e] * gg[e];
+          dg[i][e] += dyv[e] * xh[i][e];
+          db[i][e] += dyv[e];
+          s1 += gdy[i][e];
+          s2 += gdy[i][e] * xh[i][e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch && srow[i] >= 0) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (gdy[i][e] - s1 - xh[i][e] * s2);
+        if (ADD) {
+          float a[8];
+          unpack_bf8(*reinterpret_cast<const uint4*>(ADD + (size_t)srow[i] * p.ldadd + within[i]), a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
+        *reinterpret_cast<uint4*>(dX + (size_t)srow[i] * p.lddx + within[i]) = pack_bf8(o);
+        if (dX2) {
+          if (has_drop) {
+            const uint64_t e4 = ((uint64_t)m * (uint64_t)C + (uint64_t)(c * 8)) >> 2;
+            const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
+            const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
+          }
+          *reinterpret_cast<uint4*>(dX2 + (size_t)m * p.lddx2 + c * 8) = pack_bf8(o);
+        }
+      }
+    }
+  }
+  // block reduction of dgamma/dbeta partials, then one atomic per column
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&red[c * 8 + e], dg[i][e]);
+        atomicAdd(&red[C + c * 8 + e], db[i][e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(p.dgamma + i, red[i]);
+    atomicAdd(p.dbeta + i, red[C + i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream) {
+  if (!d || !d->X || !d->Y || !d->gamma || !d->beta || !d->mean || !d->rstd) return VMVM_EINVAL;
+  if (d->M <= 0 || d->C <= 0 || (d->C & 7) || d->nseg < 1 || (d->C % d->nseg) || ((d->C / d->nseg) & 7)) return VMVM_EINVAL;
+  if ((d->ldx & 7) || (d->ldy & 7)) return VMVM_EINVAL;
+  if (d->src && (d->rows_out_per_batch <= 0 || d->rows_in_per_batch <= 0)) return VMVM_EINVAL;
+  if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = (d->M + 3) / 4;
+  if (d->C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, *d);
+  else if (d->C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, *d);
+  else if (d->C <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, *d);
+  else hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(grid), dim3(256), 0, st, *d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
+extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
+  if (!d || !d->dY || !d->X || !d->gamma || !d->mean || !d->rstd || !d->dX || !d->dgamma || !d->dbeta) return VMVM_EINVAL;
+  if (d->M <= 0 || d->C <= 0 || (d->C & 7) || d->nseg < 1 || (d->C % d->nseg) || ((d->C / d->nseg) & 7)) return VMVM_EINVAL;
+  if ((d->ldx & 7) || (d->lddy & 7) || (d->lddx & 7)) return VMVM_EINVAL;
+  if (d->src && (d->rows_out_per_batch <= 0 || d->rows_in_per_batch <= 0)) return VMVM_EINVAL;
+  if (d->dX2 && d->src) return VMVM_ENOSUPPORT;
+  if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (d->M + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  const size_t sm = (size_t)2 * d->C * sizeof(float);
+  if (d->C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), sm, st, *d);
+  else if (d->C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), sm, st, *d);
+  else if (d->C <= 2048) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), sm, st, *d);
+  else hipLaunchKernelGGL(ln_bwd_kernel<6>, dim3(grid), dim3(256), sm, st, *d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}

@@ -1,0 +1,515 @@
+// misc.hip -- small fused HBM-bound kernels of the VIOLETv2 step (gfx950): im2col, token assembly,
+// embeddings, fused cross-entropy / masked-L1 losses (forward + gradient in one pass), bias
+// gradients, fused grad-norm + AdamW, and a hardware probe for ds_read_b64_tr_b16.
+#include "common.h"
+
+thread_local int g_vmvm_last_hip_error = 0;
+
+extern "C" int vmvm_version(void) { return (0 << 16) | 1; }
+extern "C" int vmvm_last_hip_error(void) { return g_vmvm_last_hip_error; }
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {   // 256-thread block reduction
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// ---------------------------------------------------------------- PatchEmbed3D im2col
+__global__ void im2col_kernel(const float* __restrict__ img, u16* __restrict__ cols, int B, int T, int H, int W) {
+  const int Hp = H / 4, Wp = W / 4;
+  const long ntok = (long)B * T * Hp * Wp;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntok * 6) return;
+  const int cd = (int)(i / ntok);
+  const long tok = i - (long)cd * ntok;
+  const int c = cd >> 1, dt = cd & 1;
+  const int x = (int)(tok % Wp);
+  const int y = (int)((tok / Wp) % Hp);
+  const int t = (int)((tok / ((long)Wp * Hp)) % T);
+  const int b = (int)(tok / ((long)Wp * Hp * T));
+  u16* dst = cols + tok * 96 + c * 32 + dt * 16;
+  const bool valid = (t + dt) < T;                      // frame T is the appended zero frame (video_swin.py:398)
+  const float* src = img + ((((long)b * T + (t + dt)) * 3 + c) * H + 4 * y) * W + 4 * x;
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(src + (long)dy * W);
+    *reinterpret_cast<uint2*>(dst + dy * 4) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+}
+
+// ---------------------------------------------------------------- EncVideo token assembly
+__global__ void encvideo_assemble_kernel(const u16* __restrict__ fc, const float* __restrict__ cls, const float* __restrict__ pos,
+                                         const float* __restrict__ len, u16* __restrict__ out, int B, int T, int hw, int Hd) {
+  const int nch = Hd / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * T * (1 + hw) * nch;
+  if (i >= total) return;
+  const int ch = (int)(i % nch);
+  const long row = i / nch;
+  const int pp = (int)(row % (1 + hw));
+  const long bt = row / (1 + hw);
+  const int t = (int)(bt % T);
+  float v[8];
+  if (pp == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = cls[ch * 8 + e];
+  } else {
+    unpack_bf8(*reinterpret_cast<const uint4*>(fc + (bt * hw + (pp - 1)) * Hd + ch * 8), v);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += pos[(long)pp * Hd + ch * 8 + e] + len[(long)t * Hd + ch * 8 + e];
+  *reinterpret_cast<uint4*>(out + row * Hd + ch * 8) = pack_bf8(v);
+}
+
+// mode 0: d_fc copy ; mode 1: dpos[p] (p==0 also -> dcls) ; mode 2: dlen[t]
+__global__ void encvideo_assemble_bwd_kernel(const u16* __restrict__ dpre, u16* __restrict__ dfc, float* __restrict__ dcls,
+                                             float* __restrict__ dpos, float* __restrict__ dlen, int B, int T, int hw, int Hd, int mode) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = 1 + hw;
+  if (mode == 0) {
+    const int nch = Hd / 8;
+    const long total = (long)B * T * hw * nch;
+    if (i >= total) return;
+    const int ch = (int)(i % nch);
+    const long row = i / nch;
+    const int pp = (int)(row % hw);
+    const long bt = row / hw;
+    *reinterpret_cast<uint4*>(dfc + row * Hd + ch * 8) = *reinterpret_cast<const uint4*>(dpre + (bt * P + pp + 1) * Hd + ch * 8);
+  } else if (mode == 1) {
+    if (i >= (long)P * Hd) return;
+    const int col = (int)(i % Hd), pp = (int)(i / Hd);
+    float s = 0.f;
+    for (int bt = 0; bt < B * T; ++bt) s += bf2f(dpre[((long)bt * P + pp) * Hd + col]);
+    dpos[(long)pp * Hd + col] += s;
+    if (pp == 0) dcls[col] += s;
+  } else {
+    if (i >= (long)T * Hd) return;
+    const int col = (int)(i % Hd), t = (int)(i / Hd);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int pp = 0; pp < P; ++pp) s += bf2f(dpre[(((long)b * T + t) * P + pp) * Hd + col]);
+    dlen[(long)t * Hd + col] += s;
+  }
+}
+
+// ---------------------------------------------------------------- BERT embeddings
+__global__ void bert_embed_kernel(const int64_t* __restrict__ txt, const float* __restrict__ word, const float* __restrict__ pos,
+                                  const float* __restrict__ type0, u16* __restrict__ out, int B, int X, int Hd) {
+  const int nch = Hd / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * X * nch) return;
+  const int ch = (int)(i % nch);
+  const long row = i / nch;
+  const int x = (int)(row % X);
+  const long id = txt[row];
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = word[id * Hd + ch * 8 + e] + pos[(long)x * Hd + ch * 8 + e] + type0[ch * 8 + e];
+  *reinterpret_cast<uint4*>(out + row * Hd + ch * 8) = pack_bf8(v);
+}
+__global__ void bert_embed_bwd_kernel(const int64_t* __restrict__ txt, const u16* __restrict__ dsum, float* __restrict__ dword,
+                                      float* __restrict__ dpos, float* __restrict__ dtype0, int B, int X, int Hd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * X * Hd) return;
+  const int col = (int)(i % Hd);
+  const long row = i / Hd;
+  const int x = (int)(row % X);
+  const float g = bf2f(dsum[i]);
+  atomicAdd(dword + txt[row] * Hd + col, g);
+  atomicAdd(dpos + (long)x * Hd + col, g);
+  atomicAdd(dtype0 + col, g);
+}
+
+// ---------------------------------------------------------------- cross entropy (ignore_index = -1)
+__global__ void count_valid_kernel(const int64_t* __restrict__ target, int M, float* __restrict__ n_valid) {
+  __shared__ float sh[4];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) c += target[i] >= 0 ? 1.f : 0.f;
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) *n_valid = c;
+}
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
+                                                            const float* __restrict__ n_valid, float* __restrict__ loss_sum,
+                                                            u16* __restrict__ dlogits, int ld_d) {
+  __shared__ float sh[4];
+  const long m = blockIdx.x;
+  const long tgt = target[m];
+  u16* drow = dlogits ? dlogits + m * ld_d : nullptr;
+  if (tgt < 0) {
+    if (drow) for (int i = threadIdx.x; i < ld_d; i += 256) drow[i] = 0;
+    return;
+  }
+  const float* row = logits + m * ld;
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, row[i]);
+  mx = block_max(mx, sh);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) s += __expf(row[i] - mx);
+  s = block_sum(s, sh);
+  const float lse = mx + __logf(s);
+  const float inv_n = 1.0f / fmaxf(*n_valid, 1.0f);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (lse - row[tgt]) * inv_n);
+  if (drow) {
+    for (int i = threadIdx.x; i < ld_d; i += 256) {
+      float g = 0.f;
+      if (i < V) g = (__expf(row[i] - lse) - (i == tgt ? 1.f : 0.f)) * inv_n;
+      drow[i] = f2bf(g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- MVM pixel masked L1
+__global__ __launch_bounds__(256) void pixel_l1_kernel(const u16* __restrict__ pred, const float* __restrict__ img, const uint8_t* __restrict__ cov,
+                                                       const float* __restrict__ mask_sum, float* __restrict__ loss_sum, u16* __restrict__ dpred,
+                                                       int B, int T, int h, int w, int ps) {
+  __shared__ float sh[4];
+  const long row = blockIdx.x;                 // (b*T+t)*h*w + i*w + j
+  const int hw = h * w, C3 = 3 * ps * ps;
+  const int ij = (int)(row % hw);
+  const long bt = row / hw;
+  const int i = ij / w, j = ij % w;
+  u16* drow = dpred + row * C3;
+  if (!cov[row]) {
+    for (int k = threadIdx.x * 8; k < C3; k += 256 * 8) *reinterpret_cast<uint4*>(drow + k) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const int H = h * ps, W = w * ps;
+  const float coef = 1.0f / (*mask_sum + 1e-5f) / 3.0f;
+  float acc = 0.f;
+  for (int k = threadIdx.x * 4; k < C3; k += 256 * 4) {
+    const int c = k / (ps * ps), rem = k - c * ps * ps, dy = rem / ps, dx = rem - dy * ps;
+    const float4 t4 = *reinterpret_cast<const float4*>(img + ((bt * 3 + c) * H + (i * ps + dy)) * (long)W + j * ps + dx);
+    const uint2 p2 = *reinterpret_cast<const uint2*>(pred + row * C3 + k);
+    const float pv[4] = {__uint_as_float(p2.x << 16), __uint_as_float(p2.x & 0xffff0000u), __uint_as_float(p2.y << 16), __uint_as_float(p2.y & 0xffff0000u)};
+    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = pv[e] - tv[e];
+      acc += fabsf(d);
+      g[e] = (d > 0.f ? coef : (d < 0.f ? -coef : 0.f));
+    }
+    *reinterpret_cast<uint2*>(drow + k) = make_uint2(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]));
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, acc * coef);
+}
+
+// ---------------------------------------------------------------- VTM head tail
+__global__ void rowdot_kernel(const u16* __restrict__ hid, int M, int K, const float* __restrict__ w, const float* __restrict__ b,
+                              float inv_temp, float* __restrict__ out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= M) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += bf2f(hid[(long)wave * K + k]) * w[k];
+  s = wave_sum(s);
+  if (lane == 0) out[wave] = (s + b[0]) * inv_temp;
+}
+__global__ void rowdot_bwd_kernel(const u16* __restrict__ hid, int M, int K, const float* __restrict__ w, const float* __restrict__ dout,
+                                  float inv_temp, u16* __restrict__ dhid, float* __restrict__ dw, float* __restrict__ db) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f, sb = 0.f;
+  const float wk = w[k];
+  for (int m = 0; m < M; ++m) {
+    const float g = dout[m] * inv_temp;
+    s += g * bf2f(hid[(long)m * K + k]);
+    sb += g;
+    dhid[(long)m * K + k] = f2bf(g * wk);
+  }
+  dw[k] += s;
+  if (k == 0) db[0] += sb;
+}
+
+// ---------------------------------------------------------------- generic helpers
+__global__ void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(dst + i) = pack_bf8(f);
+  } else {
+    for (long k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+  }
+}
+__global__ void add_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float x[8], y[8];
+    unpack_bf8(*reinterpret_cast<const uint4*>(a + i), x);
+    unpack_bf8(*reinterpret_cast<const uint4*>(b + i), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    *reinterpret_cast<uint4*>(out + i) = pack_bf8(x);
+  } else {
+    for (long k = i; k < n; ++k) out[k] = f2bf(bf2f(a[k]) + bf2f(b[k]));
+  }
+}
+__global__ void gather_rows_kernel(const u16* __restrict__ src, int ld_src, const int32_t* __restrict__ idx, u16* __restrict__ dst, int ld_dst,
+                                   long M, int C, int rows_out_per_batch, int rows_in_per_batch) {
+  const int nch = C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * nch) return;
+  const int ch = (int)(i % nch);
+  const long m = i / nch;
+  long s;
+  if (rows_out_per_batch > 0) {
+    const long b = m / rows_out_per_batch;
+    const int sr = idx[m - b * rows_out_per_batch];
+    s = sr < 0 ? -1 : (long)sr + b * rows_in_per_batch;
+  } else {
+    s = idx[m];
+  }
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (s >= 0) v = *reinterpret_cast<const uint4*>(src + s * ld_src + ch * 8);
+  *reinterpret_cast<uint4*>(dst + m * ld_dst + ch * 8) = v;
+}
+
+// column sums: block = 8 column-chunks (64 cols) x 32 row lanes ; grid.y splits the rows
+__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, int M, int N, int ldx, const float* __restrict__ row_scale,
+                                                     int rows_per_scale, float* __restrict__ out) {
+  __shared__ float sh[32][65];
+  const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * 64 + cc * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (long m = (long)blockIdx.y * 32 + rl; m < M; m += (long)gridDim.y * 32) {
+      float v[8];
+      unpack_bf8(*reinterpret_cast<const uint4*>(X + m * ldx + col), v);
+      const float s = row_scale ? row_scale[m / rows_per_scale] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e] * s;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[rl][cc * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s += sh[k][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, s);
+  }
+}
+
+// ---------------------------------------------------------------- optimizer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long k = i; k < n; ++k) s += g[k] * g[k];
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+__global__ __launch_bounds__(256) void adamw_kernel(const vmvm_adamw_desc d) {
+  float coef = d.grad_scale;
+  if (d.max_grad_norm > 0.f && d.sumsq) {
+    const float norm = sqrtf(*d.sumsq) * d.grad_scale;
+    coef *= fminf(1.0f, d.max_grad_norm / (norm + 1e-6f));
+  }
+  const float decay = 1.0f - d.lr * d.weight_decay;
+  const float step_size = d.lr / d.bias_corr1;
+  const float inv_sqrt_bc2 = rsqrtf(d.bias_corr2);
+  u16* pb = reinterpret_cast<u16*>(d.param_bf16);
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < d.n; i += stride) {
+    const int cnt = (int)((d.n - i) < 4 ? (d.n - i) : 4);
+    float p[4], g[4], m[4], v[4];
+    if (cnt == 4) {
+      const float4 p4 = *reinterpret_cast<const float4*>(d.param + i), g4 = *reinterpret_cast<const float4*>(d.grad + i);
+      const float4 m4 = *reinterpret_cast<const float4*>(d.m + i), v4 = *reinterpret_cast<const float4*>(d.v + i);
+      p[0] = p4.x; p[1] = p4.y; p[2] = p4.z; p[3] = p4.w; g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+      m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w; v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+    } else {
+      for (int e = 0; e < cnt; ++e) { p[e] = d.param[i + e]; g[e] = d.grad[i + e]; m[e] = d.m[i + e]; v[e] = d.v[i + e]; }
+    }
+    for (int e = 0; e < cnt; ++e) {
+      const float gg = g[e] * coef;
+      p[e] *= decay;
+      m[e] = d.beta1 * m[e] + (1.f - d.beta1) * gg;
+      v[e] = d.beta2 * v[e] + (1.f - d.beta2) * gg * gg;
+      const float denom = sqrtf(v[e]) * inv_sqrt_bc2 + d.eps;
+      p[e] -= step_size * m[e] / denom;
+    }
+    if (cnt == 4) {
+      *reinterpret_cast<float4*>(d.param + i) = make_float4(p[0], p[1], p[2], p[3]);
+      *reinterpret_cast<float4*>(d.m + i) = make_float4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<float4*>(d.v + i) = make_float4(v[0], v[1], v[2], v[3]);
+      if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3]));
+    } else {
+      for (int e = 0; e < cnt; ++e) { d.param[i + e] = p[e]; d.m[i + e] = m[e]; d.v[i + e] = v[e]; if (pb) pb[i + e] = f2bf(p[e]); }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- probe: ds_read_b64_tr_b16 lane mapping
+__global__ void probe_tr16_kernel(int32_t* out) {
+  __shared__ __attribute__((aligned(16))) u16 lds[64 * 16];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 64 * 16; i += 64) lds[i] = (u16)i;           // lds[row*16+col] = row*16+col, 16 cols per row
+  __syncthreads();
+  // every 16-lane group g reads the 4x16 block of rows 4g..4g+3: lane i -> row 4g + i/4, cols (i%4)*4..+3
+  const int g = lane >> 4, i = lane & 15;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (4 * g + (i >> 2)) * 16 + (i & 3) * 4));
+  for (int e = 0; e < 4; ++e) out[lane * 4 + e] = (int32_t)(u16)v[e];
+}
+
+inline int nblk(long n, int per) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int vmvm_patch_im2col(const float* img, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream) {
+  if (!img || !cols || B <= 0 || T <= 0 || (H & 3) || (W & 3)) return VMVM_EINVAL;
+  const long n = (long)B * T * (H / 4) * (W / 4) * 6;
+  hipLaunchKernelGGL(im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, img, reinterpret_cast<u16*>(cols), B, T, H, W);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_encvideo_assemble(const void* fc_out, const float* cls, const float* pos, const float* len, void* out,
+                                      int32_t B, int32_t T, int32_t hw, int32_t Hd, void* stream) {
+  if (!fc_out || !cls || !pos || !len || !out || (Hd & 7)) return VMVM_EINVAL;
+  const long n = (long)B * T * (1 + hw) * (Hd / 8);
+  hipLaunchKernelGGL(encvideo_assemble_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(fc_out), cls, pos, len,
+                     reinterpret_cast<u16*>(out), B, T, hw, Hd);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_encvideo_assemble_bwd(const void* dpre, void* d_fc_out, float* dcls, float* dpos, float* dlen,
+                                          int32_t B, int32_t T, int32_t hw, int32_t Hd, void* stream) {
+  if (!dpre || !d_fc_out || !dcls || !dpos || !dlen || (Hd & 7)) return VMVM_EINVAL;
+  const u16* dp = reinterpret_cast<const u16*>(dpre);
+  u16* df = reinterpret_cast<u16*>(d_fc_out);
+  hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)B * T * hw * (Hd / 8), 256)), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 0);
+  hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)(1 + hw) * Hd, 256)), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 1);
+  hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)T * Hd, 256)), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 2);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_bert_embed(const int64_t* txt, const float* word, const float* pos, const float* type0, void* out,
+                               int32_t B, int32_t X, int32_t Hd, void* stream) {
+  if (!txt || !word || !pos || !type0 || !out || (Hd & 7)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(bert_embed_kernel, dim3(nblk((long)B * X * (Hd / 8), 256)), dim3(256), 0, ST, txt, word, pos, type0, reinterpret_cast<u16*>(out), B, X, Hd);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_bert_embed_bwd(const int64_t* txt, const void* dsum, float* dword, float* dpos, float* dtype0,
+                                   int32_t B, int32_t X, int32_t Hd, void* stream) {
+  if (!txt || !dsum || !dword || !dpos || !dtype0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(nblk((long)B * X * Hd, 256)), dim3(256), 0, ST, txt, reinterpret_cast<const u16*>(dsum), dword, dpos, dtype0, B, X, Hd);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_count_valid(const int64_t* target, int32_t M, float* n_valid, void* stream) {
+  if (!target || !n_valid || M <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, ST, target, M, n_valid);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, int32_t V, const int64_t* target, const float* n_valid,
+                                  float* loss_sum, void* dlogits, int32_t ld_d, void* stream) {
+  if (!logits || !target || !n_valid || !loss_sum || M <= 0 || V <= 0 || ld < V) return VMVM_EINVAL;
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(M), dim3(256), 0, ST, logits, ld, V, target, n_valid, loss_sum, reinterpret_cast<u16*>(dlogits), ld_d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum, float* loss_sum, void* dpred,
+                             int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, void* stream) {
+  if (!pred || !img || !cov || !mask_sum || !loss_sum || !dpred || (ps & 3)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(pixel_l1_kernel, dim3(B * T * h * w), dim3(256), 0, ST, reinterpret_cast<const u16*>(pred), img, cov, mask_sum, loss_sum,
+                     reinterpret_cast<u16*>(dpred), B, T, h, w, ps);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_rowdot(const void* hid, int32_t M, int32_t K, const float* w, const float* b, float inv_temp, float* out, void* stream) {
+  if (!hid || !w || !b || !out || M <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(nblk((long)M * 64, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(hid), M, K, w, b, inv_temp, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_rowdot_bwd(const void* hid, int32_t M, int32_t K, const float* w, const float* dout, float inv_temp, void* dhid,
+                               float* dw, float* db, void* stream) {
+  if (!hid || !w || !dout || !dhid || !dw || !db) return VMVM_EINVAL;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk(K, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(hid), M, K, w, dout, inv_temp,
+                     reinterpret_cast<u16*>(dhid), dw, db);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(cast_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, ST, src, reinterpret_cast<u16*>(dst), (long)n);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(a), reinterpret_cast<const u16*>(b),
+                     reinterpret_cast<u16*>(out), (long)n);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_gather_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, void* dst, int32_t ld_dst, int32_t M, int32_t C,
+                                     int32_t rows_out_per_batch, int32_t rows_in_per_batch, void* stream) {
+  if (!src || !idx || !dst || M <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((long)M * (C / 8), 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), ld_src, idx,
+                     reinterpret_cast<u16*>(dst), ld_dst, (long)M, C, rows_out_per_batch, rows_in_per_batch);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
+                                int32_t accumulate, void* stream) {
+  if (!X || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return VMVM_EINVAL;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, ST) != hipSuccess) return VMVM_EHIP;
+  int gy = (M + 32 * 16 - 1) / (32 * 16);
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, ST, reinterpret_cast<const u16*>(X), M, N, ldx, row_scale, rows_per_scale, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* stream) {
+  if (!g || !out_accum || n <= 0) return VMVM_EINVAL;
+  int grid = nblk((n + 3) / 4, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, (long)n, out_accum);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_adamw(const vmvm_adamw_desc* d, void* stream) {
+  if (!d || !d->param || !d->grad || !d->m || !d->v || d->n <= 0) return VMVM_EINVAL;
+  int grid = nblk((d->n + 3) / 4, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, *d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_probe_tr16(int32_t* out, void* stream) {
+  if (!out) return VMVM_EINVAL;
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, ST, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}

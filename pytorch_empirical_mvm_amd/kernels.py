@@ -1,0 +1,247 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per libvmvm entry point).
+
+torch is used only for device memory and the current stream; every call enqueues hand-written HIP
+kernels.  All tensors must be contiguous-row CUDA tensors; bf16 tensors are torch.bfloat16."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ld(t):
+    assert t.stride(-1) == 1, "rows must be contiguous"
+    return t.stride(0) if t.dim() > 1 else t.numel()
+
+
+def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
+         scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
+         out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
+         variant=0, out_rows=None):
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
+    if M is None:
+        M = A.shape[0] if a_kmajor else A.shape[1]
+    if K is None:
+        K = A.shape[1] if a_kmajor else A.shape[0]
+    if N is None:
+        N = B.shape[0] if b_kmajor else B.shape[1]
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty((rows, N), device=A.device, dtype=out_dtype)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = _ld(A), _ld(B), _ld(out)
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.bias = L.ptr(bias)
+    d.row_scale, d.rows_per_scale = L.ptr(row_scale), rows_per_scale
+    d.scale_bias_only = int(scale_bias_only)
+    d.act = act
+    d.aux, d.ldaux = L.ptr(aux), (_ld(aux) if aux is not None else 0)
+    d.C2, d.ldc2 = L.ptr(out_preact), (_ld(out_preact) if out_preact is not None else 0)
+    d.resid, d.ldr = L.ptr(resid), (_ld(resid) if resid is not None else 0)
+    d.row_map, d.map_len, d.map_stride = L.ptr(row_map), map_len, map_stride
+    d.out_fp32 = int(out.dtype == F32)
+    d.accumulate = int(accumulate)
+    d.col_scale, d.col_scale_n = col_scale, col_scale_n
+    d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+    d.variant = variant
+    L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
+    return out
+
+
+def colsum(X, out, row_scale=None, rows_per_scale=0, accumulate=True, M=None, N=None):
+    M = X.shape[0] if M is None else M
+    N = X.shape[1] if N is None else N
+    L.check(L.load().vmvm_colsum_bf16(X.data_ptr(), M, N, _ld(X), L.ptr(row_scale), rows_per_scale, out.data_ptr(),
+                                      int(accumulate), L.stream()), "colsum")
+    return out
+
+
+def layernorm_fwd(X, gamma, beta, eps, *, M=None, C_=None, nseg=1, src=None, rows_out_per_batch=0, rows_in_per_batch=0, pad_mode=0):
+    M = X.shape[0] if M is None else M
+    Cc = X.shape[1] * nseg if C_ is None else C_
+    Y = torch.empty((M, Cc), device=X.device, dtype=BF16)
+    mean = torch.empty(M, device=X.device, dtype=F32)
+    rstd = torch.empty(M, device=X.device, dtype=F32)
+    d = L.LnFwdDesc()
+    d.X, d.ldx, d.Y, d.ldy = X.data_ptr(), _ld(X), Y.data_ptr(), Cc
+    d.gamma, d.beta, d.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    d.M, d.C, d.nseg = M, Cc, nseg
+    d.src, d.rows_out_per_batch, d.rows_in_per_batch, d.pad_mode = L.ptr(src), rows_out_per_batch, rows_in_per_batch, pad_mode
+    d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
+    L.check(L.load().vmvm_layernorm_fwd(C.byref(d), L.stream()), "layernorm_fwd")
+    return Y, mean, rstd
+
+
+def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=None, nseg=1, src=None, rows_out_per_batch=0,
+                  rows_in_per_batch=0, pad_mode=0, dX_add=None, want_dX2=False, dropout_p=0.0, seed=0, offset=0):
+    M, Cc = dY.shape
+    if dX is None:
+        dX = torch.empty((rows_in if rows_in is not None else M, Cc // nseg), device=dY.device, dtype=BF16)
+    dX2 = torch.empty((M, Cc), device=dY.device, dtype=BF16) if want_dX2 else None
+    d = L.LnBwdDesc()
+    d.dY, d.lddy, d.X, d.ldx = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X)
+    d.gamma, d.mean, d.rstd = gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    d.dX, d.lddx, d.dgamma, d.dbeta = dX.data_ptr(), _ld(dX), dgamma.data_ptr(), dbeta.data_ptr()
+    d.M, d.C, d.nseg = M, Cc, nseg
+    d.src, d.rows_out_per_batch, d.rows_in_per_batch, d.pad_mode = L.ptr(src), rows_out_per_batch, rows_in_per_batch, pad_mode
+    d.dX_add, d.ldadd = L.ptr(dX_add), (_ld(dX_add) if dX_add is not None else 0)
+    d.dX2, d.lddx2 = L.ptr(dX2), Cc
+    d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+    L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
+    return dX, dX2
+
+
+def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
+               keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale):
+    d = L.AttnFwdDesc()
+    d.qkv, d.ld_qkv, d.q_off, d.k_off, d.v_off = qkv.data_ptr(), _ld(qkv), q_off, k_off, v_off
+    d.out, d.ld_out, d.lse = out.data_ptr(), _ld(out), lse.data_ptr()
+    d.nseq, d.L, d.heads, d.head_dim, d.mode, d.scale = nseq, Lq, heads, hd, mode, scale
+    d.bias_table, d.table_len = L.ptr(bias_table), (bias_table.shape[0] if bias_table is not None else 0)
+    d.rc, d.rc0 = L.ptr(rc), rc0
+    d.region, d.n_win = L.ptr(region), n_win
+    d.keymask = L.ptr(keymask)
+    d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+    d.seq_scale, d.seqs_per_scale = L.ptr(seq_scale), seqs_per_scale
+    return d
+
+
+def attention_fwd(qkv, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0, region=None,
+                  n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0):
+    out = torch.empty((nseq * Lq, heads * hd), device=qkv.device, dtype=BF16)
+    lse = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
+    d = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
+                   keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale)
+    L.check(L.load().vmvm_attention_fwd(C.byref(d), L.stream()), "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0,
+                  region=None, n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0,
+                  dbias_table=None):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
+    b = L.AttnBwdDesc()
+    b.f = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
+                     keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale)
+    b.dout, b.ld_dout, b.dqkv, b.ld_dqkv = dout.data_ptr(), _ld(dout), dqkv.data_ptr(), _ld(dqkv)
+    b.dbias_table, b.delta = L.ptr(dbias_table), delta.data_ptr()
+    L.check(L.load().vmvm_attention_bwd(C.byref(b), L.stream()), "attention_bwd")
+    return dqkv
+
+
+def patch_im2col(img):
+    B, T, _, H, W = img.shape
+    cols = torch.empty((B * T * (H // 4) * (W // 4), 96), device=img.device, dtype=BF16)
+    L.check(L.load().vmvm_patch_im2col(img.data_ptr(), cols.data_ptr(), B, T, H, W, L.stream()), "im2col")
+    return cols
+
+
+def encvideo_assemble(fc_out, cls, pos, len_, B, T, hw, Hd):
+    out = torch.empty((B * T * (1 + hw), Hd), device=fc_out.device, dtype=BF16)
+    L.check(L.load().vmvm_encvideo_assemble(fc_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), len_.data_ptr(), out.data_ptr(),
+                                            B, T, hw, Hd, L.stream()), "encvideo_assemble")
+    return out
+
+
+def encvideo_assemble_bwd(dpre, dcls, dpos, dlen, B, T, hw, Hd):
+    dfc = torch.empty((B * T * hw, Hd), device=dpre.device, dtype=BF16)
+    L.check(L.load().vmvm_encvideo_assemble_bwd(dpre.data_ptr(), dfc.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), dlen.data_ptr(),
+                                                B, T, hw, Hd, L.stream()), "encvideo_assemble_bwd")
+    return dfc
+
+
+def bert_embed(txt, word, pos, type0):
+    B, X = txt.shape
+    Hd = word.shape[1]
+    out = torch.empty((B * X, Hd), device=txt.device, dtype=BF16)
+    L.check(L.load().vmvm_bert_embed(txt.data_ptr(), word.data_ptr(), pos.data_ptr(), type0.data_ptr(), out.data_ptr(), B, X, Hd,
+                                     L.stream()), "bert_embed")
+    return out
+
+
+def bert_embed_bwd(txt, dsum, dword, dpos, dtype0):
+    B, X = txt.shape
+    L.check(L.load().vmvm_bert_embed_bwd(txt.data_ptr(), dsum.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dtype0.data_ptr(),
+                                         B, X, dword.shape[1], L.stream()), "bert_embed_bwd")
+
+
+def cross_entropy(logits, V, target, loss_sum, want_grad=True, ld_d=None):
+    """loss_sum (f32[1], device) += mean CE over target != -1 ; returns dlogits (bf16) or None."""
+    M = logits.shape[0]
+    n_valid = torch.empty(1, device=logits.device, dtype=F32)
+    L.check(L.load().vmvm_count_valid(target.data_ptr(), M, n_valid.data_ptr(), L.stream()), "count_valid")
+    ld_d = ld_d or logits.shape[1]
+    dlog = torch.empty((M, ld_d), device=logits.device, dtype=BF16) if want_grad else None
+    L.check(L.load().vmvm_cross_entropy(logits.data_ptr(), _ld(logits), M, V, target.data_ptr(), n_valid.data_ptr(),
+                                        loss_sum.data_ptr(), L.ptr(dlog), ld_d, L.stream()), "cross_entropy")
+    return dlog
+
+
+def pixel_l1(pred, img, cov, mask_sum, loss_sum, B, T, h, w, ps):
+    dpred = torch.empty_like(pred)
+    L.check(L.load().vmvm_pixel_l1(pred.data_ptr(), img.data_ptr(), cov.data_ptr(), mask_sum.data_ptr(), loss_sum.data_ptr(),
+                                   dpred.data_ptr(), B, T, h, w, ps, L.stream()), "pixel_l1")
+    return dpred
+
+
+def rowdot(hid, w, b, inv_temp):
+    M, K = hid.shape
+    out = torch.empty(M, device=hid.device, dtype=F32)
+    L.check(L.load().vmvm_rowdot(hid.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), inv_temp, out.data_ptr(), L.stream()), "rowdot")
+    return out
+
+
+def rowdot_bwd(hid, w, dout, inv_temp, dw, db):
+    M, K = hid.shape
+    dhid = torch.empty_like(hid)
+    L.check(L.load().vmvm_rowdot_bwd(hid.data_ptr(), M, K, w.data_ptr(), dout.data_ptr(), inv_temp, dhid.data_ptr(), dw.data_ptr(),
+                                     db.data_ptr(), L.stream()), "rowdot_bwd")
+    return dhid
+
+
+def cast_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    L.check(L.load().vmvm_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()), "cast")
+    return dst
+
+
+def add_bf16(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().vmvm_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), L.stream()), "add")
+    return out
+
+
+def gather_rows(src, idx, M, rows_out_per_batch=0, rows_in_per_batch=0):
+    Cc = src.shape[1]
+    dst = torch.empty((M, Cc), device=src.device, dtype=BF16)
+    L.check(L.load().vmvm_gather_rows_bf16(src.data_ptr(), _ld(src), idx.data_ptr(), dst.data_ptr(), Cc, M, Cc, rows_out_per_batch,
+                                           rows_in_per_batch, L.stream()), "gather_rows")
+    return dst
+
+
+def sumsq(g, out):
+    L.check(L.load().vmvm_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.stream()), "sumsq")
+    return out
+
+
+def adamw(param, grad, m, v, param_bf16, *, lr, weight_decay, beta1, beta2, eps, step, sumsq_t=None, max_grad_norm=0.0, grad_scale=1.0):
+    d = L.AdamWDesc()
+    d.param, d.grad, d.m, d.v, d.param_bf16 = param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), L.ptr(param_bf16)
+    d.n = param.numel()
+    d.lr, d.weight_decay, d.beta1, d.beta2, d.eps = lr, weight_decay, beta1, beta2, eps
+    d.bias_corr1, d.bias_corr2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    d.sumsq, d.max_grad_norm, d.grad_scale = L.ptr(sumsq_t), max_grad_norm, grad_scale
+    L.check(L.load().vmvm_adamw(C.byref(d), L.stream()), "adamw")
+
+
+def probe_tr16():
+    out = torch.empty(256, device="cuda", dtype=torch.int32)
+    L.check(L.load().vmvm_probe_tr16(out.data_ptr(), L.stream()), "probe")
+    return out.cpu().view(64, 4)

@@ -1,0 +1,136 @@
+"""ctypes binding of libvmvm.so (include/vmvm.h).  No CPU fallback: if the HIP library is missing or a
+call fails this raises -- the product path never routes through the oracle or eager PyTorch math."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmvm.so")
+
+c_void_p, c_int, c_float, c_u64, c_i64 = C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_int64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
+                ("a_kmajor", c_int), ("b_kmajor", c_int),
+                ("bias", c_void_p),
+                ("row_scale", c_void_p), ("rows_per_scale", c_int),
+                ("scale_bias_only", c_int),
+                ("act", c_int),
+                ("aux", c_void_p), ("ldaux", c_int),
+                ("C2", c_void_p), ("ldc2", c_int),
+                ("resid", c_void_p), ("ldr", c_int),
+                ("row_map", c_void_p), ("map_len", c_int), ("map_stride", c_int),
+                ("out_fp32", c_int), ("accumulate", c_int),
+                ("col_scale", c_float), ("col_scale_n", c_int),
+                ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
+                ("variant", c_int)]
+
+
+class LnFwdDesc(C.Structure):
+    _fields_ = [("X", c_void_p), ("ldx", c_int), ("Y", c_void_p), ("ldy", c_int),
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+                ("M", c_int), ("C", c_int), ("nseg", c_int),
+                ("src", c_void_p), ("rows_out_per_batch", c_int), ("rows_in_per_batch", c_int),
+                ("pad_mode", c_int), ("mean", c_void_p), ("rstd", c_void_p)]
+
+
+class LnBwdDesc(C.Structure):
+    _fields_ = [("dY", c_void_p), ("lddy", c_int), ("X", c_void_p), ("ldx", c_int),
+                ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("dX", c_void_p), ("lddx", c_int), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("M", c_int), ("C", c_int), ("nseg", c_int),
+                ("src", c_void_p), ("rows_out_per_batch", c_int), ("rows_in_per_batch", c_int),
+                ("pad_mode", c_int),
+                ("dX_add", c_void_p), ("ldadd", c_int),
+                ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64)]
+
+
+class AttnFwdDesc(C.Structure):
+    _fields_ = [("qkv", c_void_p), ("ld_qkv", c_int), ("q_off", c_int), ("k_off", c_int), ("v_off", c_int),
+                ("out", c_void_p), ("ld_out", c_int), ("lse", c_void_p),
+                ("nseq", c_int), ("L", c_int), ("heads", c_int), ("head_dim", c_int), ("mode", c_int),
+                ("scale", c_float),
+                ("bias_table", c_void_p), ("table_len", c_int),
+                ("rc", c_void_p), ("rc0", c_int),
+                ("region", c_void_p), ("n_win", c_int),
+                ("keymask", c_void_p),
+                ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
+                ("seq_scale", c_void_p), ("seqs_per_scale", c_int)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("f", AttnFwdDesc), ("dout", c_void_p), ("ld_dout", c_int), ("dqkv", c_void_p), ("ld_dqkv", c_int),
+                ("dbias_table", c_void_p), ("delta", c_void_p)]
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("param_bf16", c_void_p),
+                ("n", c_i64),
+                ("lr", c_float), ("weight_decay", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("bias_corr1", c_float), ("bias_corr2", c_float),
+                ("sumsq", c_void_p), ("max_grad_norm", c_float), ("grad_scale", c_float)]
+
+
+_PROTOS = {
+    "vmvm_version": ([], c_int),
+    "vmvm_last_hip_error": ([], c_int),
+    "vmvm_gemm_bf16": ([C.POINTER(GemmDesc), c_void_p], c_int),
+    "vmvm_colsum_bf16": ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
+    "vmvm_layernorm_fwd": ([C.POINTER(LnFwdDesc), c_void_p], c_int),
+    "vmvm_layernorm_bwd": ([C.POINTER(LnBwdDesc), c_void_p], c_int),
+    "vmvm_attention_fwd": ([C.POINTER(AttnFwdDesc), c_void_p], c_int),
+    "vmvm_attention_bwd": ([C.POINTER(AttnBwdDesc), c_void_p], c_int),
+    "vmvm_patch_im2col": ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_encvideo_assemble": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_encvideo_assemble_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_bert_embed": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_bert_embed_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_count_valid": ([c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "vmvm_cross_entropy": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "vmvm_pixel_l1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_rowdot": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "vmvm_rowdot_bwd": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p], c_int),
+    "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
+    "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvmvm.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built -- run `python -m pytorch_empirical_mvm_amd.build` "
+                               "(there is NO CPU / eager fallback for the VIOLETv2 step)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in _PROTOS.items():
+            fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+            fn.argtypes, fn.restype = args, res
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libvmvm {what} failed: rc={rc} (hip error {load().vmvm_last_hip_error()})")

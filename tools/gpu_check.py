@@ -1,0 +1,499 @@
+#!/usr/bin/env python3
+"""Development harness: run every libvmvm kernel against a plain torch reference on the GPU and print error
+summaries WITHOUT stopping at the first failure (one gpurun trip -> maximum information).
+The pytest suite (tests/test_kernels_gpu.py) asserts the same properties."""
+import math
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_empirical_mvm_amd import kernels as K  # noqa: E402
+from pytorch_empirical_mvm_amd import swin_index as SI  # noqa: E402
+
+dev = "cuda"
+BF, F32 = torch.bfloat16, torch.float32
+RESULTS = []
+
+
+def rep(name, got, ref, tol=2e-2):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    bad = not math.isfinite(err) or err / scale > tol
+    RESULTS.append((name, err, scale, bad))
+    print(f"{'FAIL' if bad else 'ok  '} {name:55s} maxerr={err:.4e} refmax={scale:.4e} rel={err / scale:.3e}", flush=True)
+    return not bad
+
+
+def run(fn):
+    try:
+        fn()
+    except Exception:
+        RESULTS.append((fn.__name__, float('nan'), 0, True))
+        print(f"EXC  {fn.__name__}")
+        traceback.print_exc()
+    torch.cuda.synchronize()
+
+
+def rnd(*shape, scale=1.0, dtype=BF):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------ probe
+def check_probe():
+    m = K.probe_tr16()
+    exp = torch.zeros(64, 4, dtype=torch.int32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for e in range(4):
+            exp[lane, e] = (4 * g + e) * 16 + i
+    ok = torch.equal(m, exp)
+    print("probe tr16 mapping as assumed:", ok)
+    if not ok:
+        print(m[:20])
+    RESULTS.append(("probe_tr16", 0.0, 1.0, not ok))
+
+
+# ------------------------------------------------------------------ gemm
+def check_gemm_layouts():
+    for (M, N, K_) in [(392 * 3, 384, 128), (1000, 30528, 768), (256, 128, 96), (130, 72, 64), (4096, 512, 2048)]:
+        A = rnd(M, K_)
+        B = rnd(N, K_)
+        ref = A.float() @ B.float().t()
+        rep(f"gemm NT {M}x{N}x{K_}", K.gemm(A, B), ref)
+        if M % 8 == 0 and N % 8 == 0:
+            At, Bt = A.t().contiguous(), B.t().contiguous()
+            for var in (0, 1):
+                rep(f"gemm NN(b n-major) v{var} {M}x{N}x{K_}", K.gemm(A, Bt, b_kmajor=False, variant=var), ref)
+                rep(f"gemm TN(a m-major,b n-major) v{var} {M}x{N}x{K_}", K.gemm(At, Bt, a_kmajor=False, b_kmajor=False, variant=var), ref)
+                rep(f"gemm TT(a m-major) v{var} {M}x{N}x{K_}", K.gemm(At, B, a_kmajor=False, variant=var), ref)
+
+
+def check_gemm_epilogues():
+    M, N, K_ = 784, 256, 128
+    A, B = rnd(M, K_), rnd(N, K_, scale=0.1)
+    bias = torch.randn(N, device=dev)
+    base = A.float() @ B.float().t()
+    rep("gemm bias", K.gemm(A, B, bias=bias), base + bias)
+    pre = torch.empty(M, N, device=dev, dtype=BF)
+    out = K.gemm(A, B, bias=bias, act=1, out_preact=pre)
+    rep("gemm gelu", out, torch.nn.functional.gelu(base + bias))
+    rep("gemm gelu preact", pre, base + bias)
+    rep("gemm relu", K.gemm(A, B, bias=bias, act=2), torch.relu(base + bias))
+    u = rnd(M, N)
+    uf = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).sum().backward()
+    rep("gemm act3 gelu'", K.gemm(A, B, act=3, aux=u), base * uf.grad)
+    rep("gemm act4 relu'", K.gemm(A, B, act=4, aux=u), base * (u.float() > 0))
+    rs = torch.rand(4, device=dev) + 0.5
+    rows = torch.arange(M, device=dev) // 196
+    rep("gemm row_scale", K.gemm(A, B, bias=bias, row_scale=rs, rows_per_scale=196), (base + bias) * rs[rows, None])
+    rep("gemm scale_bias_only", K.gemm(A, B, bias=bias, row_scale=rs, rows_per_scale=196, scale_bias_only=True), base + bias * rs[rows, None])
+    r = rnd(M, N)
+    rep("gemm resid", K.gemm(A, B, resid=r), base + r.float())
+    rep("gemm fp32 out", K.gemm(A, B, out_dtype=F32), base, tol=1e-3)
+    acc = torch.randn(M, N, device=dev)
+    acc0 = acc.clone()
+    K.gemm(A, B, out=acc, accumulate=True)
+    rep("gemm fp32 accumulate", acc, base + acc0, tol=1e-3)
+    rep("gemm col_scale", K.gemm(A, B, bias=bias, col_scale=0.25, col_scale_n=64),
+        torch.cat([base[:, :64] * 0.25, base[:, 64:]], 1) + bias)
+    # row map: 2 clips x 392 slots -> token order, with pads
+    perm = torch.randperm(392, device=dev).int()
+    perm[::50] = -1
+    resid = rnd(2 * 392, N)
+    out = torch.zeros(2 * 392, N, device=dev, dtype=BF)
+    K.gemm(A, B, resid=resid, row_map=perm, map_len=392, map_stride=392, out=out)
+    ref = torch.zeros(2 * 392, N, device=dev)
+    for b in range(2):
+        for s in range(392):
+            d = int(perm[s])
+            if d >= 0:
+                ref[b * 392 + d] = base[b * 392 + s] + resid[b * 392 + d].float()
+    rep("gemm row_map + resid", out, ref)
+    # dropout: keep fraction and scaling
+    o = K.gemm(A, B, dropout_p=0.1, seed=1234, offset=7).float()
+    kept = (o != 0)
+    frac = 1.0 - kept.float().mean().item()
+    print(f"     dropout drop fraction {frac:.4f} (want 0.1)")
+    rep("gemm dropout kept values", torch.where(kept, o, torch.zeros_like(o)), torch.where(kept, base / 0.9, torch.zeros_like(base)))
+    o2 = K.gemm(A, B, dropout_p=0.1, seed=1234, offset=7).float()
+    RESULTS.append(("gemm dropout deterministic", 0, 1, not torch.equal(o, o2) or abs(frac - 0.1) > 0.01))
+
+
+# ------------------------------------------------------------------ layernorm
+def check_ln():
+    for C_ in (96, 128, 512, 768, 1024, 2048, 3072):
+        M = 777
+        x = rnd(M, C_)
+        g = torch.randn(C_, device=dev) * 0.1 + 1
+        b = torch.randn(C_, device=dev) * 0.1
+        y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5)
+        xf = x.float().requires_grad_(True)
+        gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xf, (C_,), gf, bf, 1e-5)
+        rep(f"ln fwd C={C_}", y, ref)
+        dy = rnd(M, C_)
+        ref.backward(dy.float())
+        dg, db = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+        add = rnd(M, C_)
+        dx, dx2 = K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dX_add=add, want_dX2=True, dropout_p=0.1, seed=5, offset=3)
+        rep(f"ln bwd dx(+add) C={C_}", dx, xf.grad + add.float())
+        rep(f"ln bwd dgamma C={C_}", dg, gf.grad)
+        rep(f"ln bwd dbeta C={C_}", db, bf.grad)
+        if C_ == 768:
+            # dX2 must equal the GEMM-epilogue dropout mask pattern (same seed/offset, N=C)
+            A = torch.eye(128, device=dev, dtype=BF)
+            ones = K.gemm(torch.ones(M, 128, device=dev, dtype=BF), torch.ones(C_, 128, device=dev, dtype=BF), dropout_p=0.1, seed=5, offset=3)
+            mask = (ones.float() != 0)
+            rep("ln bwd dX2 mask consistent with gemm dropout", dx2, torch.where(mask, dx.float() / 0.9, torch.zeros_like(dx.float())))
+
+
+def check_ln_gather():
+    # window map (with padding + shift) and merge map
+    B, D, H, W, C_ = 2, 12, 24, 20, 64
+    ws, ss = SI.get_window_size((D, H, W), (8, 7, 7), (4, 3, 3))
+    m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+    Lp, Lq = m.size, D * H * W
+    src = torch.from_numpy(m).to(dev)
+    x = rnd(B * Lq, C_)
+    g = torch.randn(C_, device=dev) * 0.1 + 1
+    b = torch.randn(C_, device=dev) * 0.1
+    y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5, M=B * Lp, C_=C_, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=Lq, pad_mode=0)
+    xf = x.float().requires_grad_(True)
+    gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ln = torch.nn.functional.layer_norm(xf, (C_,), gf, bf, 1e-5).view(B, Lq, C_)
+    srcl = src.long()
+    ref = torch.where((srcl >= 0)[None, :, None], ln[:, srcl.clamp(min=0)], torch.zeros((), device=dev)).reshape(B * Lp, C_)
+    rep("ln window-gather fwd", y, ref)
+    dy = rnd(B * Lp, C_)
+    ref.backward(dy.float())
+    dg, db = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    add = rnd(B * Lq, C_)
+    dx, _ = K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, rows_in=B * Lq, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=Lq,
+                            pad_mode=0, dX_add=add)
+    rep("ln window-gather bwd dx(+add)", dx, xf.grad + add.float())
+    rep("ln window-gather bwd dgamma", dg, gf.grad)
+    rep("ln window-gather bwd dbeta", db, bf.grad)
+    # gather_rows (window_partition of a gradient)
+    gr = K.gather_rows(x, src, B * Lp, Lp, Lq)
+    refg = torch.where((srcl >= 0)[None, :, None], x.float().view(B, Lq, C_)[:, srcl.clamp(min=0)], torch.zeros((), device=dev)).reshape(B * Lp, C_)
+    rep("gather_rows window", gr, refg, tol=0)
+    # merge
+    D, H, W = 3, 7, 5
+    mm, (D2, H2, W2) = SI.merge_map(D, H, W)
+    srcm = torch.from_numpy(mm).to(dev)
+    Lq, Lo = D * H * W, D2 * H2 * W2
+    x = rnd(B * Lq, C_)
+    g4 = torch.randn(4 * C_, device=dev) * 0.1 + 1
+    b4 = torch.randn(4 * C_, device=dev) * 0.1
+    y, mean, rstd = K.layernorm_fwd(x, g4, b4, 1e-5, M=B * Lo, C_=4 * C_, nseg=4, src=srcm, rows_out_per_batch=Lo, rows_in_per_batch=Lq, pad_mode=1)
+    xf = x.float().requires_grad_(True)
+    gf, bf = g4.clone().requires_grad_(True), b4.clone().requires_grad_(True)
+    sl = srcm.long().view(Lo, 4)
+    cat = torch.where((sl >= 0)[None, :, :, None], xf.view(B, Lq, C_)[:, sl.clamp(min=0)], torch.zeros((), device=dev)).reshape(B * Lo, 4 * C_)
+    ref = torch.nn.functional.layer_norm(cat, (4 * C_,), gf, bf, 1e-5)
+    rep("ln merge-gather fwd", y, ref)
+    dy = rnd(B * Lo, 4 * C_)
+    ref.backward(dy.float())
+    dg, db = torch.zeros(4 * C_, device=dev), torch.zeros(4 * C_, device=dev)
+    dx, _ = K.layernorm_bwd(dy, x, g4, mean, rstd, dg, db, rows_in=B * Lq, nseg=4, src=srcm, rows_out_per_batch=Lo, rows_in_per_batch=Lq, pad_mode=1)
+    rep("ln merge-gather bwd dx", dx, xf.grad)
+    rep("ln merge-gather bwd dgamma", dg, gf.grad)
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(q, k, v, bias, drop_mask=None):
+    s = q @ k.transpose(-1, -2) + bias
+    p = s.softmax(-1)
+    if drop_mask is not None:
+        p = p * drop_mask
+    return p @ v
+
+
+def check_attn_window():
+    for (dims, B, heads) in [((8, 14, 14), 2, 4), ((4, 7, 7), 3, 3), ((12, 24, 20), 1, 2)]:
+        D, H, W = dims
+        win = (8, 7, 7)
+        for shifted in (False, True):
+            ws, ss = SI.get_window_size(dims, win, (4, 3, 3) if shifted else (0, 0, 0))
+            m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+            N = ws[0] * ws[1] * ws[2]
+            nW = m.size // N
+            reg = SI.region_ids(Dp, Hp, Wp, ws, ss)
+            rc, rc0 = SI.rc_codes(N, win)
+            C_ = heads * 32
+            nseq = B * nW
+            qkv = rnd(nseq * N, 3 * C_, scale=1.0)
+            table = (torch.randn((2 * 8 - 1) * 13 * 13, heads, device=dev) * 0.5)
+            rc_t = torch.from_numpy(rc).to(dev)
+            reg_t = torch.from_numpy(reg).to(dev) if reg is not None else None
+            sscale = (torch.rand(B, device=dev) + 0.5)
+            out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t,
+                                       rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW)
+            qf = qkv.float().requires_grad_(True)
+            tf = table.clone().requires_grad_(True)
+            x = qf.view(nseq, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+            idx = (rc_t[:, None] - rc_t[None, :] + rc0).long()
+            bias = tf[idx.reshape(-1)].view(N, N, heads).permute(2, 0, 1)[None]
+            if reg is not None:
+                mk = torch.where(reg_t[:, :, None] != reg_t[:, None, :], -100.0, 0.0)     # (nW,N,N)
+                bias = bias + mk.repeat(B, 1, 1)[:, None]
+            o = attn_ref(x[0], x[1], x[2], bias)                                              # (nseq, heads, N, 32)
+            sc = sscale.repeat_interleave(nW)[:, None, None, None]
+            ref = (o * sc).transpose(1, 2).reshape(nseq * N, C_)
+            tag = f"win attn {dims} shifted={shifted}"
+            rep(tag + " fwd", out, ref)
+            dout = rnd(nseq * N, C_)
+            ref.backward(dout.float())
+            dtab = torch.zeros_like(table)
+            dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table,
+                                   rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW, dbias_table=dtab)
+            gq = qf.grad.clone()
+            gq[:, :C_] *= 32 ** -0.5                      # kernel returns d(q_linear) = scale * d(q_scaled)
+            rep(tag + " bwd dq", dqkv[:, :C_], gq[:, :C_])
+            rep(tag + " bwd dk", dqkv[:, C_:2 * C_], gq[:, C_:2 * C_])
+            rep(tag + " bwd dv", dqkv[:, 2 * C_:], gq[:, 2 * C_:])
+            rep(tag + " bwd dtable", dtab, tf.grad)
+
+
+def check_attn_bert():
+    for (nseq, Lq, heads) in [(3, 432, 12), (2, 232, 4), (2, 100, 2)]:
+        Hd = heads * 64
+        qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+        km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+        for s in range(nseq):
+            km[s, Lq - 5 * (s + 1):] = 0
+        out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km)
+        qf = qkv.float().requires_grad_(True)
+        x = qf.view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        bias = torch.where(km.bool(), 0.0, float("-inf"))[:, None, None, :]
+        o = attn_ref(x[0] * 0.125, x[1], x[2], bias)
+        ref = o.transpose(1, 2).reshape(nseq * Lq, Hd)
+        tag = f"bert attn nseq={nseq} L={Lq} h={heads}"
+        rep(tag + " fwd", out, ref)
+        dout = rnd(nseq * Lq, Hd)
+        ref.backward(dout.float())
+        dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km)
+        rep(tag + " bwd dq", dqkv[:, :Hd], qf.grad[:, :Hd])
+        rep(tag + " bwd dk", dqkv[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
+        rep(tag + " bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+    # dropout consistency: recover the mask from V = I trick, then compare fwd/bwd with the same mask
+    nseq, Lq, heads = 1, 64, 1
+    Hd = 64
+    qkv = torch.zeros(nseq * Lq, 3 * Hd, device=dev, dtype=BF)
+    qkv[:, 2 * Hd:] = torch.eye(64, device=dev, dtype=BF)           # V = I, q=k=0 -> P uniform = 1/64
+    out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=11, offset=5)
+    pm = out.float() * 64.0                                          # = mask/(1-p_eff)
+    frac = (pm == 0).float().mean().item()
+    print(f"     attn dropout drop fraction {frac:.4f} (p_eff = 26/256 = 0.1016)")
+    mask = (pm != 0).float() * (256.0 / 230.0)
+    qkv = rnd(nseq * Lq, 3 * Hd)
+    out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=11, offset=5)
+    qf = qkv.float().requires_grad_(True)
+    x = qf.view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    o = attn_ref(x[0] * 0.125, x[1], x[2], 0.0, mask[None, None])
+    ref = o.transpose(1, 2).reshape(nseq * Lq, Hd)
+    rep("bert attn dropout fwd (mask recovered)", out, ref)
+    dout = rnd(nseq * Lq, Hd)
+    ref.backward(dout.float())
+    dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=11, offset=5)
+    rep("bert attn dropout bwd dq", dqkv[:, :Hd], qf.grad[:, :Hd])
+    rep("bert attn dropout bwd dk", dqkv[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
+    rep("bert attn dropout bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+
+
+# ------------------------------------------------------------------ misc
+def check_misc():
+    B, T, H, W = 2, 4, 64, 96
+    img = torch.randn(B, T, 3, H, W, device=dev)
+    cols = K.patch_im2col(img)
+    x = torch.nn.functional.pad(img.transpose(1, 2), (0, 0, 0, 0, 0, 1))                    # (B,3,T+1,H,W)
+    w = torch.randn(32, 3, 2, 4, 4, device=dev)
+    ref = torch.nn.functional.conv3d(x.to(BF).float(), w, stride=(1, 4, 4)).permute(0, 2, 3, 4, 1).reshape(-1, 32)
+    rep("im2col (via conv3d)", cols.float() @ w.view(32, 96).t(), ref, tol=1e-3)
+    # encvideo assemble
+    hw, Hd = 6, 64
+    fc = rnd(B * T * hw, Hd)
+    cls, pos, ln = torch.randn(Hd, device=dev), torch.randn(1 + 14 * 14, Hd, device=dev), torch.randn(6, Hd, device=dev)
+    out = K.encvideo_assemble(fc, cls, pos, ln, B, T, hw, Hd)
+    ref = torch.cat([cls.expand(B, T, 1, Hd), fc.float().view(B, T, hw, Hd)], 2) + pos[None, None, :1 + hw] + ln[None, :T, None]
+    rep("encvideo assemble", out, ref.reshape(-1, Hd))
+    dpre = rnd(B * T * (1 + hw), Hd)
+    dcls, dpos, dlen = torch.zeros(Hd, device=dev), torch.zeros_like(pos), torch.zeros_like(ln)
+    dfc = K.encvideo_assemble_bwd(dpre, dcls, dpos, dlen, B, T, hw, Hd)
+    d4 = dpre.float().view(B, T, 1 + hw, Hd)
+    rep("encvideo bwd dfc", dfc, d4[:, :, 1:].reshape(-1, Hd), tol=0)
+    rep("encvideo bwd dcls", dcls, d4[:, :, 0].sum((0, 1)), tol=1e-3)
+    rep("encvideo bwd dpos", dpos[:1 + hw], d4.sum((0, 1)), tol=1e-3)
+    rep("encvideo bwd dlen", dlen[:T], d4.sum((0, 2)), tol=1e-3)
+    # bert embed
+    X, V = 32, 1000
+    txt = torch.randint(0, V, (B, X), device=dev)
+    word, pemb, temb = torch.randn(V, Hd, device=dev), torch.randn(512, Hd, device=dev), torch.randn(2, Hd, device=dev)
+    out = K.bert_embed(txt, word, pemb, temb[0])
+    rep("bert embed", out, (word[txt] + pemb[:X][None] + temb[0]).reshape(-1, Hd))
+    ds = rnd(B * X, Hd)
+    dword, dposb, dtype0 = torch.zeros_like(word), torch.zeros_like(pemb), torch.zeros(Hd, device=dev)
+    K.bert_embed_bwd(txt, ds, dword, dposb, dtype0)
+    refw = torch.zeros_like(word).index_add_(0, txt.reshape(-1), ds.float())
+    rep("bert embed bwd dword", dword, refw, tol=1e-3)
+    rep("bert embed bwd dpos", dposb[:X], ds.float().view(B, X, Hd).sum(0), tol=1e-3)
+    rep("bert embed bwd dtype", dtype0, ds.float().sum(0), tol=1e-3)
+    # cross entropy
+    M, V, ld = 64, 30522, 30528
+    logits = torch.randn(M, ld, device=dev) * 3
+    tgt = torch.randint(0, V, (M,), device=dev)
+    tgt[::3] = -1
+    loss = torch.zeros(1, device=dev)
+    dlog = K.cross_entropy(logits, V, tgt, loss)
+    lf = logits[:, :V].clone().requires_grad_(True)
+    refl = torch.nn.functional.cross_entropy(lf, tgt, ignore_index=-1)
+    refl.backward()
+    rep("cross entropy loss", loss, refl.detach().view(1), tol=1e-4)
+    rep("cross entropy dlogits", dlog[:, :V], lf.grad, tol=1e-2)
+    rep("cross entropy dlogits pad", dlog[:, V:], torch.zeros(M, ld - V, device=dev), tol=0)
+    # pixel l1
+    B, T, h, w, ps = 2, 2, 3, 2, 32
+    pred = rnd(B * T * h * w, 3 * ps * ps)
+    tgt_img = torch.randn(B, T, 3, h * ps, w * ps, device=dev)
+    cov = (torch.rand(B, T, h, w, device=dev) < 0.4).to(torch.uint8)
+    cov[0, 0, 0, 0] = 1
+    full = cov.float()[:, :, None, :, None, :, None].expand(-1, -1, 3, -1, ps, -1, ps).reshape(B, T, 3, h * ps, w * ps)
+    msum = full.sum().view(1)
+    loss = torch.zeros(1, device=dev)
+    dpred = K.pixel_l1(pred, tgt_img, cov.view(-1), msum, loss, B, T, h, w, ps)
+    pf = pred.float().requires_grad_(True)
+    xx = pf.view(B * T, h, w, 3 * ps * ps).permute(0, 3, 1, 2)
+    xx = torch.nn.functional.pixel_shuffle(xx, ps).view(B, T, 3, h * ps, w * ps)
+    refl = ((xx - tgt_img).abs() * full).sum() / (full.sum() + 1e-5) / 3
+    refl.backward()
+    rep("pixel l1 loss", loss, refl.detach().view(1), tol=1e-4)
+    rep("pixel l1 dpred", dpred, pf.grad, tol=1e-2)
+    # rowdot
+    M, Kd = 12, 1536
+    hid = rnd(M, Kd)
+    wv, bv = torch.randn(Kd, device=dev) * 0.05, torch.randn(1, device=dev)
+    o = K.rowdot(hid, wv, bv, 20.0)
+    rep("rowdot", o, (hid.float() @ wv + bv) * 20.0, tol=1e-3)
+    do = torch.randn(M, device=dev)
+    dw, dbv = torch.zeros(Kd, device=dev), torch.zeros(1, device=dev)
+    dh = K.rowdot_bwd(hid, wv, do, 20.0, dw, dbv)
+    rep("rowdot bwd dhid", dh, (do * 20.0)[:, None] * wv[None])
+    rep("rowdot bwd dw", dw, (do * 20.0) @ hid.float(), tol=1e-3)
+    rep("rowdot bwd db", dbv, (do * 20.0).sum().view(1), tol=1e-3)
+    # colsum
+    Xc = rnd(5000, 264)
+    o = torch.zeros(264, device=dev)
+    rs = torch.rand(5, device=dev)
+    K.colsum(Xc, o, rs, 1000)
+    rep("colsum row-scaled", o, (Xc.float() * rs.repeat_interleave(1000)[:, None]).sum(0), tol=1e-3)
+    # optimizer
+    n = 100003
+    p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 3
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.zeros(n, device=dev, dtype=BF)
+    ss = torch.zeros(1, device=dev)
+    K.sumsq(g, ss)
+    rep("sumsq", ss, (g.double() ** 2).sum().float().view(1), tol=1e-4)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.98), weight_decay=1e-3)
+    for step in (1, 2):
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        K.adamw(p, g, m, v, pb, lr=1e-2, weight_decay=1e-3, beta1=0.9, beta2=0.98, eps=1e-8, step=step, sumsq_t=ss, max_grad_norm=1.0)
+    rep("adamw 2 steps (clip)", p, pr.detach(), tol=1e-5)
+    rep("adamw bf16 shadow", pb, p, tol=1e-2)
+
+
+def bench_gemm():
+    print("---- gemm timing (ms, TFLOP/s) vs torch.matmul (hipBLASLt ceiling)")
+    for (M, N, K_) in [(8192, 8192, 8192), (69120, 3072, 768), (69120, 768, 3072), (802816, 384, 128), (50176, 2048, 512)]:
+        A, B = rnd(M, K_), rnd(N, K_)
+        for name, fn in (("vmvm", lambda: K.gemm(A, B)), ("torch", lambda: A @ B.t())):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"     {name:6s} {M}x{N}x{K_}: {ms:.3f} ms  {2.0 * M * N * K_ / ms / 1e9:.1f} TF")
+        Bt = B.t().contiguous()
+        At = A.t().contiguous()
+        for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False))):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"     {name:6s} {M}x{N}x{K_}: {ms:.3f} ms  {2.0 * M * N * K_ / ms / 1e9:.1f} TF")
+
+
+def bench_attn():
+    print("---- attention timing")
+    B, heads, N = 32, 16, 392
+    nW = 4
+    nseq = B * nW
+    C_ = heads * 32
+    qkv = rnd(nseq * N, 3 * C_)
+    rc, rc0 = SI.rc_codes(N, (8, 7, 7))
+    rc_t = torch.from_numpy(rc).to(dev)
+    table = torch.randn(2535, heads, device=dev) * 0.1
+    reg = torch.from_numpy(SI.region_ids(8, 14, 14, (8, 7, 7), (0, 3, 3))).to(dev)
+    f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
+    out, lse = f()
+    dout = rnd(nseq * N, C_)
+    dtab = torch.zeros_like(table)
+    b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab)
+    fl = 4.0 * nseq * heads * N * N * 32
+    for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF (stage-3 shape, B=32)")
+    nseq, Lq, heads = 160, 432, 12
+    Hd = 768
+    qkv = rnd(nseq * Lq, 3 * Hd)
+    km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+    f = lambda: K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    out, lse = f()
+    dout = rnd(nseq * Lq, Hd)
+    b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    fl = 4.0 * nseq * heads * Lq * Lq * 64
+    for name, fn, mult in (("bert fwd", f, 1), ("bert bwd", b, 2.5)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF (B=32 x 5 seqs)")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["probe", "gemm", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
+    table = dict(probe=check_probe, gemm=check_gemm_layouts, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
+                 attnw=check_attn_window, attnb=check_attn_bert, misc=check_misc)
+    for w in which:
+        if w == "bench":
+            run(bench_gemm); run(bench_attn)
+        else:
+            run(table[w])
+    bad = [r for r in RESULTS if r[3]]
+    print(f"==== {len(RESULTS) - len(bad)} ok, {len(bad)} FAILED")
+    for r in bad:
+        print("   FAILED:", r[0])
