@@ -39,8 +39,9 @@ int vmvm_last_hip_error(void);
  * Operand layouts:  a_kmajor=1: A is [M][lda] (k contiguous);  a_kmajor=0: A is [K][lda] (m contiguous)
  *                   b_kmajor=1: B is [N][ldb] (k contiguous);  b_kmajor=0: B is [K][ldb] (n contiguous)
  *   forward  Y=X W^T : (1,1)      dgrad dX=dY W : (1,0)      wgrad dW=dY^T X : (0,0)
- * Every contiguous extent (K for k-major, M/N for m/n-major, ld*) must be a multiple of 8; N%4==0.
- * Epilogue order: v = acc; v *= col_scale (n < col_scale_n); v += bias[n];
+ * ld* must be multiples of 8 and cover the contiguous extent rounded up to 8 (operands are read in 16-byte chunks;
+ * a chunk straddling the logical extent must still lie inside the row); N%4==0.
+ * Epilogue order: v = acc; v += bias[n]; v *= col_scale (n < col_scale_n);
  *   act (0 none, 1 GELU-erf [C2 receives the pre-activation], 2 ReLU, 3 multiply by GELU'(aux[m,n]),
  *        4 multiply by (aux[m,n] > 0));
  *   v *= row_scale[m/rows_per_scale] ; dropout(p, Philox(seed, offset + m*N+n)) ; + resid[dst,n] ; store at row dst where
@@ -88,6 +89,7 @@ typedef struct {
   const int32_t* src; int32_t rows_out_per_batch, rows_in_per_batch;
   int32_t pad_mode;                      /* 0: src<0 -> zero OUTPUT row ; 1: src<0 -> zero INPUT segment */
   float* mean; float* rstd;
+  int32_t x_fp32;                        /* X is f32 (identity map, C <= 512): PatchEmbed3D keeps its conv output in f32 */
 } vmvm_ln_fwd_desc;
 int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream);
 
@@ -103,6 +105,7 @@ typedef struct {
   const void* dX_add; int32_t ldadd;     /* optional bf16, indexed like dX (source rows): dX = LNbwd + dX_add (residual gradient) */
   /* optional second output dX2 = dropout_mask(seed, offset + m*C+c) * dX / (1-p)  (HF hidden dropout backward) */
   void* dX2; int32_t lddx2; float dropout_p; uint64_t seed, offset;
+  int32_t x_fp32;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
 
@@ -147,8 +150,11 @@ int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
  * Small fused kernels
  * ------------------------------------------------------------------------------------------ */
 /* PatchEmbed3D im2col (video_swin.py:390-401): img f32 (B,T,3,H,W) [the reference transposes to (B,3,T,H,W)
- * first, model.py:39] -> cols bf16 [B*T*(H/4)*(W/4)][96], k = c*32 + dt*16 + dy*4 + dx ; frame T is the zero pad. */
-int vmvm_patch_im2col(const float* img, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream);
+ * first, model.py:39] -> cols bf16 [B*T*(H/4)*(W/4)][192]: columns k = c*32 + dt*16 + dy*4 + dx hold bf16(x) and columns 96+k
+ * hold bf16(x - bf16(x)), so the bf16 MFMA GEMM against [W | W] sees ~16 mantissa bits of every pixel ; frame T is the zero pad. */
+/* cov (optional, u8 (B,T,H/32,W/32)): covered 32x32 pixel blocks read as zeros == `img *= 1-cov` of
+ * Agent_Pretrain.masking (main_pretrain.py:362-364) without writing a masked copy of the clip. */
+int vmvm_patch_im2col(const float* img, const uint8_t* cov, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream);
 
 /* EncVideo token assembly (model.py:58-71): pre[b,t,0,:]=cls, pre[b,t,1+p,:]=fc_out[b,t,p,:]; + pos[p] + len[t].
  * out bf16 [B*T*(1+hw)][Hd] (the following LayerNorm is vmvm_layernorm_fwd). */
@@ -181,8 +187,9 @@ int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const 
 /* VTM head tail (main_pretrain.py:147,260): logit[m] = (dot(hid[m,:], w) + b) / temp ; hid bf16 [M][K] */
 int vmvm_rowdot(const void* hid, int32_t M, int32_t K, const float* w, const float* b, float inv_temp,
                 float* out, void* stream);
+/* dhid = dout*inv_temp*w, masked by (hid > 0) when relu_mask (hid is then the ReLU output feeding the dot) */
 int vmvm_rowdot_bwd(const void* hid, int32_t M, int32_t K, const float* w, const float* dout, float inv_temp,
-                    void* dhid, float* dw, float* db, void* stream);
+                    void* dhid, float* dw, float* db, int32_t relu_mask, void* stream);
 
 /* generic helpers */
 int vmvm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
@@ -191,6 +198,14 @@ int vmvm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int vmvm_gather_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, void* dst, int32_t ld_dst,
                           int32_t M, int32_t C, int32_t rows_out_per_batch, int32_t rows_in_per_batch, void* stream);
 int vmvm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* dst_f32[idx[m],:] += src[m,:] (atomics; idx < 0 skipped) -- gradient of a row gather with repeated sources */
+int vmvm_scatter_add_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst,
+                               int32_t M, int32_t C, void* stream);
+/* out = dy * GELU'(u)  (backward of the MLM head transform activation) */
+int vmvm_gelu_bwd_bf16(const void* dy, const void* u, void* out, int64_t n, void* stream);
+/* elementwise dropout y = keep(seed, offset+i) ? x/(1-p) : 0  (HF embedding dropout; main_pretrain.py:146 fc[0]).
+ * The same call with dy as x is the backward. */
+int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer (agent.py:84-113,181-193): fused global grad-norm + clip + AdamW over a flat f32 arena,

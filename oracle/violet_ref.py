@@ -140,27 +140,40 @@ def param_shapes(cfg):
     return s
 
 
-def closed_form(key, shape, dtype=torch.float32):
-    """Deterministic closed-form tensor: amp*sin(i*phi + k*1.7) (+1 for norm gains).
+def _hash_uniform(n, seed):
+    """n uniforms in [0,1): splitmix64 of (index, seed) in pure integer numpy -> bit-identical on every platform."""
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
-    Re-creatable bit-identically anywhere (float64 numpy sin, then cast); golden
-    fixtures therefore store outputs only (SURVEY 8c 'Golden-vector policy')."""
+
+def closed_form(key, shape, dtype=torch.float32):
+    """Deterministic closed-form tensor (integer hash -> uniform, scaled like the reference's own initialisation:
+    Linear / embeddings std .02, LayerNorm ~1 / ~0, conv fan-in uniform) so the network is as well conditioned as a
+    freshly initialised one.  Re-creatable bit-identically anywhere; golden fixtures therefore store outputs only
+    (SURVEY 8c 'Golden-vector policy')."""
     n = int(np.prod(shape))
-    k = zlib.crc32(key.encode()) % 997
-    i = np.arange(n, dtype=np.float64)
+    k = zlib.crc32(key.encode())
+    u = 2.0 * _hash_uniform(n, k) - 1.0                       # uniform(-1,1), std 1/sqrt(3)
+    r3 = math.sqrt(3.0)
     is_norm_w = key.endswith("weight") and ("norm" in key.lower()) and len(shape) == 1
     is_bias = key.endswith("bias") and len(shape) == 1
     if is_norm_w:
-        v = 1.0 + 0.05 * np.sin(i * 0.37 + k * 1.7)
+        v = 1.0 + 0.1 * u
     elif is_bias:
-        v = 0.02 * np.sin(i * 0.61 + k * 1.7)
+        v = 0.02 * u
     elif "emb_" in key or "embeddings" in key:
-        v = 0.05 * np.sin(i * 0.7310 + k * 1.7)
+        v = 0.02 * r3 * u
     elif "relative_position_bias_table" in key:
-        v = 0.2 * np.sin(i * 0.913 + k * 1.7)
-    else:
+        v = 0.2 * r3 * u
+    elif "patch_embed.proj.weight" in key or key.startswith("decoder_pixel") or key.startswith("fc."):
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else n
-        v = (1.2 / math.sqrt(fan_in)) * np.sin(i * 0.7853 + k * 1.7)
+        v = u / math.sqrt(fan_in)
+    else:
+        v = 0.02 * r3 * u
     return torch.from_numpy(v.reshape(shape)).to(dtype)
 
 
@@ -172,7 +185,9 @@ def make_batch(cfg, B, dtype=torch.float32):
     """Closed-form synthetic batch (collate schema main_pretrain_yaml.py:69-80)."""
     T, S, X = cfg["T"], cfg["img"], cfg["n_txt"]
     n = B * T * 3 * S * S
-    img = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(B, T, 3, S, S) * 1.5).to(dtype)
+    smooth = np.sin(np.arange(n, dtype=np.float64) * 0.0137) * 0.8
+    noise = (2.0 * _hash_uniform(n, 77) - 1.0) * 1.2
+    img = torch.from_numpy((smooth + noise).reshape(B, T, 3, S, S)).to(dtype)
     txt = torch.zeros(B, X, dtype=torch.long)
     for b in range(B):
         ln = 6 + (5 * b) % (X - 8)

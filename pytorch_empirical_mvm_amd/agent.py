@@ -1,0 +1,153 @@
+"""Training-agent surface of the reference (agent.py Agent_Base, main_pretrain.py:269-619 Agent_Pretrain) over the
+HIP engine: masking -> prepare_batch -> step (forward, losses, backward, all-reduce, clip, AdamW, LR schedule)."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import config as CFG
+from . import dist as D
+from . import kernels as K
+
+
+class Agent_Pretrain:
+    def __init__(self, args, model):
+        self.args, self.model = args, model
+        self.engine = model.engine
+        self.patch_size = model.patch_size
+        self.cls_token_id, self.sep_token_id = CFG.TOKENS["cls"], CFG.TOKENS["sep"]
+        self.pad_token_id, self.mask_token_id, self.unk_token_id = CFG.TOKENS["pad"], CFG.TOKENS["mask"], CFG.TOKENS["unk"]
+        self.global_step = 0
+        self.sched_step = 0                 # WarmupLinearLR.last_epoch: the ctor already performed step 0 (agent.py:13-32)
+        self.opt_step = 0
+        self.world_size, self.rank = 1, 0
+        self.comm = None
+        self.log = {d: {} for d in (args.dataset if isinstance(args.dataset, (list, tuple)) else [args.dataset])}
+        self._sumsq = torch.zeros(1, device=self.engine.device, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ distributed (agent.py:195-201, utils/dist.py:20-75)
+    def prepare_dist_model(self):
+        """Replaces DDP(find_unused_parameters=True) / DeepSpeed ZeRO-1: plain data parallel, one process per GPU,
+        gradient all-reduce (RCCL over xGMI) of the flat arena, non-Swin half overlapped with the Swin backward."""
+        if D.is_initialized():
+            self.world_size, self.rank = D.world_size(), D.rank()
+            self.comm = D.GradReducer(self.engine.store, self.engine.device)
+            D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
+            self.engine.store.refresh_shadow()
+
+    def reduce_mean(self, v):
+        """agent.py:118-125"""
+        if self.world_size < 2:
+            return v
+        t = torch.tensor([float(v)], device=self.engine.device)
+        D.all_reduce_(t)
+        return float(t.item()) / self.world_size
+
+    # ------------------------------------------------------------------ masking (main_pretrain.py:276-372)
+    @torch.no_grad()
+    def masking(self, img, txt, mask, vq=None, p_mask=0.15, materialize=False):
+        """Same distributions and RNG sources as the reference (`random.choice`, `torch.rand`, `np.random.randint`);
+        returns the reference's keys plus `cov` (B,T,h,w) u8, the patch cover the kernels consume.  `img` / `mvm_mask`
+        are only materialised on request -- the HIP path applies the cover while reading the clip."""
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        h, w = H // self.patch_size, W // self.patch_size
+        txt = txt.clone()
+        spc = (txt == self.cls_token_id) | (txt == self.sep_token_id) | (txt == self.pad_token_id) | (txt == self.mask_token_id)
+        ans_mtm = torch.full_like(txt, -1)
+        cov = torch.zeros(B, T, h, w, dtype=torch.uint8)
+        if p_mask > 0:
+            for i in range(B):
+                mask_type = random.choice(self.args.pretrain_masks)
+                if mask_type == "am":
+                    raise NotImplementedError("attention-guided masking ('am') is outside the accelerated path (SURVEY 8f.2)")
+                sel = (~spc[i].cpu()) & (torch.rand(X) < p_mask)
+                if mask_type == "bm":
+                    for _ in range(T):
+                        t = np.random.randint(1, T) if T > 1 else 1
+                        hh, ww = np.random.randint(1, h * 2 // 3), np.random.randint(1, w * 2 // 3)
+                        t1, h1, w1 = np.random.randint(0, T - t + 1), np.random.randint(0, h - hh + 1), np.random.randint(0, w - ww + 1)
+                        cov[i, t1:t1 + t, h1:h1 + hh, w1:w1 + ww] = 1
+                else:
+                    r = torch.rand((1 + h * w) * T) < p_mask
+                    cov[i] = r.view(T, 1 + h * w)[:, 1:].reshape(T, h, w).to(torch.uint8)
+                sel = sel.to(txt.device)
+                ans_mtm[i] = torch.where(sel, txt[i], ans_mtm[i])
+                txt[i] = torch.where(sel, torch.full_like(txt[i], self.mask_token_id), txt[i])
+        ans_mvm = torch.full((B, T * (1 + h * w)), -1, dtype=torch.long)
+        out = {"txt": txt, "mask": mask, "ans_mtm": ans_mtm, "ans_mvm": ans_mvm, "cov": cov, "unmask_img": img}
+        if materialize:
+            full = cov.to(img.dtype).to(img.device)[:, :, None, :, None, :, None].expand(-1, -1, 3, -1, 32, -1, 32).reshape(B, T, 3, H, W)
+            out["mvm_mask"] = full
+            out["img"] = img * (1.0 - full)
+        else:
+            out["img"] = img
+        return out
+
+    def prepare_batch(self, batch):
+        """agent.py:156-159 (move_to_cuda)"""
+        dev = self.engine.device
+        return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    # ------------------------------------------------------------------ one optimizer step (main_pretrain.py:555-573, agent.py:181-193)
+    def current_lrs(self):
+        f = CFG.lr_factor(self.sched_step, self.args.max_iter)
+        base = self.args.lr
+        mul = self.args.vis_backbone_lr_mul
+        lrs = [max(1e-8, base * mul * f), max(1e-8, base * f)]
+        return [lrs[0], lrs[1], lrs[0], lrs[1]]
+
+    def step(self, batch, is_train=True, negatives=None, dp_all=None, sync=True):
+        eng = self.engine
+        src_img = batch["unmask_img"] if "unmask_img" in batch else batch["img"]
+        b = dict(img=src_img.to(eng.device, torch.float32).contiguous(), cov=batch["cov"].to(eng.device).contiguous(),
+                 txt=batch["txt"].to(eng.device).contiguous(), mask=batch["mask"].to(eng.device).contiguous(),
+                 ans_mtm=batch["ans_mtm"].to(eng.device).contiguous())
+        if is_train:
+            hook = self.comm.reduce_other if self.comm is not None else None
+            losses, _ = eng.forward_backward(b, negatives=negatives, train=True, dp_all=dp_all, on_other_grads_ready=hook)
+            self.backward_step()
+            self.global_step += 1
+        else:
+            losses, outs = eng.forward_backward(b, negatives=negatives, train=False, want_outputs=True, backward=False)
+        if not sync:
+            return losses
+        return {"mtm": float(losses["mtm"].item()), "mvm": float(losses["mvm"].item()), "vtm": float(losses["vtm"].item()), "smtm": -1}
+
+    def backward_step(self):
+        """all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:186-193)"""
+        S = self.engine.store
+        if self.comm is not None:
+            self.comm.reduce_swin_and_wait()
+        self.opt_step += 1
+        gscale = 1.0 / self.world_size
+        self._sumsq.zero_()
+        if self.args.max_grad_norm > 0:
+            K.sumsq(S.grad[:S.n_trainable], self._sumsq)
+        lrs = self.current_lrs()
+        for gi in range(4):
+            a, e = S.segments[gi]
+            if e > a:
+                K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
+                        beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
+                        grad_scale=gscale)
+        self.sched_step += 1
+        S.grad.zero_()
+
+    def grad_norm(self):
+        return float(torch.sqrt(self._sumsq).item()) / self.world_size
+
+    # ------------------------------------------------------------------ checkpoint surface (main_pretrain.py:612-619, agent.py:127-132)
+    def save_training_meta(self):
+        if self.rank == 0:
+            os.makedirs(self.args.path_output, exist_ok=True)
+            json.dump(dict(self.args), open(f"{self.args.path_output}/args.json", "w"), indent=2)
+            self.save_model(0)
+
+    def save_model(self, ep, dataset="init", part=0):
+        if self.rank == 0:
+            os.makedirs(self.args.path_output, exist_ok=True)
+            sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+            torch.save(sd, os.path.join(self.args.path_output, f"ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt"))

@@ -1,0 +1,164 @@
+"""Architecture table and argument defaults of the reference surface.
+
+Arch values: visbackbone/swin_tiny.py:2-24, swin_base.py:3-6, swin_large.py:3-6, swin_*_patch244_*.py:4
+(only patch_size/embed_dim/depths/num_heads/window_size/patch_norm are read, video_swin.py:621-639).
+Argument names/defaults: utils/args.py:24-150 and _args/args_pretrain.json."""
+import json
+
+ARCH = {
+    "tiny": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(8, 7, 7)),
+    "small": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), window=(8, 7, 7)),
+    "base": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window=(8, 7, 7)),
+    "large": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=(8, 7, 7)),
+    "large384": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window=(8, 12, 12)),
+}
+PATCH = (2, 4, 4)
+DROP_PATH_RATE = 0.2                      # hard-coded for every size (video_swin.py:635)
+BERT = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512, types=2, eps=1e-12,
+            hidden_dropout=0.1, attn_dropout=0.1)
+TOKENS = dict(cls=101, sep=102, pad=0, mask=103, unk=100)      # bert-base-uncased
+
+DEFAULT_ARGS = dict(  # utils/args.py defaults overlaid by _args/args_pretrain.json
+    type="pretrain", task="pretrain", temp=0.05, pretrain_tasks=["vtm", "mlm", "mvm"], pretrain_masks=["rm", "bm"],
+    mvm_target=["pixel"], size_img=224, size_frame=4, size_txt=32, size_batch=20, size_epoch=10, lr=5e-5, decay=1e-3,
+    max_grad_norm=1.0, vis_backbone="vidswin", vis_backbone_size="base", vis_backbone_init="random", vis_backbone_lr_mul=1,
+    txt_backbone="bert-base-uncased", txt_backbone_embed_only=True, fusion_encoder="bert-base-uncased",
+    temporal_fusion="vidswin", size_patch=32, max_size_frame=6, max_size_patch=14, p_mask=0.15, seed=88,
+    path_ckpt="", path_output="_snapshot/pretrain", logging_steps=20, max_iter=1000, deepspeed=False, use_checkpoint=False,
+    dataset=["synthetic"],
+)
+
+
+class Args(dict):
+    """EasyDict-like (utils/args.py:246): attribute access over a dict, JSON round-trippable (agent.py:131)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def get_args(config_path=None, **overrides):
+    """utils/args.py:14-22,235-246 : defaults <- JSON config <- explicit overrides (CLI wins)."""
+    a = Args(DEFAULT_ARGS)
+    if config_path:
+        a.update(json.load(open(config_path)))
+    a.update(overrides)
+    if isinstance(a.mvm_target, str):
+        a.mvm_target = [a.mvm_target]
+    return a
+
+
+def model_cfg(args):
+    size = args.vis_backbone_size
+    if int(args.size_img) == 384 and size == "large":
+        size = "large384"                 # video_swin.py:574-580
+    if size not in ARCH:
+        raise ValueError(f"unknown vis_backbone_size {size}")
+    cfg = dict(ARCH[size])
+    for k in ("arch_override",):
+        if k in args and args[k]:
+            cfg.update(args[k])
+    cfg.update(size=size, hidden=BERT["hidden"], vocab=BERT["vocab"], bert_layers=args.get("bert_layers", BERT["layers"]),
+               max_size_frame=args.max_size_frame, max_size_patch=args.max_size_patch, size_patch=args.size_patch,
+               temp=args.temp, mvm_target=list(args.mvm_target))
+    return cfg
+
+
+def param_shapes(cfg):
+    """Ordered {state_dict key: shape} of VIOLET_Pretrain (SURVEY.md section 8b.2 key list)."""
+    E, depths, heads, win = cfg["embed_dim"], cfg["depths"], cfg["num_heads"], cfg["window"]
+    H, V = cfg["hidden"], cfg["vocab"]
+    s = {}
+    s["enc_txt.emb_txt.word_embeddings.weight"] = (V, H)
+    s["enc_txt.emb_txt.position_embeddings.weight"] = (BERT["max_pos"], H)
+    s["enc_txt.emb_txt.token_type_embeddings.weight"] = (BERT["types"], H)
+    s["enc_txt.emb_txt.LayerNorm.weight"] = (H,)
+    s["enc_txt.emb_txt.LayerNorm.bias"] = (H,)
+    for l in range(cfg["bert_layers"]):
+        p = f"trsfr.layer.{l}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (BERT["ffn"], H)
+        s[p + "intermediate.dense.bias"] = (BERT["ffn"],)
+        s[p + "output.dense.weight"] = (H, BERT["ffn"])
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    C_out = E * 8
+    s["enc_img.emb_cls"] = (1, 1, 1, H)
+    s["enc_img.emb_pos"] = (1, 1, 1 + cfg["max_size_patch"] ** 2, H)
+    s["enc_img.emb_len"] = (1, cfg["max_size_frame"], 1, H)
+    s["enc_img.emb_odr"] = (1, 1, 1, H)
+    if C_out != H:                                     # model.py:20-21
+        s["enc_img.fc.weight"] = (H, C_out)
+        s["enc_img.fc.bias"] = (H,)
+    s["enc_img.norm.weight"] = (H,)
+    s["enc_img.norm.bias"] = (H,)
+    sw = "enc_img.swin."
+    s[sw + "patch_embed.proj.weight"] = (E, 3) + PATCH
+    s[sw + "patch_embed.proj.bias"] = (E,)
+    s[sw + "patch_embed.norm.weight"] = (E,)
+    s[sw + "patch_embed.norm.bias"] = (E,)
+    ntab = (2 * win[0] - 1) * (2 * win[1] - 1) * (2 * win[2] - 1)
+    for i, (d, nh) in enumerate(zip(depths, heads)):
+        C = E * 2 ** i
+        for b in range(d):
+            p = sw + f"layers.{i}.blocks.{b}."
+            s[p + "norm1.weight"] = (C,)
+            s[p + "norm1.bias"] = (C,)
+            s[p + "attn.relative_position_bias_table"] = (ntab, nh)
+            s[p + "attn.qkv.weight"] = (3 * C, C)
+            s[p + "attn.qkv.bias"] = (3 * C,)
+            s[p + "attn.proj.weight"] = (C, C)
+            s[p + "attn.proj.bias"] = (C,)
+            s[p + "norm2.weight"] = (C,)
+            s[p + "norm2.bias"] = (C,)
+            s[p + "mlp.fc1.weight"] = (4 * C, C)
+            s[p + "mlp.fc1.bias"] = (4 * C,)
+            s[p + "mlp.fc2.weight"] = (C, 4 * C)
+            s[p + "mlp.fc2.bias"] = (C,)
+        if i < len(depths) - 1:
+            p = sw + f"layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,)
+            s[p + "norm.bias"] = (4 * C,)
+    s[sw + "norm.weight"] = (C_out,)
+    s[sw + "norm.bias"] = (C_out,)
+    s["fc.1.weight"] = (2 * H, H)
+    s["fc.1.bias"] = (2 * H,)
+    s["fc.3.weight"] = (1, 2 * H)
+    s["fc.3.bias"] = (1,)
+    s["fc_mtm.predictions.bias"] = (V,)
+    s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
+    s["fc_mtm.predictions.transform.dense.bias"] = (H,)
+    s["fc_mtm.predictions.transform.LayerNorm.weight"] = (H,)
+    s["fc_mtm.predictions.transform.LayerNorm.bias"] = (H,)
+    s["fc_mtm.predictions.decoder.weight"] = (V, H)
+    if "pixel" in cfg["mvm_target"]:
+        s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
+        s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    return s
+
+
+def param_group(name):
+    """agent.py:86-106 : 0 decay+swin, 1 decay+other, 2 no-decay+swin, 3 no-decay+other (substring rules)."""
+    nd = any(k in name for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
+    return (2 if nd else 0) + (0 if "swin." in name else 1)
+
+
+def lr_factor(step, max_iter, warmup_ratio=0.1):
+    """WarmupLinearLR.get_lr_factor (agent.py:22-28); step = scheduler.last_epoch."""
+    warm = int(warmup_ratio * max_iter)
+    if step < warm:
+        return max(0.0, step / warm)
+    step = min(step, max_iter)
+    return max(0.0, (max_iter - step) / (max_iter - warm))

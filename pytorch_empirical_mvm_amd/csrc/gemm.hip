@@ -173,14 +173,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
       const int n = n0 + wn * 64 + j * 16 + g * 4;
       if (n >= N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (n < p.col_scale_n) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.col_scale;
-      }
       if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         const float bs = p.scale_bias_only ? rs : 1.0f;   // DropPath producer form: A rows already carry the scale
         v[0] += b.x * bs; v[1] += b.y * bs; v[2] += b.z * bs; v[3] += b.w * bs;
+      }
+      if (n < p.col_scale_n) {                            // q = (x Wq^T + bq) * scale  (video_swin.py:152)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.col_scale;
       }
       if (p.act == 1) {
         if (p.C2) {
@@ -250,10 +250,11 @@ int launch(const vmvm_gemm_desc& d, hipStream_t st) {
 extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
-  if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7)) return VMVM_EINVAL;
-  if (d->a_kmajor ? (d->K & 7) : (d->M & 7)) return VMVM_EINVAL;
-  if (d->b_kmajor ? (d->K & 7) : (d->N & 7)) return VMVM_EINVAL;
-  if (d->out_fp32 ? (d->ldc & 3) : (d->ldc & 3)) return VMVM_EINVAL;
+  if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
+  // 16-byte chunks may straddle the logical extent as long as the row stride covers the round-up
+  const int K8 = (d->K + 7) & ~7, M8 = (d->M + 7) & ~7, N8 = (d->N + 7) & ~7;
+  if (d->a_kmajor ? (d->lda < K8) : (d->lda < M8)) return VMVM_EINVAL;
+  if (d->b_kmajor ? (d->ldb < K8) : (d->ldb < N8)) return VMVM_EINVAL;
   if (d->accumulate && !d->out_fp32) return VMVM_EINVAL;
   if ((d->act == 3 || d->act == 4) && !d->aux) return VMVM_EINVAL;
   if (d->row_map && d->map_len <= 0) return VMVM_EINVAL;

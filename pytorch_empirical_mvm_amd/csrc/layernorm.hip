@@ -11,13 +11,24 @@
 
 namespace {
 
-template <int NCH>
+// 8 consecutive input elements of a row: bf16 (one 16-byte load) or f32 (two)
+template <bool XF32>
+__device__ __forceinline__ void load_x8(const void* X, size_t elem_off, float* f) {
+  if (XF32) {
+    const float* p = reinterpret_cast<const float*>(X) + elem_off;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(X) + elem_off), f);
+  }
+}
+
+template <int NCH, bool XF32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long m = (long)blockIdx.x * 4 + wave;
   if (m >= p.M) return;
   const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
-  const u16* X = reinterpret_cast<const u16*>(p.X);
   u16* Y = reinterpret_cast<u16*>(p.Y) + (size_t)m * p.ldy;
   long b = 0, ml = m;
   if (p.src) { b = m / p.rows_out_per_batch; ml = m - b * p.rows_out_per_batch; }
@@ -40,8 +51,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
       }
       if (srow >= 0) {
         any_valid = true;
-        const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)srow * p.ldx + within);
-        unpack_bf8(v, x[i]);
+        load_x8<XF32>(p.X, (size_t)srow * p.ldx + within, x[i]);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += x[i][e];
@@ -89,12 +99,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
   }
 }
 
-template <int NCH>
+template <int NCH, bool XF32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][C] partial dgamma/dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
-  const u16* X = reinterpret_cast<const u16*>(p.X);
   const u16* dY = reinterpret_cast<const u16*>(p.dY);
   u16* dX = reinterpret_cast<u16*>(p.dX);
   const u16* ADD = reinterpret_cast<const u16*>(p.dX_add);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
           srow[i] = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
         }
         float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
-        if (srow[i] >= 0) unpack_bf8(*reinterpret_cast<const uint4*>(X + (size_t)srow[i] * p.ldx + within[i]), xv);
+        if (srow[i] >= 0) load_x8<XF32>(p.X, (size_t)srow[i] * p.ldx + within[i], xv);
         unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col), dyv);
         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -204,14 +213,18 @@ extern "C" int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream) {
   if (!d || !d->X || !d->Y || !d->gamma || !d->beta || !d->mean || !d->rstd) return VMVM_EINVAL;
   if (d->M <= 0 || d->C <= 0 || (d->C & 7) || d->nseg < 1 || (d->C % d->nseg) || ((d->C / d->nseg) & 7)) return VMVM_EINVAL;
   if ((d->ldx & 7) || (d->ldy & 7)) return VMVM_EINVAL;
+  if (d->x_fp32 && d->src) return VMVM_ENOSUPPORT;
   if (d->src && (d->rows_out_per_batch <= 0 || d->rows_in_per_batch <= 0)) return VMVM_EINVAL;
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = (d->M + 3) / 4;
-  if (d->C <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, *d);
-  else if (d->C <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, *d);
-  else if (d->C <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, *d);
-  else hipLaunchKernelGGL(ln_fwd_kernel<6>, dim3(grid), dim3(256), 0, st, *d);
+  if (d->x_fp32) {
+    if (d->C > 512) return VMVM_ENOSUPPORT;
+    hipLaunchKernelGGL((ln_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, st, *d);
+  } else if (d->C <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, st, *d);
+  else if (d->C <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<2, false>), dim3(grid), dim3(256), 0, st, *d);
+  else if (d->C <= 2048) hipLaunchKernelGGL((ln_fwd_kernel<4, false>), dim3(grid), dim3(256), 0, st, *d);
+  else hipLaunchKernelGGL((ln_fwd_kernel<6, false>), dim3(grid), dim3(256), 0, st, *d);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -227,10 +240,13 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   int grid = (d->M + 3) / 4;
   if (grid > 2048) grid = 2048;
   const size_t sm = (size_t)2 * d->C * sizeof(float);
-  if (d->C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), sm, st, *d);
-  else if (d->C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), sm, st, *d);
-  else if (d->C <= 2048) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), sm, st, *d);
-  else hipLaunchKernelGGL(ln_bwd_kernel<6>, dim3(grid), dim3(256), sm, st, *d);
+  if (d->x_fp32) {
+    if (d->C > 512) return VMVM_ENOSUPPORT;
+    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), sm, st, *d);
+  } else if (d->C <= 512) hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), sm, st, *d);
+  else if (d->C <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), sm, st, *d);
+  else if (d->C <= 2048) hipLaunchKernelGGL((ln_bwd_kernel<4, false>), dim3(grid), dim3(256), sm, st, *d);
+  else hipLaunchKernelGGL((ln_bwd_kernel<6, false>), dim3(grid), dim3(256), sm, st, *d);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

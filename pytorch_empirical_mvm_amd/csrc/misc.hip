@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 }
 
 // ---------------------------------------------------------------- PatchEmbed3D im2col
-__global__ void im2col_kernel(const float* __restrict__ img, u16* __restrict__ cols, int B, int T, int H, int W) {
+__global__ void im2col_kernel(const float* __restrict__ img, const uint8_t* __restrict__ cov, u16* __restrict__ cols, int B, int T, int H, int W) {
   const int Hp = H / 4, Wp = W / 4;
   const long ntok = (long)B * T * Hp * Wp;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,14 +40,19 @@ __global__ void im2col_kernel(const float* __restrict__ img, u16* __restrict__ c
   const int y = (int)((tok / Wp) % Hp);
   const int t = (int)((tok / ((long)Wp * Hp)) % T);
   const int b = (int)(tok / ((long)Wp * Hp * T));
-  u16* dst = cols + tok * 96 + c * 32 + dt * 16;
-  const bool valid = (t + dt) < T;                      // frame T is the appended zero frame (video_swin.py:398)
+  u16* dst = cols + tok * 192 + c * 32 + dt * 16;
+  bool valid = (t + dt) < T;                            // frame T is the appended zero frame (video_swin.py:398)
+  if (valid && cov) valid = cov[(((long)b * T + (t + dt)) * (H / 32) + (y >> 3)) * (W / 32) + (x >> 3)] == 0;
   const float* src = img + ((((long)b * T + (t + dt)) * 3 + c) * H + 4 * y) * W + 4 * x;
 #pragma unroll
   for (int dy = 0; dy < 4; ++dy) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) v = *reinterpret_cast<const float4*>(src + (long)dy * W);
-    *reinterpret_cast<uint2*>(dst + dy * 4) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    const uint2 hi = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    *reinterpret_cast<uint2*>(dst + dy * 4) = hi;
+    const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xffff0000u);
+    const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xffff0000u);
+    *reinterpret_cast<uint2*>(dst + 96 + dy * 4) = make_uint2(pack_bf2(rx, ry), pack_bf2(rz, rw));
   }
 }
 
@@ -220,16 +225,17 @@ __global__ void rowdot_kernel(const u16* __restrict__ hid, int M, int K, const f
   if (lane == 0) out[wave] = (s + b[0]) * inv_temp;
 }
 __global__ void rowdot_bwd_kernel(const u16* __restrict__ hid, int M, int K, const float* __restrict__ w, const float* __restrict__ dout,
-                                  float inv_temp, u16* __restrict__ dhid, float* __restrict__ dw, float* __restrict__ db) {
+                                  float inv_temp, u16* __restrict__ dhid, float* __restrict__ dw, float* __restrict__ db, int relu_mask) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   float s = 0.f, sb = 0.f;
   const float wk = w[k];
   for (int m = 0; m < M; ++m) {
     const float g = dout[m] * inv_temp;
-    s += g * bf2f(hid[(long)m * K + k]);
+    const float hv = bf2f(hid[(long)m * K + k]);
+    s += g * hv;
     sb += g;
-    dhid[(long)m * K + k] = f2bf(g * wk);
+    dhid[(long)m * K + k] = f2bf((relu_mask && !(hv > 0.f)) ? 0.f : g * wk);
   }
   dw[k] += s;
   if (k == 0) db[0] += sb;
@@ -277,6 +283,35 @@ __global__ void gather_rows_kernel(const u16* __restrict__ src, int ld_src, cons
   uint4 v = make_uint4(0, 0, 0, 0);
   if (s >= 0) v = *reinterpret_cast<const uint4*>(src + s * ld_src + ch * 8);
   *reinterpret_cast<uint4*>(dst + m * ld_dst + ch * 8) = v;
+}
+
+__global__ void scatter_add_rows_kernel(const u16* __restrict__ src, int ld_src, const int32_t* __restrict__ idx, float* __restrict__ dst,
+                                        int ld_dst, long M, int C) {
+  const int nch = C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * nch) return;
+  const int ch = (int)(i % nch);
+  const long m = i / nch;
+  const int d = idx[m];
+  if (d < 0) return;
+  float v[8];
+  unpack_bf8(*reinterpret_cast<const uint4*>(src + m * ld_src + ch * 8), v);
+  float* o = dst + (long)d * ld_dst + ch * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(o + e, v[e]);
+}
+__global__ void gelu_bwd_kernel(const u16* __restrict__ dy, const u16* __restrict__ u, u16* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = f2bf(bf2f(dy[i]) * gelu_grad_f(bf2f(u[i])));
+}
+__global__ void dropout_kernel(const u16* __restrict__ x, u16* __restrict__ y, long n, float p, uint64_t seed, uint64_t offset) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  const uint32_t thr = dropout_threshold(p);
+  const float ks = 1.f / (1.f - p);
+  const uint4 b0 = dropout_bits(seed, offset, (uint64_t)(i >> 2)), b1 = dropout_bits(seed, offset, (uint64_t)(i >> 2) + 1);
+  const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  for (int e = 0; e < 8 && i + e < n; ++e) y[i + e] = bits[e] < thr ? (u16)0 : f2bf(bf2f(x[i + e]) * ks);
 }
 
 // column sums: block = 8 column-chunks (64 cols) x 32 row lanes ; grid.y splits the rows
@@ -383,10 +418,11 @@ inline int nblk(long n, int per) { return (int)((n + per - 1) / per); }
 
 #define ST reinterpret_cast<hipStream_t>(stream)
 
-extern "C" int vmvm_patch_im2col(const float* img, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream) {
+extern "C" int vmvm_patch_im2col(const float* img, const uint8_t* cov, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream) {
   if (!img || !cols || B <= 0 || T <= 0 || (H & 3) || (W & 3)) return VMVM_EINVAL;
+  if (cov && ((H & 31) || (W & 31))) return VMVM_EINVAL;
   const long n = (long)B * T * (H / 4) * (W / 4) * 6;
-  hipLaunchKernelGGL(im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, img, reinterpret_cast<u16*>(cols), B, T, H, W);
+  hipLaunchKernelGGL(im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, img, cov, reinterpret_cast<u16*>(cols), B, T, H, W);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -452,10 +488,10 @@ extern "C" int vmvm_rowdot(const void* hid, int32_t M, int32_t K, const float* w
   return VMVM_OK;
 }
 extern "C" int vmvm_rowdot_bwd(const void* hid, int32_t M, int32_t K, const float* w, const float* dout, float inv_temp, void* dhid,
-                               float* dw, float* db, void* stream) {
+                               float* dw, float* db, int32_t relu_mask, void* stream) {
   if (!hid || !w || !dout || !dhid || !dw || !db) return VMVM_EINVAL;
   hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk(K, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(hid), M, K, w, dout, inv_temp,
-                     reinterpret_cast<u16*>(dhid), dw, db);
+                     reinterpret_cast<u16*>(dhid), dw, db, relu_mask);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -477,6 +513,28 @@ extern "C" int vmvm_gather_rows_bf16(const void* src, int32_t ld_src, const int3
   if (!src || !idx || !dst || M <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7)) return VMVM_EINVAL;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((long)M * (C / 8), 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), ld_src, idx,
                      reinterpret_cast<u16*>(dst), ld_dst, (long)M, C, rows_out_per_batch, rows_in_per_batch);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_scatter_add_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t M, int32_t C,
+                                          void* stream) {
+  if (!src || !idx || !dst || M <= 0 || (C & 7) || (ld_src & 7)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblk((long)M * (C / 8), 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), ld_src, idx,
+                     dst, ld_dst, (long)M, C);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_gelu_bwd_bf16(const void* dy, const void* u, void* out, int64_t n, void* stream) {
+  if (!dy || !u || !out || n <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(dy), reinterpret_cast<const u16*>(u),
+                     reinterpret_cast<u16*>(out), (long)n);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+  if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return VMVM_EINVAL;
+  hipLaunchKernelGGL(dropout_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(x), reinterpret_cast<u16*>(y),
+                     (long)n, p, seed, offset);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -1,0 +1,105 @@
+"""Data-parallel plumbing (replaces utils/dist.py:20-75 + DDP/DeepSpeed, agent.py:195-201).
+
+One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm) or "gloo" (CPU tests).
+The only exchange of the step is the gradient sum: the flat f32 gradient arena is reduced in two phases --
+the non-Swin optimizer groups (fusion encoder, heads, embeddings: complete as soon as the fusion backward ends)
+on a side stream while the Video-Swin backward still runs, then the Swin groups.  xGMI is point-to-point, so
+a few LARGE messages (chunks of <= 256 MiB) are used instead of many small DDP-style buckets."""
+import os
+
+import torch
+import torch.distributed as dist
+
+CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 per collective
+
+
+def init_from_env(backend=None):
+    """utils/dist.py:20-75 : env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world < 2:
+        return 0, 1, 0
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method="env://")
+    return rank, world, local
+
+
+def is_initialized():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if is_initialized() else 0
+
+
+def barrier():
+    if is_initialized():
+        dist.barrier()
+
+
+def all_reduce_(t):
+    if is_initialized():
+        dist.all_reduce(t)
+    return t
+
+
+def broadcast_(t, src=0):
+    if is_initialized():
+        for a in range(0, t.numel(), CHUNK_ELEMS):
+            dist.broadcast(t[a:a + CHUNK_ELEMS], src)
+    return t
+
+
+def all_reduce_chunks_(flat, a, e):
+    """sum-all-reduce flat[a:e] in CHUNK_ELEMS pieces; returns the number of collectives issued."""
+    n = 0
+    for s in range(a, e, CHUNK_ELEMS):
+        dist.all_reduce(flat[s:min(e, s + CHUNK_ELEMS)])
+        n += 1
+    return n
+
+
+class GradReducer:
+    """Two-phase gradient all-reduce over the ParamStore arena (segments: 0 swin-decay, 1 other-decay, 2 swin-nodecay,
+    3 other-nodecay).  Sums only -- the 1/world average is folded into the AdamW kernel's grad_scale."""
+
+    def __init__(self, store, device):
+        self.store = store
+        self.cuda = torch.device(device).type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.pending = False
+
+    def _run(self, segs):
+        g = self.store.grad
+        for gi in segs:
+            a, e = self.store.segments[gi]
+            if e > a:
+                all_reduce_chunks_(g, a, e)
+
+    def reduce_other(self):
+        """called by the engine right after the last non-Swin gradient has been written"""
+        if not is_initialized():
+            return
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._run((1, 3))
+            self.pending = True
+        else:
+            self._run((1, 3))
+
+    def reduce_swin_and_wait(self):
+        if not is_initialized():
+            return
+        self._run((0, 2))
+        if self.cuda and self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False

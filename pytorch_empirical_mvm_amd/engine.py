@@ -1,0 +1,531 @@
+"""The VIOLETv2 pretraining step as a static schedule of libvmvm kernel launches (forward, losses, backward).
+
+No autograd graph: every block has an explicit forward that pushes its backward closure on a tape; weight
+gradients are accumulated by the wgrad GEMM epilogue straight into one flat f32 gradient arena (which the
+data-parallel all-reduce and the fused AdamW walk as a whole), activations are bf16, statistics f32.
+torch supplies device memory, the current stream and index uploads only.
+
+Reference call stack reproduced: VIOLET_Pretrain.forward (main_pretrain.py:226-267) ->
+EncVideo.forward (model.py:32-78) -> SwinTransformer3D.forward (video_swin.py:470-482) ; EncTxt (model.py:106-115) ;
+go_cross x2 (model.py:204-214) ; heads + losses (main_pretrain.py:374-432, 555-567)."""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import config as CFG
+from . import kernels as K
+from . import swin_index as SI
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter arena
+# ----------------------------------------------------------------------------------------------------
+class ParamStore:
+    """All parameters in ONE flat f32 buffer (+ grad, Adam m/v, bf16 compute copy), laid out by optimizer
+    group (agent.py:84-113) so clip / AdamW / all-reduce are a handful of launches over contiguous memory."""
+    FROZEN = ("enc_img.emb_odr",)          # never receives a gradient in pretraining
+    PAD = 8
+    TAIL = 1 << 16
+
+    def __init__(self, shapes, device):
+        self.device = device
+        order = sorted(shapes.keys(), key=lambda n: (4 if n in self.FROZEN else CFG.param_group(n)))   # stable
+        self.index = OrderedDict()
+        off = 0
+        bounds = [0]
+        cur_g = 0
+        for n in order:
+            g = 4 if n in self.FROZEN else CFG.param_group(n)
+            while cur_g < g:
+                bounds.append(off)
+                cur_g += 1
+            cnt = int(np.prod(shapes[n]))
+            self.index[n] = (off, cnt, tuple(shapes[n]))
+            off += -(-cnt // self.PAD) * self.PAD
+        while cur_g < 5:
+            bounds.append(off)
+            cur_g += 1
+        self.total = off
+        self.segments = [(bounds[i], bounds[i + 1]) for i in range(5)]       # 4 optimizer groups + frozen
+        self.n_trainable = bounds[4]
+        self.flat = torch.zeros(off + self.TAIL, device=device, dtype=F32)
+        self.grad = torch.zeros(off + self.TAIL, device=device, dtype=F32)
+        self.m = torch.zeros(off, device=device, dtype=F32)
+        self.v = torch.zeros(off, device=device, dtype=F32)
+        self.shadow = torch.zeros(off + self.TAIL, device=device, dtype=BF16)
+
+    def _view(self, buf, n, shape=None):
+        o, c, s = self.index[n]
+        return buf[o:o + c].view(shape or s)
+
+    def p(self, n, shape=None):
+        return self._view(self.flat, n, shape)
+
+    def g(self, n, shape=None):
+        return self._view(self.grad, n, shape)
+
+    def b(self, n, shape=None):
+        return self._view(self.shadow, n, shape)
+
+    def fused(self, buf, names, shape):
+        """view over ADJACENT parameters (e.g. BERT query/key/value -> one [3H,H] GEMM operand)."""
+        o0 = self.index[names[0]][0]
+        o = o0
+        for n in names:
+            assert self.index[n][0] == o, f"{n} is not adjacent in the arena"
+            o += self.index[n][1]
+        return buf[o0:o].view(shape)
+
+    def refresh_shadow(self):
+        K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
+
+    def load_state(self, sd):
+        for n, (o, c, s) in self.index.items():
+            if n in sd:
+                self.flat[o:o + c].copy_(sd[n].reshape(-1).to(self.device, F32))
+        self.refresh_shadow()
+
+    def state_dict(self):
+        return OrderedDict((n, self.p(n).detach().clone()) for n in self.index)
+
+
+class V:
+    """activation + its gradient slot"""
+    __slots__ = ("t", "g")
+
+    def __init__(self, t):
+        self.t, self.g = t, None
+
+
+def _acc(v, g):
+    v.g = g if v.g is None else K.add_bf16(v.g, g)
+
+
+def _dev_i32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
+
+
+# ----------------------------------------------------------------------------------------------------
+# engine
+# ----------------------------------------------------------------------------------------------------
+class VioletEngine:
+    def __init__(self, cfg, device="cuda", seed=88):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.store = ParamStore(CFG.param_shapes(cfg), self.device)
+        self.seed = int(seed)
+        self.rng_offset = 0
+        self._idx_cache = {}
+        self.tape = []
+        self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
+
+    # -------------------------------------------------------------- small helpers
+    def _next_offset(self, n):
+        o = self.rng_offset
+        self.rng_offset += int(n) + 64
+        return o
+
+    def _cached(self, key, fn):
+        if key not in self._idx_cache:
+            self._idx_cache[key] = fn()
+        return self._idx_cache[key]
+
+    def _linear_bwd(self, dy, x, wname, bname, *, w=None, gw=None, gb=None, M=None, row_scale=None, rows_per_scale=0,
+                    need_dx=True, dx_kw=None, wN=None):
+        """dW += dy^T x ; db += colsum(dy) ; dx = dy W   (all on the MFMA GEMM, no transposed copies)."""
+        S = self.store
+        w = S.b(wname) if w is None else w
+        gw = S.g(wname) if gw is None else gw
+        w2 = w.view(w.shape[0], -1)
+        gw2 = gw.view(gw.shape[0], -1)
+        N = wN or w2.shape[0]
+        if bname is not None or gb is not None:
+            K.colsum(dy, S.g(bname) if gb is None else gb, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
+        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True)
+        if not need_dx:
+            return None
+        return K.gemm(dy, w2, b_kmajor=False, M=M or dy.shape[0], N=w2.shape[1], K=N, **(dx_kw or {}))
+
+    # -------------------------------------------------------------- Video-Swin
+    def _patch_embed(self, img, cov):
+        """PatchEmbed3D (video_swin.py:390-407) as im2col + MFMA GEMM + LayerNorm.  The layer is 0.1% of the FLOPs but sets
+        the precision of everything downstream, so the pixels enter as a bf16 hi/lo pair (K = 2x96) and the conv output
+        stays f32 into the LayerNorm (the reference runs this conv in fp16 = 3 more mantissa bits than bf16)."""
+        S, pre = self.store, "enc_img.swin.patch_embed."
+        cols = K.patch_im2col(img, cov)                                   # [M,192] = [hi | lo]
+        E = self.cfg["embed_dim"]
+        wb = S.b(pre + "proj.weight", (E, 96))
+        w2 = torch.cat([wb, wb], dim=1).contiguous()                     # [E,192] (tiny; plumbing)
+        z = K.gemm(cols, w2, bias=S.p(pre + "proj.bias"), out_dtype=F32)
+        x, mean, rstd = K.layernorm_fwd(z, S.p(pre + "norm.weight"), S.p(pre + "norm.bias"), 1e-5)
+        out = V(x)
+
+        def bwd():
+            dz, _ = K.layernorm_bwd(out.g, z, S.p(pre + "norm.weight"), mean, rstd, S.g(pre + "norm.weight"), S.g(pre + "norm.bias"))
+            K.colsum(dz, S.g(pre + "proj.bias"), accumulate=True)
+            K.gemm(dz, cols, a_kmajor=False, b_kmajor=False, M=E, N=96, K=dz.shape[0], out=S.g(pre + "proj.weight", (E, 96)), accumulate=True)
+        self.tape.append(bwd)
+        return out
+
+    def _swin_block(self, xv, B, dims, C, nh, pre, shifted, dp):
+        S, cfg = self.store, self.cfg
+        D, H, W = dims
+        L = D * H * W
+        win = tuple(cfg["window"])
+        ws, ss = SI.get_window_size(dims, win, tuple(i // 2 for i in win) if shifted else (0, 0, 0))
+        wm, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+        N = ws[0] * ws[1] * ws[2]
+        Lp = wm.size
+        nW = Lp // N
+        dev = self.device
+        src = self._cached(("wm", dims, ws, ss), lambda: _dev_i32(wm, dev))
+        reg_np = SI.region_ids(Dp, Hp, Wp, ws, ss)
+        reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss), lambda: torch.from_numpy(reg_np).to(dev))
+        rc_np, rc0 = SI.rc_codes(N, win)
+        rc = self._cached(("rc", N, win), lambda: _dev_i32(rc_np, dev))
+        scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
+        x = xv.t
+        g1, b1 = S.p(pre + "norm1.weight"), S.p(pre + "norm1.bias")
+        xw, mean1, rstd1 = K.layernorm_fwd(x, g1, b1, 1e-5, M=B * Lp, C_=C, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0)
+        qkv = K.gemm(xw, S.b(pre + "attn.qkv.weight"), bias=S.p(pre + "attn.qkv.bias"), col_scale=scale, col_scale_n=C)
+        table = S.p(pre + "attn.relative_position_bias_table")
+        akw = dict(q_off=0, k_off=C, v_off=2 * C, bias_table=table, rc=rc, rc0=rc0, region=reg, n_win=nW, seq_scale=dp, seqs_per_scale=nW)
+        ao, lse = K.attention_fwd(qkv, B * nW, N, nh, C // nh, 0, scale, **akw)
+        x1 = K.gemm(ao, S.b(pre + "attn.proj.weight"), bias=S.p(pre + "attn.proj.bias"), row_scale=dp, rows_per_scale=Lp,
+                    scale_bias_only=True, resid=x, row_map=src, map_len=Lp, map_stride=L, out_rows=B * L)
+        g2, b2 = S.p(pre + "norm2.weight"), S.p(pre + "norm2.bias")
+        y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5)
+        u = torch.empty((B * L, 4 * C), device=dev, dtype=BF16)
+        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp, rows_per_scale=L)
+        x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dp, rows_per_scale=L,
+                    scale_bias_only=True, resid=x1)
+        out = V(x2)
+
+        def bwd():
+            dx2 = out.g
+            du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dp, rows_per_scale=L,
+                                  dx_kw=dict(act=3, aux=u, row_scale=dp, rows_per_scale=L))
+            dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
+            dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
+            dx1w = K.gather_rows(dx1, src, B * Lp, Lp, L)
+            dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dp, rows_per_scale=Lp)
+            dqkv = K.attention_bwd(dao, qkv, ao, lse, B * nW, N, nh, C // nh, 0, scale,
+                                   dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
+            dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
+            dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
+                                    src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0, dX_add=dx1)
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out
+
+    def _patch_merge(self, xv, B, dims, C, pre):
+        S = self.store
+        D, H, W = dims
+        mm, (D2, H2, W2) = SI.merge_map(D, H, W)
+        src = self._cached(("mm", dims), lambda: _dev_i32(mm, self.device))
+        L, Lo = D * H * W, D2 * H2 * W2
+        x = xv.t
+        gam, bet = S.p(pre + "norm.weight"), S.p(pre + "norm.bias")
+        y, mean, rstd = K.layernorm_fwd(x, gam, bet, 1e-5, M=B * Lo, C_=4 * C, nseg=4, src=src, rows_out_per_batch=Lo, rows_in_per_batch=L, pad_mode=1)
+        o = K.gemm(y, S.b(pre + "reduction.weight"))
+        out = V(o)
+
+        def bwd():
+            dy = self._linear_bwd(out.g, y, pre + "reduction.weight", None)
+            dx, _ = K.layernorm_bwd(dy, x, gam, mean, rstd, S.g(pre + "norm.weight"), S.g(pre + "norm.bias"), rows_in=B * L, nseg=4, src=src,
+                                    rows_out_per_batch=Lo, rows_in_per_batch=L, pad_mode=1)
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out, (D2, H2, W2)
+
+    def swin_forward(self, img, cov, dp_all):
+        """img f32 (B,T,3,H,W) -> V([B*T*h*w, 8E]) channels-last tokens (after the final norm)."""
+        cfg, S = self.cfg, self.store
+        B, T, _, H, W = img.shape
+        xv = self._patch_embed(img, cov)
+        dims = (T, H // 4, W // 4)
+        C = cfg["embed_dim"]
+        blk = 0
+        for i, (d, nh) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+            for b in range(d):
+                dp = None if dp_all is None else dp_all[blk]
+                xv = self._swin_block(xv, B, dims, C, nh, f"enc_img.swin.layers.{i}.blocks.{b}.", b % 2 == 1, dp)
+                blk += 1
+            if i < len(cfg["depths"]) - 1:
+                xv, dims = self._patch_merge(xv, B, dims, C, f"enc_img.swin.layers.{i}.downsample.")
+                C *= 2
+        x = xv.t
+        gam, bet = S.p("enc_img.swin.norm.weight"), S.p("enc_img.swin.norm.bias")
+        y, mean, rstd = K.layernorm_fwd(x, gam, bet, 1e-5)
+        out = V(y)
+        inp = xv
+
+        def bwd():
+            dx, _ = K.layernorm_bwd(out.g, x, gam, mean, rstd, S.g("enc_img.swin.norm.weight"), S.g("enc_img.swin.norm.bias"))
+            _acc(inp, dx)
+        self.tape.append(bwd)
+        return out, dims, C
+
+    # -------------------------------------------------------------- EncVideo / EncTxt  -> one token pool
+    def encode(self, img, cov, txt, dp_all, train):
+        """returns pool V([B*Lv + B*X, 768]) : rows [0, B*Lv) = feat_img (model.py:71), rest = feat_txt (model.py:107)."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        Hd = cfg["hidden"]
+        sw, dims, C8 = self.swin_forward(img, cov, dp_all)
+        hw = dims[1] * dims[2]
+        assert dims[1] == H // 32 and dims[2] == W // 32                       # model.py:34 hard-codes //32
+        Lv = T * (1 + hw)
+        has_fc = "enc_img.fc.weight" in S.index
+        f = K.gemm(sw.t, S.b("enc_img.fc.weight"), bias=S.p("enc_img.fc.bias")) if has_fc else sw.t
+        pos = S.p("enc_img.emb_pos", (1 + cfg["max_size_patch"] ** 2, Hd))
+        ln_ = S.p("enc_img.emb_len", (cfg["max_size_frame"], Hd))
+        if T > cfg["max_size_frame"]:
+            raise RuntimeError(f"max_size_frame ({cfg['max_size_frame']}) must be >= T ({T})  (model.py:69)")
+        pre = K.encvideo_assemble(f, S.p("enc_img.emb_cls", (Hd,)), pos, ln_, B, T, hw, Hd)
+        pool = torch.empty((B * Lv + B * X, Hd), device=dev, dtype=BF16)
+        gi, bi = S.p("enc_img.norm.weight"), S.p("enc_img.norm.bias")
+        fi, mean_i, rstd_i = K.layernorm_fwd(pre, gi, bi, 1e-5)
+        pool[:B * Lv].copy_(fi)
+        # text: HF BertEmbeddings (word + position + token_type(0)) -> LayerNorm(1e-12) -> dropout(0.1)
+        pt = "enc_txt.emb_txt."
+        e = K.bert_embed(txt, S.p(pt + "word_embeddings.weight"), S.p(pt + "position_embeddings.weight"),
+                         S.p(pt + "token_type_embeddings.weight")[0])
+        gt, bt = S.p(pt + "LayerNorm.weight"), S.p(pt + "LayerNorm.bias")
+        ft, mean_t, rstd_t = K.layernorm_fwd(e, gt, bt, CFG.BERT["eps"])
+        p_drop = CFG.BERT["hidden_dropout"] if train else 0.0
+        off_t = self._next_offset(ft.numel())
+        if p_drop > 0:
+            ft = K.dropout(ft, p_drop, self.seed, off_t)
+        pool[B * Lv:].copy_(ft)
+        out = V(pool)
+
+        def bwd():
+            dpool = out.g                                                       # bf16 [B*Lv + B*X, Hd]
+            dft = dpool[B * Lv:]
+            if p_drop > 0:
+                dft = K.dropout(dft, p_drop, self.seed, off_t)
+            de, _ = K.layernorm_bwd(dft, e, gt, mean_t, rstd_t, S.g(pt + "LayerNorm.weight"), S.g(pt + "LayerNorm.bias"))
+            K.bert_embed_bwd(txt, de, S.g(pt + "word_embeddings.weight"), S.g(pt + "position_embeddings.weight"),
+                             S.g(pt + "token_type_embeddings.weight")[0])
+            dpre, _ = K.layernorm_bwd(dpool[:B * Lv], pre, gi, mean_i, rstd_i, S.g("enc_img.norm.weight"), S.g("enc_img.norm.bias"))
+            df = K.encvideo_assemble_bwd(dpre, S.g("enc_img.emb_cls", (Hd,)), S.g("enc_img.emb_pos", (1 + cfg["max_size_patch"] ** 2, Hd)),
+                                         S.g("enc_img.emb_len", (cfg["max_size_frame"], Hd)), B, T, hw, Hd)
+            if has_fc:
+                df = self._linear_bwd(df, sw.t, "enc_img.fc.weight", "enc_img.fc.bias")
+            _acc(sw, df)
+        self.tape.append(bwd)
+        return out, Lv, hw
+
+    # -------------------------------------------------------------- fusion encoder
+    def _bert_layer(self, xv, nseq, Lq, keymask, l, train):
+        S, dev = self.store, self.device
+        pre = f"trsfr.layer.{l}."
+        Hd, nh = self.cfg["hidden"], CFG.BERT["heads"]
+        qn = [pre + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+        bn = [pre + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+        Wqkv, Gqkv = S.fused(S.shadow, qn, (3 * Hd, Hd)), S.fused(S.grad, qn, (3 * Hd, Hd))
+        bqkv, gbqkv = S.fused(S.flat, bn, (3 * Hd,)), S.fused(S.grad, bn, (3 * Hd,))
+        p_h = CFG.BERT["hidden_dropout"] if train else 0.0
+        p_a = CFG.BERT["attn_dropout"] if train else 0.0
+        M = nseq * Lq
+        x = xv.t
+        qkv = K.gemm(x, Wqkv, bias=bqkv)
+        o_att = self._next_offset(nseq * nh * Lq * Lq)
+        akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att)
+        ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), **akw)
+        o1 = self._next_offset(M * Hd)
+        a = K.gemm(ctx, S.b(pre + "attention.output.dense.weight"), bias=S.p(pre + "attention.output.dense.bias"), resid=x,
+                   dropout_p=p_h, seed=self.seed, offset=o1)
+        g1, b1 = S.p(pre + "attention.output.LayerNorm.weight"), S.p(pre + "attention.output.LayerNorm.bias")
+        x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
+        u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=BF16)
+        h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u)
+        o2 = self._next_offset(M * Hd)
+        f = K.gemm(h, S.b(pre + "output.dense.weight"), bias=S.p(pre + "output.dense.bias"), resid=x1, dropout_p=p_h, seed=self.seed, offset=o2)
+        g2, b2 = S.p(pre + "output.LayerNorm.weight"), S.p(pre + "output.LayerNorm.bias")
+        x2, mean2, rstd2 = K.layernorm_fwd(f, g2, b2, CFG.BERT["eps"])
+        out = V(x2)
+
+        def bwd():
+            df, dfm = K.layernorm_bwd(out.g, f, g2, mean2, rstd2, S.g(pre + "output.LayerNorm.weight"), S.g(pre + "output.LayerNorm.bias"),
+                                      want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o2)
+            dfm = df if dfm is None else dfm
+            du = self._linear_bwd(dfm, h, pre + "output.dense.weight", pre + "output.dense.bias", dx_kw=dict(act=3, aux=u))
+            dx1 = self._linear_bwd(du, x1, pre + "intermediate.dense.weight", pre + "intermediate.dense.bias", dx_kw=dict(resid=df))
+            da, dam = K.layernorm_bwd(dx1, a, g1, mean1, rstd1, S.g(pre + "attention.output.LayerNorm.weight"),
+                                      S.g(pre + "attention.output.LayerNorm.bias"), want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o1)
+            dam = da if dam is None else dam
+            dctx = self._linear_bwd(dam, ctx, pre + "attention.output.dense.weight", pre + "attention.output.dense.bias")
+            dqkv = K.attention_bwd(dctx, qkv, ctx, lse, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), **akw)
+            dx = self._linear_bwd(dqkv, x, None, None, w=Wqkv, gw=Gqkv, gb=gbqkv, dx_kw=dict(resid=da))
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out
+
+    def go_cross(self, pool, idx, keymask, nseq, Lq, train):
+        """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214)."""
+        Hd = self.cfg["hidden"]
+        x = K.gather_rows(pool.t, idx, nseq * Lq)
+        xv = V(x)
+        cur = xv
+        for l in range(self.cfg["bert_layers"]):
+            cur = self._bert_layer(cur, nseq, Lq, keymask, l, train)
+        return cur, xv, idx
+
+    # -------------------------------------------------------------- full step
+    def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
+                         dropout=None, on_other_grads_ready=None):
+        """One pass of the hot path.  batch: img f32 (B,T,3,H,W) UN-masked, cov u8 (B,T,h,w), txt i64 (B,X) (masked ids),
+        mask i64 (B,X), ans_mtm i64 (B,X).  Returns dict of loss scalars (device f32 tensors) and optional outputs."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        img, cov, txt, mask, ans_mtm = batch["img"], batch["cov"], batch["txt"], batch["mask"], batch["ans_mtm"]
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        Hd = cfg["hidden"]
+        O = min(B, 4)
+        self.tape = []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(B)
+        train = train if dropout is None else bool(dropout)      # dropout sites follow `train` unless overridden
+        pool, Lv, hw = self.encode(img, cov, txt, dp_all, train)
+        Lq = Lv + X
+        # ---- sequence assembly indices (pass 1: (img_i, txt_i); pass 2: (img_i, txt_i), (img_i, txt_neg) ...)
+        if negatives is None:
+            negatives = self.sample_negatives(B)
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx1 = np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)])
+        pairs = []
+        for i in range(B):
+            pairs.append((i, i))
+            for k in range(O - 1):
+                pairs.append((i, int(negatives[i][k])))
+        idx2 = np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs])
+        idx1_d, idx2_d = _dev_i32(idx1, dev), _dev_i32(idx2, dev)
+        km_txt = (mask != 0).to(torch.uint8)
+        km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
+        tj = torch.tensor([j for _, j in pairs], device=dev)
+        km2 = torch.cat([torch.ones(B * O, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
+
+        out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
+        out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
+        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm")}
+        outs = {}
+
+        # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560)
+        pm = "fc_mtm.predictions."
+        Vv = cfg["vocab"]
+        Vpad = -(-Vv // 8) * 8
+        txt_rows = self._cached(("txt_rows", B, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(B)]), dev))
+        r_m = K.gather_rows(out1.t, txt_rows, B * X)
+        u_m = torch.empty((B * X, Hd), device=dev, dtype=BF16)
+        t_m = K.gemm(r_m, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_m)
+        gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
+        tn, mean_m, rstd_m = K.layernorm_fwd(t_m, gm, bm, CFG.BERT["eps"])
+        Wdec = S.b(pm + "decoder.weight")
+        Nlog = -(-Vv // 4) * 4
+        logits = torch.empty((B * X, Vpad), device=dev, dtype=F32)
+        K.gemm(tn, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=logits)
+        tgt_m = ans_mtm.reshape(-1).contiguous()
+        dlog = K.cross_entropy(logits, Vv, tgt_m, losses["mtm"], want_grad=backward, ld_d=Vpad)
+        if want_outputs:
+            outs["out_mtm"] = logits[:, :Vv].reshape(B, X, Vv)
+
+        # ---- VTM head (main_pretrain.py:146-147,260-262,561)
+        cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
+        r_v = K.gather_rows(out2.t, cls_rows, B * O)
+        p_fc = 0.1 if train else 0.0
+        off_fc = self._next_offset(r_v.numel())
+        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
+        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        inv_temp = 1.0 / cfg["temp"]
+        lg_v = K.rowdot(h_v, S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp)           # [B*O]
+        tgt_v = torch.zeros(B, dtype=torch.int64, device=dev)
+        dlg_v = K.cross_entropy(lg_v.view(B, O), O, tgt_v, losses["vtm"], want_grad=backward, ld_d=O)
+        if want_outputs:
+            outs["out_vtm"] = lg_v.view(B, O)
+
+        # ---- MVM pixel head (main_pretrain.py:178-179,420-432)
+        ps = cfg["size_patch"]
+        h_, w_ = H // ps, W // ps
+        vis_rows = self._cached(("vis_rows", B, T, hw, Lq), lambda: _dev_i32(
+            np.concatenate([i * Lq + t * (1 + hw) + 1 + np.arange(hw) for i in range(B) for t in range(T)]), dev))
+        r_p = K.gather_rows(out1.t, vis_rows, B * T * hw)
+        Wpix = S.b("decoder_pixel.0.weight", (3 * ps * ps, Hd))
+        pred = K.gemm(r_p, Wpix, bias=S.p("decoder_pixel.0.bias"))
+        mask_sum = (cov.to(F32).sum() * float(3 * ps * ps)).view(1)
+        dpred = K.pixel_l1(pred, img, cov.reshape(-1), mask_sum, losses["mvm"], B, T, h_, w_, ps)
+        if want_outputs:
+            outs["out_mvm"] = out1.t.view(B, Lq, Hd)[:, :Lv]
+            outs["pred_pixel"] = pred
+        if not backward:
+            self.tape = []
+            return losses, outs
+
+        # =============================== backward ===============================
+        # heads -> gradients of the two encoder outputs
+        dcat = torch.empty((B * T * hw + B * X, Hd), device=dev, dtype=BF16)       # [pixel rows ; mlm rows]
+        self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
+                         dx_kw=dict(out=dcat[:B * T * hw]))
+        K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
+        K.gemm(dlog, tn, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
+        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
+        dt_m, _ = K.layernorm_bwd(dtn, t_m, gm, mean_m, rstd_m, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
+        du_m = K.gelu_bwd(dt_m, u_m)
+        self._linear_bwd(du_m, r_m, pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dcat[B * T * hw:]))
+        inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows]))
+        out1.g = K.gather_rows(dcat, inv1, B * Lq)
+        # VTM
+        dlg = dlg_v.float().reshape(-1).contiguous()
+        dh_v = K.rowdot_bwd(h_v, S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
+        dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
+        if p_fc > 0:
+            dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
+        inv2 = self._cached(("inv2", B * O, Lq, Lv), lambda: self._inverse_rows(B * O * Lq, [cls_rows]))
+        out2.g = K.gather_rows(dr_v, inv2, B * O * Lq)
+
+        # encoders (tape holds: encode, pass-1 layers, pass-2 layers) -> run pass 2 and pass 1, then scatter into the pool
+        n_layers = cfg["bert_layers"]
+        for _ in range(2 * n_layers):
+            self.tape.pop()()
+        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
+        K.scatter_add_rows(in1.g, idx1_d, dpool)
+        K.scatter_add_rows(in2.g, idx2_d, dpool)
+        pool.g = K.cast_bf16(dpool)
+        self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
+        if on_other_grads_ready is not None:
+            on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward
+        while self.tape:
+            self.tape.pop()()
+        return losses, outs
+
+    def _inverse_rows(self, n_rows, row_lists):
+        inv = np.full(n_rows, -1, dtype=np.int32)
+        off = 0
+        for r in row_lists:
+            rr = r.cpu().numpy()
+            inv[rr] = off + np.arange(rr.size)
+            off += rr.size
+        return _dev_i32(inv, self.device)
+
+    # -------------------------------------------------------------- stochastic pieces (host RNG, tiny uploads)
+    def sample_negatives(self, B, rng=None):
+        """main_pretrain.py:250-256 : O-1 negatives per clip from the LOCAL batch, without replacement."""
+        rng = rng or np.random
+        O = min(B, 4)
+        return np.stack([rng.permutation([j for j in range(B) if j != i])[:O - 1] for i in range(B)]) if O > 1 else np.zeros((B, 0), np.int64)
+
+    def sample_drop_path(self, B, rng=None):
+        """video_swin.py:46-54 : per-sample keep mask floor(keep + U), scaled by 1/keep; one (B,) f32 vector per block."""
+        rng = rng or np.random
+        rows = []
+        for p in self.dpr:
+            keep = 1.0 - p
+            rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
+        t = torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device)
+        return [t[i] for i in range(t.shape[0])]

@@ -72,6 +72,7 @@ def layernorm_fwd(X, gamma, beta, eps, *, M=None, C_=None, nseg=1, src=None, row
     d.M, d.C, d.nseg = M, Cc, nseg
     d.src, d.rows_out_per_batch, d.rows_in_per_batch, d.pad_mode = L.ptr(src), rows_out_per_batch, rows_in_per_batch, pad_mode
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
+    d.x_fp32 = int(X.dtype == F32)
     L.check(L.load().vmvm_layernorm_fwd(C.byref(d), L.stream()), "layernorm_fwd")
     return Y, mean, rstd
 
@@ -91,6 +92,7 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
     d.dX_add, d.ldadd = L.ptr(dX_add), (_ld(dX_add) if dX_add is not None else 0)
     d.dX2, d.lddx2 = L.ptr(dX2), Cc
     d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+    d.x_fp32 = int(X.dtype == F32)
     L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
     return dX, dX2
 
@@ -134,10 +136,10 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     return dqkv
 
 
-def patch_im2col(img):
+def patch_im2col(img, cov=None):
     B, T, _, H, W = img.shape
-    cols = torch.empty((B * T * (H // 4) * (W // 4), 96), device=img.device, dtype=BF16)
-    L.check(L.load().vmvm_patch_im2col(img.data_ptr(), cols.data_ptr(), B, T, H, W, L.stream()), "im2col")
+    cols = torch.empty((B * T * (H // 4) * (W // 4), 192), device=img.device, dtype=BF16)
+    L.check(L.load().vmvm_patch_im2col(img.data_ptr(), L.ptr(cov), cols.data_ptr(), B, T, H, W, L.stream()), "im2col")
     return cols
 
 
@@ -196,11 +198,11 @@ def rowdot(hid, w, b, inv_temp):
     return out
 
 
-def rowdot_bwd(hid, w, dout, inv_temp, dw, db):
+def rowdot_bwd(hid, w, dout, inv_temp, dw, db, relu_mask=False):
     M, K = hid.shape
     dhid = torch.empty_like(hid)
     L.check(L.load().vmvm_rowdot_bwd(hid.data_ptr(), M, K, w.data_ptr(), dout.data_ptr(), inv_temp, dhid.data_ptr(), dw.data_ptr(),
-                                     db.data_ptr(), L.stream()), "rowdot_bwd")
+                                     db.data_ptr(), int(relu_mask), L.stream()), "rowdot_bwd")
     return dhid
 
 
@@ -224,6 +226,25 @@ def gather_rows(src, idx, M, rows_out_per_batch=0, rows_in_per_batch=0):
     L.check(L.load().vmvm_gather_rows_bf16(src.data_ptr(), _ld(src), idx.data_ptr(), dst.data_ptr(), Cc, M, Cc, rows_out_per_batch,
                                            rows_in_per_batch, L.stream()), "gather_rows")
     return dst
+
+
+def scatter_add_rows(src, idx, dst_f32):
+    M, Cc = src.shape
+    L.check(L.load().vmvm_scatter_add_rows_bf16(src.data_ptr(), _ld(src), idx.data_ptr(), dst_f32.data_ptr(), _ld(dst_f32), M, Cc,
+                                                L.stream()), "scatter_add_rows")
+    return dst_f32
+
+
+def gelu_bwd(dy, u):
+    out = torch.empty_like(dy)
+    L.check(L.load().vmvm_gelu_bwd_bf16(dy.data_ptr(), u.data_ptr(), out.data_ptr(), dy.numel(), L.stream()), "gelu_bwd")
+    return out
+
+
+def dropout(x, p, seed, offset):
+    y = torch.empty_like(x)
+    L.check(L.load().vmvm_dropout_bf16(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, offset, L.stream()), "dropout")
+    return y
 
 
 def sumsq(g, out):

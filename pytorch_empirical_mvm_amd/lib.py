@@ -34,7 +34,7 @@ class LnFwdDesc(C.Structure):
                 ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
                 ("M", c_int), ("C", c_int), ("nseg", c_int),
                 ("src", c_void_p), ("rows_out_per_batch", c_int), ("rows_in_per_batch", c_int),
-                ("pad_mode", c_int), ("mean", c_void_p), ("rstd", c_void_p)]
+                ("pad_mode", c_int), ("mean", c_void_p), ("rstd", c_void_p), ("x_fp32", c_int)]
 
 
 class LnBwdDesc(C.Structure):
@@ -45,7 +45,7 @@ class LnBwdDesc(C.Structure):
                 ("src", c_void_p), ("rows_out_per_batch", c_int), ("rows_in_per_batch", c_int),
                 ("pad_mode", c_int),
                 ("dX_add", c_void_p), ("ldadd", c_int),
-                ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64)]
+                ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int)]
 
 
 class AttnFwdDesc(C.Structure):
@@ -83,7 +83,7 @@ _PROTOS = {
     "vmvm_layernorm_bwd": ([C.POINTER(LnBwdDesc), c_void_p], c_int),
     "vmvm_attention_fwd": ([C.POINTER(AttnFwdDesc), c_void_p], c_int),
     "vmvm_attention_bwd": ([C.POINTER(AttnBwdDesc), c_void_p], c_int),
-    "vmvm_patch_im2col": ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_patch_im2col": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_encvideo_assemble": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_encvideo_assemble_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_bert_embed": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
@@ -92,10 +92,13 @@ _PROTOS = {
     "vmvm_cross_entropy": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "vmvm_pixel_l1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_rowdot": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
-    "vmvm_rowdot_bwd": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "vmvm_rowdot_bwd": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_scatter_add_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_gelu_bwd_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_dropout_bf16": ([c_void_p, c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
     "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p], c_int),
     "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
     "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),

@@ -1,0 +1,149 @@
+"""Module / checkpoint surface of the reference (model.py, main_pretrain.py:140-267) over the HIP engine.
+
+`VIOLET_Pretrain(args, tokzr)` exposes the reference's attribute tree (`enc_img.swin.layers.0.blocks.0.attn.qkv.weight`,
+`trsfr.layer.3.output.dense.bias`, `fc_mtm.predictions.decoder.weight`, ...) as nn.Parameters that are VIEWS into the
+engine's flat f32 arena, so `state_dict()` / `load_state_dict()` / `torch.save` interchange with the reference's
+checkpoints (flat CPU state_dict, main_pretrain.py:612-619) while the kernels see one contiguous buffer."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import config as CFG
+from .engine import VioletEngine
+
+
+class _Node(torch.nn.Module):
+    pass
+
+
+def _trunc_normal_(t, std, gen):
+    # video_swin.py:17-43 (a=-2, b=2 in absolute units, as the reference passes them)
+    l = (1.0 + math.erf((-2.0) / std / math.sqrt(2.0))) / 2.0
+    u = (1.0 + math.erf((2.0) / std / math.sqrt(2.0))) / 2.0
+    t.uniform_(2 * l - 1, 2 * u - 1, generator=gen).erfinv_().mul_(std * math.sqrt(2.0)).clamp_(-2.0, 2.0)
+    return t
+
+
+class VIOLET_Pretrain(torch.nn.Module):
+    def __init__(self, args, tokzr=None, device="cuda"):
+        super().__init__()
+        self.args = args
+        self.cfg = CFG.model_cfg(args)
+        self.patch_size = args.size_patch                      # main_pretrain.py:145
+        self.hidden_size = self.cfg["hidden"]
+        self.tokzr = tokzr
+        self.cls_token_id, self.sep_token_id = CFG.TOKENS["cls"], CFG.TOKENS["sep"]
+        self.pad_token_id, self.mask_token_id, self.unk_token_id = CFG.TOKENS["pad"], CFG.TOKENS["mask"], CFG.TOKENS["unk"]
+        self.engine = VioletEngine(self.cfg, device=device, seed=args.get("seed", 88))
+        store = self.engine.store
+        for name in store.index:
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            prm = torch.nn.Parameter(store.p(name), requires_grad=name not in store.FROZEN or True)
+            prm.grad = store.g(name)
+            node.register_parameter(parts[-1], prm)
+        # relative_position_index buffers (video_swin.py:123-137) for checkpoint key parity
+        win = tuple(self.cfg["window"])
+        from .swin_index import rc_codes
+        n_full = win[0] * win[1] * win[2]
+        rc, rc0 = rc_codes(n_full, win)
+        rpi = torch.from_numpy((rc[:, None].astype(np.int64) - rc[None, :] + rc0))
+        for i, d in enumerate(self.cfg["depths"]):
+            for b in range(d):
+                getattr(self.enc_img.swin.layers, str(i)).blocks.__getattr__(str(b)).attn.register_buffer("relative_position_index", rpi)
+        self.init_weights(args.get("seed", 88))
+
+    # ------------------------------------------------------------------ init / state
+    @torch.no_grad()
+    def init_weights(self, seed=88):
+        """Reference initialisation: video_swin.py:544-551 (Linear trunc-normal .02 / LayerNorm 1,0), Conv3d default,
+        bias table trunc-normal .02 (:144), model.py:22-25 (0.02*randn embeddings), BERT N(0,.02), heads default nn.Linear."""
+        gen = torch.Generator().manual_seed(int(seed))
+        sd = {}
+        for name, (_, _, shape) in self.engine.store.index.items():
+            t = torch.zeros(shape)
+            last = name.split(".")[-1]
+            is_ln = ("norm" in name.lower()) and last in ("weight", "bias") and len(shape) == 1
+            if is_ln:
+                t.fill_(1.0 if last == "weight" else 0.0)
+            elif last == "bias":
+                if name in ("fc.1.bias", "fc.3.bias", "decoder_pixel.0.bias", "enc_img.fc.bias", "enc_img.swin.patch_embed.proj.bias"):
+                    fan_in = {"fc.1.bias": self.hidden_size, "fc.3.bias": 2 * self.hidden_size, "decoder_pixel.0.bias": self.hidden_size,
+                              "enc_img.fc.bias": self.cfg["embed_dim"] * 8, "enc_img.swin.patch_embed.proj.bias": 96}[name]
+                    b = 1.0 / math.sqrt(fan_in)
+                    t.uniform_(-b, b, generator=gen)
+            elif "relative_position_bias_table" in name:
+                _trunc_normal_(t, 0.02, gen)
+            elif name.startswith("enc_img.swin.") and "patch_embed.proj.weight" not in name:
+                _trunc_normal_(t, 0.02, gen)
+            elif name.startswith("enc_img.emb_"):
+                t.normal_(0.0, 1.0, generator=gen).mul_(0.02)
+            elif name.startswith("trsfr.") or name.startswith("enc_txt.") or name.startswith("fc_mtm."):
+                t.normal_(0.0, 0.02, generator=gen)
+            else:                                           # nn.Linear / Conv default: kaiming_uniform(a=sqrt(5))
+                fan_in = int(np.prod(shape[1:]))
+                b = 1.0 / math.sqrt(fan_in)
+                t.uniform_(-b, b, generator=gen)
+            sd[name] = t
+        self.engine.store.load_state(sd)
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        key = "fc_mtm.predictions.bias"
+        prefix = k.get("prefix", "")
+        if prefix + key in sd:                              # HF ties decoder.bias to predictions.bias (both keys are saved)
+            sd[prefix + "fc_mtm.predictions.decoder.bias"] = sd[prefix + key]
+        return sd
+
+    def load_state_dict(self, sd, strict=False):
+        own = super().state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own and k != "fc_mtm.predictions.decoder.bias"]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
+        self.engine.store.load_state({k: v for k, v in sd.items() if k in self.engine.store.index})
+        return missing, unexpected
+
+    def load_ckpt(self, ckpt):
+        """model.py:295-353 : non-strict, shape-filtered; emb_len / emb_pos grow-or-shrink copy."""
+        if ckpt == "" or not os.path.exists(ckpt):
+            return
+        loaded = torch.load(ckpt, map_location="cpu")
+        own = super().state_dict()
+        toload = {k: v for k, v in loaded.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+        for k, dim in (("enc_img.emb_len", 1), ("enc_img.emb_pos", 2)):
+            if k in loaded and k in own and tuple(loaded[k].shape) != tuple(own[k].shape):
+                cur = own[k].detach().cpu().clone()
+                n = min(cur.shape[dim], loaded[k].shape[dim])
+                sl = [slice(None)] * cur.dim()
+                sl[dim] = slice(0, n)
+                cur[tuple(sl)] = loaded[k][tuple(sl)]
+                toload[k] = cur
+        self.load_state_dict(toload, strict=False)
+
+    # ------------------------------------------------------------------ forward (inference surface)
+    @torch.no_grad()
+    def forward(self, batch, negatives=None):
+        """main_pretrain.py:226-267 : returns the reference's output dict (eval semantics, no dropout)."""
+        dev = self.engine.device
+        img, txt, mask = batch["img"].to(dev, torch.float32), batch["txt"].to(dev), batch["mask"].to(dev)
+        B, T, _, H, W = img.shape
+        ps = self.patch_size
+        cov = batch.get("cov")
+        if cov is None:
+            cov = torch.zeros(B, T, H // ps, W // ps, dtype=torch.uint8, device=dev)
+        ans_mtm = batch.get("ans_mtm")
+        if ans_mtm is None:
+            ans_mtm = torch.full_like(txt, -1)
+        b = dict(img=img.contiguous(), cov=cov.to(dev).contiguous(), txt=txt.contiguous(), mask=mask.contiguous(), ans_mtm=ans_mtm.to(dev).contiguous())
+        losses, outs = self.engine.forward_backward(b, negatives=negatives, train=False, want_outputs=True, backward=False)
+        O = min(B, 4)
+        return {"out_vtm": outs["out_vtm"], "out_mvm": outs["out_mvm"], "out_mtm": outs["out_mtm"], "out_smtm": None,
+                "ans_vtm": torch.zeros(B, dtype=torch.long, device=dev), "ans_mtm": b["ans_mtm"], "ans_mvm": batch.get("ans_mvm"),
+                "ans_smtm": None, "losses": losses, "pred_pixel": outs["pred_pixel"]}

@@ -50,7 +50,7 @@ def test_reduced_swin_fwd_and_grads():
     cfg = R.make_cfg("tiny", T=12, arch=arch)
     sd = {k: R.closed_form(k, s).requires_grad_(True) for k, s in R.param_shapes(cfg).items() if k.startswith("enc_img.swin.")}
     n = 1 * 3 * 12 * 96 * 80
-    x = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(1, 3, 12, 96, 80) * 1.5).float()
+    x = R.make_batch(dict(T=12, img=96, n_txt=32, vocab=30522), 1)[0][:, :, :, :, :80].transpose(1, 2).contiguous()
     y = R.swin_forward(sd, cfg, x)                      # channels-last (B,D,H,W,C)
     check_samp(d, "y", y)
     yc = y.permute(0, 4, 1, 2, 3).contiguous()         # the reference weights the NCDHW tensor

@@ -164,7 +164,7 @@ def gold_reduced_swin(vs):
     assert {k: tuple(v) for k, v in own.items()} == {k: tuple(v.shape) for k, v in sd.items()}, "key/shape mismatch"
     m.load_state_dict(sd, strict=False)
     n = 1 * 3 * 12 * 96 * 80
-    x = torch.from_numpy(np.sin(np.arange(n, dtype=np.float64) * 0.0137).reshape(1, 3, 12, 96, 80) * 1.5).float()
+    x = R.make_batch(dict(T=12, img=96, n_txt=32, vocab=30522), 1)[0][:, :, :, :, :80].transpose(1, 2).contiguous()
     y = m(x)
     d = {}
     put(d, "y", y.permute(0, 2, 3, 4, 1).contiguous(), 256)
