@@ -64,6 +64,7 @@ typedef struct {
   float col_scale; int32_t col_scale_n;
   float dropout_p; uint64_t seed, offset;
   int32_t variant;        /* 0 = default; 1 = force scalar (non-transposing-read) LDS path */
+  int32_t splitk;         /* 0 = auto (split the reduction when C is a plain f32 accumulator), 1 = off, >1 = K slices */
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 

@@ -10,6 +10,9 @@
 //   P stays in registers and is fed straight back as the B operand of  O^T = mfma(V^T, P^T):
 //   the MFMA k-slot order is free as long as both operands agree, so the accumulator layout of two
 //   adjacent S^T tiles IS a valid 32-deep operand (no cross-lane movement, no LDS round trip).
+//   K/V/Q/dO live in LDS once, row-major ([token][hd], 16-byte-chunk XOR swizzle): operands with k = hd are
+//   ds_read_b128 fragments, operands with k = tokens (V^T, K^T, Q^T, dO^T) are produced by the gfx950
+//   transposing read ds_read_b64_tr_b16 from the SAME image -- no transposed copies, no scatter writes.
 // Relative-position bias is evaluated arithmetically: idx(i,j) = rc[i]-rc[j]+rc0 into the per-head
 // table slice held in LDS; the shift mask is region[i] != region[j] ? -100 : 0.
 // Backward is two kernels (no atomics on dQ/dK/dV): A) per query tile: dQ (+ the bias-table
@@ -23,25 +26,18 @@ namespace {
 
 constexpr float NEG_INF = -__builtin_huge_valf();
 
-__host__ __device__ inline int odd16_stride(int bytes) {  // smallest multiple of 16 with odd quotient >= bytes
-  int q = (bytes + 15) / 16;
-  if (!(q & 1)) ++q;
-  return q * 16;
-}
-
 struct Smem {
-  int nt, nt2, lp16, lp32, vstride;
-  int off_k, off_vt, off_rc, off_reg, off_tab, off_dtab, off_lse, off_delta, total;
+  int nt, nt2, lp16, lp32;
+  int off_a, off_b, off_rc, off_reg, off_tab, off_dtab, off_lse, off_delta, total;
 };
 
-// which: 0 fwd (K, Vt) ; 1 bwdA (K, Kt, dtab) ; 2 bwdB (Qt, dOt, lse, delta)
+// which: 0 fwd (a=K, b=V) ; 1 bwdA (a=K, b=V, dtab) ; 2 bwdB (a=Q, b=dO, lse, delta)
 __host__ __device__ inline Smem smem_layout(int L, int hd, int mode, int table_len, int which) {
   Smem s;
   s.nt = (L + 15) / 16; s.nt2 = (s.nt + 1) / 2; s.lp16 = s.nt * 16; s.lp32 = s.nt2 * 32;
-  s.vstride = odd16_stride(s.lp32 * 2);
   int o = 0;
-  s.off_k = o; if (which != 2) o += s.lp16 * hd * 2;
-  s.off_vt = o; o += hd * s.vstride * (which == 2 ? 2 : 1);          // Vt | Kt | (Qt,dOt)
+  s.off_a = o; o += s.lp32 * hd * 2;
+  s.off_b = o; o += s.lp32 * hd * 2;
   s.off_rc = o; o += s.lp32 * 4;
   s.off_reg = o; o += s.lp32;                                         // region (mode 0) or keymask (mode 1)
   s.off_tab = o; if (mode == 0) o += ((table_len + 3) & ~3) * 4;
@@ -75,21 +71,6 @@ __device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src
     *reinterpret_cast<uint4*>(dst + k_off_swz<HD>(row, ch)) = v;
   }
 }
-// fill transposed [HD][stride] (token contiguous) from global rows (zero beyond L, up to lp32)
-template <int HD>
-__device__ __forceinline__ void fill_transposed(unsigned char* dst, int stride, const u16* src, int ld, int L, int lp32, int tid, int nthreads) {
-  constexpr int CPR = HD / 8;
-  for (int i = tid; i < lp32 * CPR; i += nthreads) {
-    const int row = i / CPR, ch = i - row * CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < L) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-    const u16 e[8] = {(u16)(v.x & 0xffff), (u16)(v.x >> 16), (u16)(v.y & 0xffff), (u16)(v.y >> 16),
-                      (u16)(v.z & 0xffff), (u16)(v.z >> 16), (u16)(v.w & 0xffff), (u16)(v.w >> 16)};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) *reinterpret_cast<u16*>(dst + (ch * 8 + k) * stride + row * 2) = e[k];
-  }
-}
-
 __device__ __forceinline__ bf16x8 load_frag_global(const u16* p, bool valid) {
   uint4 v = make_uint4(0, 0, 0, 0);
   if (valid) v = *reinterpret_cast<const uint4*>(p);
@@ -99,12 +80,22 @@ __device__ __forceinline__ bf16x8 frag_from_f32(const float* a, const float* b) 
   uint4 v = make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3]));
   return __builtin_bit_cast(bf16x8, v);
 }
-// 8 token-contiguous bf16 from a transposed image: tokens t0+0..3 and t1+0..3 of row d
-__device__ __forceinline__ bf16x8 load_frag_transposed(const unsigned char* base, int stride, int d, int t0, int t1) {
-  const uint2 a = *reinterpret_cast<const uint2*>(base + d * stride + t0 * 2);
-  const uint2 b = *reinterpret_cast<const uint2*>(base + d * stride + t1 * 2);
-  uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+// operand with k = tokens from the row-major swizzled image: row/col index d = dt*16 + (lane&15); k-slots 0-3 = tokens
+// tok_a + 0..3, k-slots 4-7 = tokens tok_b + 0..3 (tok_a/b = 16*tile + 4*(lane>>4)) -> two transposing 4x16 block reads.
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_tokens(const unsigned char* img, int dt, int tok_a, int tok_b, int r) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int chunk = dt * 2 + ((r & 3) >> 1), sub = (r & 1) * 8;
+  const int ra = tok_a + (r >> 2), rb = tok_b + (r >> 2);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + k_off_swz<HD>(ra, chunk) + sub));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + k_off_swz<HD>(rb, chunk) + sub));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(bf16x8, v);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_hd(const unsigned char* img, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(img + k_off_swz<HD>(row, chunk));
 }
 
 __device__ __forceinline__ uint32_t drop_thr8(float p) { return (uint32_t)(p * 256.f + 0.5f); }
@@ -128,14 +119,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
   const int logical = xcd_remap(blockIdx.x, p.nseq * heads);
   const int seq = logical / heads, h = logical - seq * heads;
   const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
-  unsigned char* Ksm = smem + sm.off_k;
-  unsigned char* Vt = smem + sm.off_vt;
+  unsigned char* Ksm = smem + sm.off_a;
+  unsigned char* Vsm = smem + sm.off_b;
   int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
   unsigned char* reg = smem + sm.off_reg;
   float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
 
-  fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp16, tid, NW * 64);
-  fill_transposed<HD>(Vt, sm.vstride, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
   if (MODE == 0) {
     for (int i = tid; i < sm.lp32; i += NW * 64) {
       rc[i] = i < L ? p.rc[i] : 0;
@@ -241,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
         const bf16x8 pf = frag_from_f32(a, b);
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
-          const bf16x8 vf = load_frag_transposed(Vt, sm.vstride, dt * 16 + r, c * 32 + g * 4, c * 32 + 16 + g * 4);
+          const bf16x8 vf = frag_tokens<HD>(Vsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
         }
       }
@@ -260,46 +251,50 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 // backward A: dQ (+ delta, + relative-position-bias table gradient)
 // ================================================================================================
 template <int HD, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bwd_desc pb) {
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bwd_desc pb, const int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int L = p.L, heads = p.heads;
   const Smem sm = smem_layout(L, HD, MODE, p.table_len, 1);
-  const int logical = xcd_remap(blockIdx.x, p.nseq * heads);
-  const int seq = logical / heads, h = logical - seq * heads;
-  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
-  const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
-  const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * L * p.ld_out + h * HD;
-  unsigned char* Ksm = smem + sm.off_k;
-  unsigned char* Kt = smem + sm.off_vt;
+  // persistent over sequences: workgroup (chunk, head) walks seq = chunk, chunk+nchunks, ... so the bias-table gradient
+  // is accumulated in LDS across many windows and flushed with ONE global atomic per entry per workgroup.
+  const int logical = xcd_remap(blockIdx.x, nchunks * heads);
+  const int chunk = logical / heads, h = logical - chunk * heads;
+  unsigned char* Ksm = smem + sm.off_a;
+  unsigned char* Vsm = smem + sm.off_b;
   int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
   unsigned char* reg = smem + sm.off_reg;
   float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
   float* dtab = reinterpret_cast<float*>(smem + sm.off_dtab);
-
-  fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp16, tid, NW * 64);
-  fill_transposed<HD>(Kt, sm.vstride, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
+  const bool want_dtab = pb.dbias_table != nullptr;
+  const uint32_t thr8 = drop_thr8(p.dropout_p);
+  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const int nt = sm.nt, nt2 = sm.nt2;
   if (MODE == 0) {
-    for (int i = tid; i < sm.lp32; i += NW * 64) {
-      rc[i] = i < L ? p.rc[i] : 0;
-      reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
-    }
+    for (int i = tid; i < sm.lp32; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
     for (int i = tid; i < p.table_len; i += NW * 64) { tab[i] = p.bias_table[(size_t)i * heads + h]; dtab[i] = 0.f; }
+  }
+
+  for (int seq = chunk; seq < p.nseq; seq += nchunks) {
+  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+  const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
+  const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * L * p.ld_out + h * HD;
+  __syncthreads();                                  // every wave is done with the previous sequence's LDS image
+  fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  if (MODE == 0) {
+    for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
   } else {
     for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
   }
   __syncthreads();
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
-  const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
-  const int nt = sm.nt, nt2 = sm.nt2;
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
-  const u16* Vg = qkv + p.v_off + h * HD;
 
   for (int qt = wave; qt < nt; qt += NW) {
     const int q = qt * 16 + r;
@@ -339,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
           for (int s = 0; s < HD / 32; ++s) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], s4, 0, 0, 0);
-            const bf16x8 vf = load_frag_global(Vg + (size_t)row * p.ld_qkv + g * 8 + s * 32, row < L);
+            const bf16x8 vf = frag_hd<HD>(Vsm, row, s * 4 + g);
             dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dp4, 0, 0, 0);
           }
           const int key0 = t * 16 + g * 4;
@@ -360,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
               const float pr = (key0 + j < L && qv) ? __expf(s - lse) : 0.f;
               const float d = pr * (dp4[j] * seq_scale - dl);
               ds[u][j] = d;
-              if (pr != 0.f) atomicAdd(&dtab[bi], d);
+              if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], d);
             }
           } else {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
@@ -378,7 +373,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
       const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
-        const bf16x8 kf = load_frag_transposed(Kt, sm.vstride, dt * 16 + r, c * 32 + g * 4, c * 32 + 16 + g * 4);
+        const bf16x8 kf = frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
       }
     }
@@ -390,7 +385,133 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
         *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
     }
   }
-  if (MODE == 0) {
+  }   // sequences
+  if (MODE == 0 && want_dtab) {
+    __syncthreads();
+    for (int i = tid; i < p.table_len; i += NW * 64) {
+      const float v = dtab[i];
+      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+    }
+  }
+}
+
+// ================================================================================================
+// backward A' (window mode): dQ + bias-table gradient with the dS tiles accumulated IN REGISTERS across windows.
+// A wave owns one fixed query tile (16 queries) for the whole launch and walks the windows of its chunk; the 16 x N
+// block of dS it produces per window is summed into racc[] (same accumulator layout as the forward scores), so the
+// scatter into the relative-position table (rc[i]-rc[j]+rc0) happens once per workgroup instead of once per window:
+// per-element LDS atomics were 50% of the backward attention time.
+// ================================================================================================
+template <int NT_MAX, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqg) {
+  constexpr int HD = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads;
+  const Smem sm = smem_layout(L, HD, 0, p.table_len, 1);
+  const int logical = xcd_remap(blockIdx.x, nchunks * heads * nqg);
+  const int chunk = logical / (heads * nqg);
+  const int rem = logical - chunk * heads * nqg;
+  const int h = rem / nqg, qg = rem - h * nqg;
+  unsigned char* Ksm = smem + sm.off_a;
+  unsigned char* Vsm = smem + sm.off_b;
+  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
+  unsigned char* reg = smem + sm.off_reg;
+  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  float* dtab = reinterpret_cast<float*>(smem + sm.off_dtab);
+  const bool want_dtab = pb.dbias_table != nullptr;
+  const int nt = sm.nt, nt2 = sm.nt2;
+  for (int i = tid; i < sm.lp32; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
+  for (int i = tid; i < p.table_len; i += NW * 64) { tab[i] = p.bias_table[(size_t)i * heads + h]; dtab[i] = 0.f; }
+
+  const int qt = qg * NW + wave;
+  const int q = qt * 16 + r;
+  const bool qv = (qt < nt) && (q < L);
+  f32x4 racc[NT_MAX];
+#pragma unroll
+  for (int t = 0; t < NT_MAX; ++t) racc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int seq = chunk; seq < p.nseq; seq += nchunks) {
+    const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+    const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
+    const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * L * p.ld_out + h * HD;
+    __syncthreads();
+    fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+    fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+    for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
+    __syncthreads();
+    if (qt >= nt) continue;                                   // wave-uniform; barriers above are still reached by all waves
+    const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+    const bf16x8 qf = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8, qv);
+    const bf16x8 dof = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8, qv);
+    const bf16x8 of = load_frag_global(O + (size_t)q * p.ld_out + g * 8, qv);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)dof[e] * (float)of[e];
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0 && qv) pb.delta[((size_t)seq * heads + h) * L + q] = dl;
+    const float lse = qv ? p.lse[((size_t)seq * heads + h) * L + q] : 0.f;
+    const int rcq = rc[qv ? q : 0], regq = reg[qv ? q : 0];
+    f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < NT_MAX / 2; ++c) {
+      if (c < nt2) {
+        float ds[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * c + u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ds[u][j] = 0.f;
+          if (t < nt) {
+            const int row = t * 16 + r;
+            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Ksm, row, g), qf, s4, 0, 0, 0);
+            dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Vsm, row, g), dof, dp4, 0, 0, 0);
+            const int key0 = t * 16 + g * 4;
+            const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
+            const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0);
+            const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
+            const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float sv = s4[j] + tab[rcq - rks[j] + p.rc0] + (regq != gks[j] ? -100.f : 0.f);
+              const float pr = (key0 + j < L && qv) ? __expf(sv - lse) : 0.f;
+              const float d = pr * (dp4[j] * seq_scale - dl);
+              ds[u][j] = d;
+              racc[t][j] += d;
+            }
+          }
+        }
+        const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (qv) {
+      u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + q) * pb.ld_dqkv + p.q_off + h * HD + g * 4;
+      const float sc = p.scale;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
+    }
+  }
+  if (want_dtab) {
+    if (qv) {
+      const int rcq = rc[q];
+#pragma unroll
+      for (int t = 0; t < NT_MAX; ++t) {
+        if (t < nt) {
+          const int key0 = t * 16 + g * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (key0 + j < L) atomicAdd(&dtab[rcq - rc[key0 + j] + p.rc0], racc[t][j]);
+        }
+      }
+    }
     __syncthreads();
     for (int i = tid; i < p.table_len; i += NW * 64) {
       const float v = dtab[i];
@@ -414,16 +535,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   const int seq = logical / heads, h = logical - seq * heads;
   const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
   const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
-  unsigned char* Qt = smem + sm.off_vt;
-  unsigned char* dOt = Qt + HD * sm.vstride;
+  unsigned char* Qsm = smem + sm.off_a;
+  unsigned char* dOsm = smem + sm.off_b;
   int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
   unsigned char* reg = smem + sm.off_reg;
   float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
   float* lse_s = reinterpret_cast<float*>(smem + sm.off_lse);
   float* delta_s = reinterpret_cast<float*>(smem + sm.off_delta);
 
-  fill_transposed<HD>(Qt, sm.vstride, qkv + p.q_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
-  fill_transposed<HD>(dOt, sm.vstride, dO, pb.ld_dout, L, sm.lp32, tid, NW * 64);
+  fill_rowmajor<HD>(Qsm, qkv + p.q_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_rowmajor<HD>(dOsm, dO, pb.ld_dout, L, sm.lp32, tid, NW * 64);
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   const float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
   for (int i = tid; i < sm.lp32; i += NW * 64) {
@@ -445,7 +566,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   const uint32_t thr8 = drop_thr8(p.dropout_p);
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
-  const u16* Qg = qkv + p.q_off + h * HD;
 
   for (int kt = wave; kt < nt; kt += NW) {
     const int key = kt * 16 + r;
@@ -474,9 +594,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
           f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < HD / 32; ++s) {
-            const bf16x8 qf = load_frag_global(Qg + (size_t)qrow * p.ld_qkv + g * 8 + s * 32, qrow < L);
+            const bf16x8 qf = frag_hd<HD>(Qsm, qrow, s * 4 + g);
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[s], s4, 0, 0, 0);
-            const bf16x8 dof = load_frag_global(dO + (size_t)qrow * pb.ld_dout + g * 8 + s * 32, qrow < L);
+            const bf16x8 dof = frag_hd<HD>(dOsm, qrow, s * 4 + g);
             dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[s], dp4, 0, 0, 0);
           }
           // lane now holds (query = qt*16 + 4g + j, key)
@@ -519,9 +639,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
       const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
-        const bf16x8 dof = load_frag_transposed(dOt, sm.vstride, dt * 16 + r, c * 32 + g * 4, c * 32 + 16 + g * 4);
+        const bf16x8 dof = frag_tokens<HD>(dOsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
-        const bf16x8 qf = load_frag_transposed(Qt, sm.vstride, dt * 16 + r, c * 32 + g * 4, c * 32 + 16 + g * 4);
+        const bf16x8 qf = frag_tokens<HD>(Qsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
         dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf, dk[dt], 0, 0, 0);
       }
     }
@@ -594,20 +714,47 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     hipLaunchKernelGGL((KERN<HD, MODE, NW>), dim3(nb), dim3(NW * 64), s_.total, st, *d);     \
     VMVM_CHECK_LAUNCH();                                                                     \
   } while (0)
+#define LAUNCH_BWD_DQ(HD, MODE, NW)                                                          \
+  do {                                                                                       \
+    const Smem s_ = smem_layout(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 1);        \
+    int rc_ = set_smem(attn_bwd_dq_kernel<HD, MODE, NW>, s_.total);                          \
+    if (rc_) return rc_;                                                                     \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, MODE, NW>), dim3(nchunks * d->f.heads), dim3(NW * 64), s_.total, st, *d, nchunks); \
+    VMVM_CHECK_LAUNCH();                                                                     \
+  } while (0)
 
 extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   if (!d) return VMVM_EINVAL;
   int rc = check_desc(&d->f);
   if (rc) return rc;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
-  if (d->f.mode == 0 && !d->dbias_table) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nb = d->f.nseq * d->f.heads;
+  // dq: persistent workgroups, ~3 per CU (mode 0) so the per-workgroup bias-table flush is amortised over many windows
+  int nchunks = d->f.nseq;
   if (d->f.mode == 0) {
-    LAUNCH_BWD(attn_bwd_dq_kernel, 32, 0, 4, 1);
+    const int want = (768 + d->f.heads - 1) / d->f.heads;
+    if (nchunks > want) nchunks = want;
+  }
+  if (d->f.mode == 0) {
+    const Smem s_ = smem_layout(d->f.L, 32, 0, d->f.table_len, 1);
+    const int nqg = (s_.nt + 3) / 4;
+    int nch = 768 / (d->f.heads * nqg);
+    if (nch < 1) nch = 1;
+    if (nch > d->f.nseq) nch = d->f.nseq;
+    if (s_.nt <= 16) {
+      int rc_ = set_smem(attn_bwd_dq_win_kernel<16, 4>, s_.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_bwd_dq_win_kernel<16, 4>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg);
+    } else {
+      int rc_ = set_smem(attn_bwd_dq_win_kernel<28, 4>, s_.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_bwd_dq_win_kernel<28, 4>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg);
+    }
+    VMVM_CHECK_LAUNCH();
     LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2);
   } else {
-    LAUNCH_BWD(attn_bwd_dq_kernel, 64, 1, 8, 1);
+    LAUNCH_BWD_DQ(64, 1, 8);
     LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2);
   }
   return VMVM_OK;

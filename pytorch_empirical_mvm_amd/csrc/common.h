@@ -48,10 +48,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact-erf GELU (video_swin.py:66 nn.GELU ; HF hidden_act="gelu") and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (video_swin.py:66 nn.GELU ; HF hidden_act="gelu") and its derivative.  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the bf16 output rounding): one rcp + one exp instead of ocml's branchy erff.
+__device__ __forceinline__ void erf_exp_f(float z, float& erfz, float& ez2) {       // erf(z), exp(-z^2)
+  const float a = fabsf(z);
+  const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
+  ez2 = __expf(-a * a);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = fmaf(-poly, ez2, 1.0f);
+  erfz = copysignf(e, z);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e, g;
+  erf_exp_f(x * 0.70710678118654752f, e, g);
+  return 0.5f * x * (1.0f + e);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  float e, g;
+  erf_exp_f(x * 0.70710678118654752f, e, g);                    // g = exp(-x^2/2)
+  return fmaf(x * 0.39894228040143268f, g, 0.5f * (1.0f + e));
 }
 
 // Philox4x32-7 counter RNG: 4 x 32 random bits per (counter, key)

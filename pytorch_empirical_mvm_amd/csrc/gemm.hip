@@ -101,9 +101,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   // XCD-aware bijective remap (block b runs on XCD b%8)
   const int bid = blockIdx.x;
   const int q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
-  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  const int tm = logical / nbn, tn = logical - tm * nbn;
+  // XCD remap over the whole grid (tiles x K-slices); consecutive logical ids = neighbouring tiles of one K-slice
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  const int nbt = nb * S;
+  const int q2 = nbt >> 3, rr2 = nbt & 7;
+  const int logical = (xcd < rr2 ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2) + idx;
+  const int slice = logical / nb, tile = logical - slice * nb;
+  const int tm = tile / nbn, tn = tile - tm * nbn;
   const int m0 = tm * BM, n0 = tn * BN;
+  (void)q; (void)rr;
 
   const u16* A = reinterpret_cast<const u16*>(p.A);
   const u16* B = reinterpret_cast<const u16*>(p.B);
@@ -115,15 +121,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
-  const int nk = (K + BK - 1) / BK;
-  load_tile<AK>(A, p.lda, M, K, m0, 0, tid, ra);
-  load_tile<BKM>(B, p.ldb, N, K, n0, 0, tid, rb);
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + S - 1) / S;
+  const int kt0 = slice * per;
+  const int nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;        // this block multiplies K-tiles [kt0, nk)
+  if (kt0 >= nk) return;
+  load_tile<AK>(A, p.lda, M, K, m0, kt0 * BK, tid, ra);
+  load_tile<BKM>(B, p.ldb, N, K, n0, kt0 * BK, tid, rb);
   store_tile<AK>(smem, tid, ra);
   store_tile<BKM>(smem + TILE_BYTES, tid, rb);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
     const unsigned char* la = smem + cur * 2 * TILE_BYTES;
     const unsigned char* lb = la + TILE_BYTES;
     if (kt + 1 < nk) {
@@ -216,7 +226,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
         v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
         v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
       }
-      if (p.out_fp32) {
+      if (S > 1) {                                       // split-K partial: f32 atomics into the (pre-existing) accumulator
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+      } else if (p.out_fp32) {
         float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
         if (p.accumulate) {
           const float4 o = *reinterpret_cast<const float4*>(c);
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
 
 template <bool AK, bool BKM, bool TR>
 int launch(const vmvm_gemm_desc& d, hipStream_t st) {
-  const int nb = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  const int nb = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * (d.splitk > 1 ? d.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AK, BKM, TR>),
@@ -261,6 +275,24 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (d->row_scale && d->rows_per_scale <= 0) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool tr = d->variant != 1;
+  vmvm_gemm_desc dd = *d;
+  d = &dd;
+  // split-K: weight gradients have few output tiles and a very long reduction (tokens); spread the reduction over
+  // ~4 workgroups per CU and combine with f32 atomics into the gradient accumulator.
+  const bool plain_acc = dd.out_fp32 && dd.accumulate && !dd.bias && !dd.row_scale && !dd.act && !dd.resid && !dd.row_map &&
+                         dd.dropout_p <= 0.f && dd.col_scale_n == 0;
+  if (dd.splitk == 0) {
+    dd.splitk = 1;
+    if (plain_acc) {
+      const int tiles = ((dd.M + BM - 1) / BM) * ((dd.N + BN - 1) / BN);
+      const int nk_all = (dd.K + BK - 1) / BK;
+      int s = 1024 / tiles;
+      if (s > nk_all / 4) s = nk_all / 4;
+      if (s > 1) dd.splitk = s;
+    }
+  } else if (dd.splitk > 1 && !plain_acc) {
+    return VMVM_EINVAL;
+  }
   if (d->a_kmajor && d->b_kmajor) return launch<true, true, true>(*d, st);
   if (d->a_kmajor && !d->b_kmajor) return tr ? launch<true, false, true>(*d, st) : launch<true, false, false>(*d, st);
   if (!d->a_kmajor && !d->b_kmajor) return tr ? launch<false, false, true>(*d, st) : launch<false, false, false>(*d, st);

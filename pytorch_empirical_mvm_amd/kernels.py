@@ -19,7 +19,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None):
+         variant=0, out_rows=None, splitk=0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -48,6 +48,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.col_scale, d.col_scale_n = col_scale, col_scale_n
     d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
     d.variant = variant
+    d.splitk = splitk
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
 

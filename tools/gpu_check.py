@@ -100,6 +100,11 @@ def check_gemm_epilogues():
     acc0 = acc.clone()
     K.gemm(A, B, out=acc, accumulate=True)
     rep("gemm fp32 accumulate", acc, base + acc0, tol=1e-3)
+    for sk in (1, 3, 0):
+        acc = torch.randn(N, K_, device=dev)
+        acc0 = acc.clone()
+        K.gemm(A.t().contiguous().t().contiguous(), A, a_kmajor=False, b_kmajor=False, M=K_, N=K_, K=M, out=acc[:K_], accumulate=True, splitk=sk)
+        rep(f"gemm wgrad-shape accumulate splitk={sk}", acc[:K_], A.float().t() @ A.float() + acc0[:K_], tol=2e-3)
     rep("gemm col_scale", K.gemm(A, B, bias=bias, col_scale=0.25, col_scale_n=64),
         torch.cat([(base + bias)[:, :64] * 0.25, (base + bias)[:, 64:]], 1))
     # row map: 2 clips x 392 slots -> token order, with pads
@@ -426,7 +431,10 @@ def bench_gemm():
             print(f"     {name:6s} {M}x{N}x{K_}: {ms:.3f} ms  {2.0 * M * N * K_ / ms / 1e9:.1f} TF")
         Bt = B.t().contiguous()
         At = A.t().contiguous()
-        for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False))):
+        dy = rnd(M, N)
+        gw = torch.zeros(N, K_, device=dev)
+        for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False)),
+                         ("wgrad", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True))):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -454,7 +462,8 @@ def bench_attn():
     dtab = torch.zeros_like(table)
     b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab)
     fl = 4.0 * nseq * heads * N * N * 32
-    for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5)):
+    b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None)
+    for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5), ("win bwd (no table grad)", b0, 2.5)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
