@@ -1,0 +1,71 @@
+"""The C-ABI library loads and exports every symbol include/vmvm.h declares; ctypes struct layouts match the header's
+field order; the product path fails loudly (no CPU fallback) when the library is missing.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "vmvm.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    from pytorch_empirical_mvm_amd import build, lib
+    build.build(force=False, verbose=False)
+    declared = sorted(set(re.findall(r"^int (vmvm_\w+)\(", _header(), flags=re.M)))
+    assert len(declared) >= 25
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), f"{name} declared in include/vmvm.h but not exported"
+    assert sorted(lib.exported_symbols()) == declared, set(declared) ^ set(lib.exported_symbols())
+    assert lib.load().vmvm_version() >= 1
+
+
+@pytest.mark.parametrize("cname,pyname", [("vmvm_gemm_desc", "GemmDesc"), ("vmvm_ln_fwd_desc", "LnFwdDesc"), ("vmvm_ln_bwd_desc", "LnBwdDesc"),
+                                          ("vmvm_attn_fwd_desc", "AttnFwdDesc"), ("vmvm_attn_bwd_desc", "AttnBwdDesc"), ("vmvm_adamw_desc", "AdamWDesc")])
+def test_ctypes_structs_follow_header_field_order(cname, pyname):
+    from pytorch_empirical_mvm_amd import lib
+    m = re.search(r"typedef struct \{([^}]*)\} " + cname + ";", _header())
+    assert m, cname
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.split(",")
+        first = parts[0].split()
+        names.append(first[-1].lstrip("*"))
+        names += [p.strip().lstrip("*") for p in parts[1:]]
+    py = [f[0] for f in getattr(lib, pyname)._fields_]
+    assert py == names, (py, names)
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from pytorch_empirical_mvm_amd import lib
+    l = lib.load()
+    d = lib.GemmDesc()
+    assert l.vmvm_gemm_bf16(ctypes.byref(d), None) == -1          # VMVM_EINVAL: null operands
+    assert l.vmvm_sumsq_f32(None, 10, None, None) == -1
+    a = lib.AttnFwdDesc()
+    assert l.vmvm_attention_fwd(ctypes.byref(a), None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pytorch_empirical_mvm_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libvmvm.so")
+    with pytest.raises(RuntimeError, match="NO CPU"):
+        lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pytorch_empirical_mvm_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle|violet_ref", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,72 @@
+"""Data-parallel path on CPU: 2 processes, gloo.  The two-phase gradient reduction (non-Swin groups first, then Swin)
+must produce the rank-sum in every trainable segment and leave the frozen segment alone; AdamW's 1/world scale is
+applied by the kernel (checked on the GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd import dist as D
+    from pytorch_empirical_mvm_amd.engine import ParamStore
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world) and D.is_initialized()
+    args = CFG.get_args(vis_backbone_size="tiny", arch_override=dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7)),
+                        bert_layers=1)
+    S = ParamStore(CFG.param_shapes(CFG.model_cfg(args)), torch.device("cpu"))
+    g = torch.Generator().manual_seed(100 + rank)
+    S.grad[:S.total].copy_(torch.randn(S.total, generator=g))
+    mine = S.grad[:S.total].clone()
+    S.flat[:S.total].fill_(float(rank + 1))
+    D.broadcast_(S.flat)
+    red = D.GradReducer(S, "cpu")
+    red.reduce_other()
+    mid = S.grad[:S.total].clone()
+    red.reduce_swin_and_wait()
+    # expected: sum over ranks in trainable segments
+    others = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    tot = sum(others)
+    ok = True
+    for gi in range(4):
+        a, e = S.segments[gi]
+        ok &= torch.allclose(S.grad[a:e], tot[a:e], atol=1e-5)
+        if gi in (0, 2):
+            ok &= torch.equal(mid[a:e], mine[a:e])            # Swin groups untouched by phase 1
+        else:
+            ok &= torch.allclose(mid[a:e], tot[a:e], atol=1e-5)
+    a, e = S.segments[4]
+    ok &= torch.equal(S.grad[a:e], mine[a:e])                   # frozen segment never reduced
+    ok &= bool((S.flat[:S.total] == 1.0).all())                 # parameters broadcast from rank 0
+    t = torch.tensor([float(rank)])
+    D.all_reduce_(t)
+    ok &= float(t) == sum(range(world))
+    q.put((rank, bool(ok)))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_phase_gradient_reduction_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

@@ -1,0 +1,81 @@
+"""Host-side logic of the product package against the oracle / reference goldens (CPU only)."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from oracle import violet_ref as R
+from pytorch_empirical_mvm_amd import config as CFG
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_param_inventory_matches_reference_key_list():
+    for size, T in (("tiny", 4), ("base", 8), ("large", 8)):
+        args = CFG.get_args(vis_backbone_size=size, size_frame=T, max_size_frame=max(T, 6))
+        mine = CFG.param_shapes(CFG.model_cfg(args))
+        ref = R.param_shapes(R.make_cfg(size, T=T))
+        assert list(mine.keys()) == list(ref.keys())
+        assert all(tuple(mine[k]) == tuple(ref[k]) for k in ref)
+    n_base = sum(int(np.prod(s)) for s in CFG.param_shapes(CFG.model_cfg(CFG.get_args(vis_backbone_size="base", max_size_frame=8))).values())
+    assert n_base == 225_086_979                      # SURVEY.md section 8(a) a15 probe (Swin-B, T=8)
+
+
+def test_param_groups_and_lr_schedule_match_reference_goldens():
+    d = np.load(os.path.join(G, "optimizer.npz"))
+    for n, row in zip([str(x) for x in d["names"]], d["groups"]):
+        g = CFG.param_group(n)                      # 0 decay+swin, 1 decay+other, 2 nodecay+swin, 3 nodecay+other
+        assert int(np.argmax(row)) == g, n
+    for k, lr in d["lr_table"]:
+        assert abs(max(1e-8, 5e-5 * CFG.lr_factor(int(k), 1000)) - lr) <= 1e-12 + 1e-9 * lr
+
+
+def test_agent_masking_reproduces_reference_draws():
+    """Agent_Pretrain.masking consumes `random`, `torch.rand`, `np.random` in the reference's order (main_pretrain.py:303-352)."""
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, "masking.npz"))
+    cfg = R.make_cfg("tiny", T=4)
+    img, txt, mask = R.make_batch(cfg, 3)
+
+    class _M:
+        patch_size = 32
+        engine = type("E", (), {"device": torch.device("cpu")})()
+    for name in ("rm", "bm"):
+        args = CFG.get_args(pretrain_masks=[name])
+        ag = Agent_Pretrain.__new__(Agent_Pretrain)
+        ag.args, ag.patch_size = args, 32
+        ag.cls_token_id, ag.sep_token_id, ag.pad_token_id, ag.mask_token_id = 101, 102, 0, 103
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        o = ag.masking(img.clone(), txt.clone(), mask.clone(), None, materialize=True)
+        np.testing.assert_array_equal(o["cov"].numpy(), d[f"{name}.cov"])
+        np.testing.assert_array_equal(o["txt"].numpy(), d[f"{name}.txt"])
+        np.testing.assert_array_equal(o["ans_mtm"].numpy(), d[f"{name}.ans_mtm"])
+        np.testing.assert_array_equal(o["ans_mvm"].numpy(), d[f"{name}.ans_mvm"])
+        np.testing.assert_allclose(float(o["img"].double().sum()), float(d[f"{name}.img_sum"]), rtol=1e-9)
+        assert float(o["mvm_mask"].double().sum()) == float(d[f"{name}.mask_sum"])
+
+
+def test_arena_layout_groups_and_fused_qkv():
+    """ParamStore: optimizer groups are contiguous segments, every view is 8-element aligned, BERT q/k/v are adjacent."""
+    from pytorch_empirical_mvm_amd.engine import ParamStore
+    args = CFG.get_args(vis_backbone_size="tiny", arch_override=dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7)),
+                        bert_layers=2)
+    shapes = CFG.param_shapes(CFG.model_cfg(args))
+    S = ParamStore.__new__(ParamStore)
+    # layout only (no device allocation): replicate __init__'s index computation through a CPU store
+    S.__init__(shapes, torch.device("cpu"))
+    seen = 0
+    for n, (o, c, shp) in S.index.items():
+        assert o % 8 == 0 and o >= seen
+        seen = o + c
+        g = 4 if n in S.FROZEN else CFG.param_group(n)
+        a, e = S.segments[g]
+        assert a <= o and o + c <= e, (n, g)
+    assert S.segments[4][1] - S.segments[4][0] == 768          # frozen enc_img.emb_odr
+    H = 768
+    qn = [f"trsfr.layer.1.attention.self.{x}.weight" for x in ("query", "key", "value")]
+    w = S.fused(S.flat, qn, (3 * H, H))
+    S.p(qn[1]).fill_(2.0)
+    assert float(w[H:2 * H].sum()) == 2.0 * H * H and float(w[:H].sum()) == 0.0
+    assert S.n_trainable == S.segments[3][1]
