@@ -65,6 +65,8 @@ typedef struct {
   float dropout_p; uint64_t seed, offset;
   int32_t variant;        /* 0 = default; 1 = force scalar (non-transposing-read) LDS path */
   int32_t splitk;         /* 0 = auto (split the reduction when C is a plain f32 accumulator), 1 = off, >1 = K slices */
+  void* workspace; int64_t workspace_bytes;   /* optional caller-owned scratch for split-K slabs (splitk*M*N f32); without it
+                                                 the slices combine with f32 atomics */
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 

@@ -58,6 +58,30 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const ui
   }
 }
 
+// ---- direct global -> LDS staging (buffer_load_dwordx4 ... lds): no VGPR round trip, no ds_write.  The LDS image is
+// lane-linear per wave instruction (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
+// offset (same involution as the read side).  Out-of-range rows fall beyond num_records and read as zero.
+template <bool KMAJOR>
+__device__ __forceinline__ void issue_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, int row0, int k0, unsigned char* lds, int tid) {
+  const int wave_base = (tid & ~63);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + i * 256;
+    unsigned goff;
+    if (KMAJOR) {
+      const int row = u >> 3, cs = u & 7;
+      const int c = cs ^ ((row >> 1) & 7);
+      goff = (unsigned)(((size_t)(row0 + row) * ld + k0 + c * 8) * 2);
+    } else {
+      const int krow = u >> 4, unit = u & 15;
+      const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
+      goff = (unsigned)(((size_t)(k0 + krow) * ld + row0 + (slot * 2 + (unit & 1)) * 8) * 2);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds + (i * 256 + wave_base) * 16), 16, goff, 0, 0, 0);
+  }
+}
+
 // ---- LDS -> MFMA fragment (8 bf16 along k for row/col `x` of the tile), k-step s (32 wide) ------
 template <bool KMAJOR, bool TR>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int x16, int s, int lane) {
@@ -90,7 +114,7 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int x16, i
   }
 }
 
-template <bool AK, bool BKM, bool TR>
+template <bool AK, bool BKM, bool TR, bool DIRECT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,26 +144,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
   const int nk_all = (K + BK - 1) / BK;
   const int per = (nk_all + S - 1) / S;
   const int kt0 = slice * per;
   const int nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;        // this block multiplies K-tiles [kt0, nk)
   if (kt0 >= nk) return;
-  load_tile<AK>(A, p.lda, M, K, m0, kt0 * BK, tid, ra);
-  load_tile<BKM>(B, p.ldb, N, K, n0, kt0 * BK, tid, rb);
-  store_tile<AK>(smem, tid, ra);
-  store_tile<BKM>(smem + TILE_BYTES, tid, rb);
-  __syncthreads();
 
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const unsigned char* la = smem + cur * 2 * TILE_BYTES;
-    const unsigned char* lb = la + TILE_BYTES;
-    if (kt + 1 < nk) {
-      load_tile<AK>(A, p.lda, M, K, m0, (kt + 1) * BK, tid, ra);
-      load_tile<BKM>(B, p.ldb, N, K, n0, (kt + 1) * BK, tid, rb);
-    }
+  auto mma_tile = [&](const unsigned char* la, const unsigned char* lb) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 fa[4], fb[4];
@@ -153,12 +164,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      unsigned char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      store_tile<AK>(na, tid, ra);
-      store_tile<BKM>(na + TILE_BYTES, tid, rb);
-    }
+  };
+
+  if (DIRECT) {
+    const size_t bytesA = (size_t)(AK ? M : K) * p.lda * 2, bytesB = (size_t)(BKM ? N : K) * p.ldb * 2;
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(B), 0, (int)bytesB, 0x00020000);
+    issue_tile<AK>(ra_, p.lda, m0, kt0 * BK, smem, tid);
+    issue_tile<BKM>(rb_, p.ldb, n0, kt0 * BK, smem + TILE_BYTES, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const unsigned char* la = smem + cur * 2 * TILE_BYTES;
+      if (kt + 1 < nk) {
+        unsigned char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        issue_tile<AK>(ra_, p.lda, m0, (kt + 1) * BK, na, tid);
+        issue_tile<BKM>(rb_, p.ldb, n0, (kt + 1) * BK, na + TILE_BYTES, tid);
+      }
+      mma_tile(la, la + TILE_BYTES);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    uint4 ra[4], rb[4];
+    load_tile<AK>(A, p.lda, M, K, m0, kt0 * BK, tid, ra);
+    load_tile<BKM>(B, p.ldb, N, K, n0, kt0 * BK, tid, rb);
+    store_tile<AK>(smem, tid, ra);
+    store_tile<BKM>(smem + TILE_BYTES, tid, rb);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const unsigned char* la = smem + cur * 2 * TILE_BYTES;
+      if (kt + 1 < nk) {
+        load_tile<AK>(A, p.lda, M, K, m0, (kt + 1) * BK, tid, ra);
+        load_tile<BKM>(B, p.ldb, N, K, n0, (kt + 1) * BK, tid, rb);
+      }
+      mma_tile(la, la + TILE_BYTES);
+      if (kt + 1 < nk) {
+        unsigned char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        store_tile<AK>(na, tid, ra);
+        store_tile<BKM>(na + TILE_BYTES, tid, rb);
+      }
+      __syncthreads();
+    }
   }
 
   // ------------------------------- epilogue -------------------------------
@@ -226,10 +275,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
         v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
         v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
       }
-      if (S > 1) {                                       // split-K partial: f32 atomics into the (pre-existing) accumulator
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+      if (S > 1) {
+        if (p.workspace) {                               // split-K partial slab [slice][M][N], summed by splitk_reduce_kernel
+          float* c = reinterpret_cast<float*>(p.workspace) + ((size_t)slice * M + dst) * N + n;
+          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {                                         // no workspace: f32 atomics into the accumulator
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+          for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+        }
       } else if (p.out_fp32) {
         float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
         if (p.accumulate) {
@@ -245,17 +299,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   }
 }
 
-template <bool AK, bool BKM, bool TR>
+// C[m][n] += sum_s ws[s][m][n]   (float4 lanes; every slab element was written by exactly one block)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int S) {
+  const long n4 = N >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * n4) return;
+  const long m = i / n4, c = (i - m * n4) * 4;
+  float4 a = *reinterpret_cast<const float4*>(C + m * ldc + c);
+  const size_t slab = (size_t)M * N;
+  for (int s = 0; s < S; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + s * slab + m * N + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(C + m * ldc + c) = a;
+}
+
+template <bool AK, bool BKM, bool TR, bool DIRECT>
 int launch(const vmvm_gemm_desc& d, hipStream_t st) {
   const int nb = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * (d.splitk > 1 ? d.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AK, BKM, TR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AK, BKM, TR, DIRECT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<AK, BKM, TR>), dim3(nb), dim3(256), SMEM_BYTES, st, d);
+  hipLaunchKernelGGL((gemm_kernel<AK, BKM, TR, DIRECT>), dim3(nb), dim3(256), SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
+  if (d.splitk > 1 && d.workspace) {
+    const long n = (long)d.M * (d.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
+                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    VMVM_CHECK_LAUNCH();
+  }
   return VMVM_OK;
 }
 
@@ -293,8 +368,22 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   } else if (dd.splitk > 1 && !plain_acc) {
     return VMVM_EINVAL;
   }
-  if (d->a_kmajor && d->b_kmajor) return launch<true, true, true>(*d, st);
-  if (d->a_kmajor && !d->b_kmajor) return tr ? launch<true, false, true>(*d, st) : launch<true, false, false>(*d, st);
-  if (!d->a_kmajor && !d->b_kmajor) return tr ? launch<false, false, true>(*d, st) : launch<false, false, false>(*d, st);
-  return tr ? launch<false, true, true>(*d, st) : launch<false, true, false>(*d, st);
+  if (dd.splitk > 1 && dd.workspace) {
+    // every (slice, tile) must be written: slices whose K range is empty would leave garbage -> shrink S to the useful count
+    const int nk_all = (dd.K + BK - 1) / BK;
+    const int per = (nk_all + dd.splitk - 1) / dd.splitk;
+    dd.splitk = (nk_all + per - 1) / per;
+    const size_t need = (size_t)dd.splitk * dd.M * dd.N * sizeof(float);
+    if ((size_t)dd.workspace_bytes < need || dd.splitk < 2) dd.workspace = nullptr;     // fall back to atomics
+  }
+  // direct-to-LDS staging needs whole 64-wide K tiles for k-major operands (an out-of-extent k chunk would read the next
+  // columns, not zeros) and 32-bit byte offsets; everything else takes the register-staged path (variant 2 forces it).
+  const size_t bytesA = (size_t)(dd.a_kmajor ? dd.M : dd.K) * dd.lda * 2, bytesB = (size_t)(dd.b_kmajor ? dd.N : dd.K) * dd.ldb * 2;
+  const bool direct = dd.variant == 0 && (dd.K % BK == 0) && bytesA < 0x7fffffffull && bytesB < 0x7fffffffull;
+  if (d->a_kmajor && d->b_kmajor) return direct ? launch<true, true, true, true>(*d, st) : launch<true, true, true, false>(*d, st);
+  if (d->a_kmajor && !d->b_kmajor)
+    return direct ? launch<true, false, true, true>(*d, st) : (tr ? launch<true, false, true, false>(*d, st) : launch<true, false, false, false>(*d, st));
+  if (!d->a_kmajor && !d->b_kmajor)
+    return direct ? launch<false, false, true, true>(*d, st) : (tr ? launch<false, false, true, false>(*d, st) : launch<false, false, false, false>(*d, st));
+  return direct ? launch<false, true, true, true>(*d, st) : (tr ? launch<false, true, true, false>(*d, st) : launch<false, true, false, false>(*d, st));
 }

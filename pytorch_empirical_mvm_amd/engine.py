@@ -122,6 +122,9 @@ class VioletEngine:
         self._idx_cache = {}
         self.tape = []
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
+        if self.device.type == "cuda":
+            self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
+            K.set_workspace(self.workspace)
 
     # -------------------------------------------------------------- small helpers
     def _next_offset(self, n):

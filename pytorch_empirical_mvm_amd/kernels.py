@@ -11,6 +11,13 @@ from . import lib as L
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+_WORKSPACE = {}          # device -> caller-owned split-K scratch (set by the engine; the C ABI never allocates)
+
+
+def set_workspace(t):
+    _WORKSPACE[t.device] = t
+
+
 def _ld(t):
     assert t.stride(-1) == 1, "rows must be contiguous"
     return t.stride(0) if t.dim() > 1 else t.numel()
@@ -19,7 +26,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0):
+         variant=0, out_rows=None, splitk=0, workspace=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -49,6 +56,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
     d.variant = variant
     d.splitk = splitk
+    if workspace is None and accumulate:
+        workspace = _WORKSPACE.get(A.device)
+    d.workspace, d.workspace_bytes = L.ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
 

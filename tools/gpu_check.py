@@ -100,11 +100,12 @@ def check_gemm_epilogues():
     acc0 = acc.clone()
     K.gemm(A, B, out=acc, accumulate=True)
     rep("gemm fp32 accumulate", acc, base + acc0, tol=1e-3)
-    for sk in (1, 3, 0):
+    ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    for sk, w in ((1, None), (3, None), (0, None), (3, ws), (0, ws), (7, ws)):
         acc = torch.randn(N, K_, device=dev)
         acc0 = acc.clone()
-        K.gemm(A.t().contiguous().t().contiguous(), A, a_kmajor=False, b_kmajor=False, M=K_, N=K_, K=M, out=acc[:K_], accumulate=True, splitk=sk)
-        rep(f"gemm wgrad-shape accumulate splitk={sk}", acc[:K_], A.float().t() @ A.float() + acc0[:K_], tol=2e-3)
+        K.gemm(A.t().contiguous().t().contiguous(), A, a_kmajor=False, b_kmajor=False, M=K_, N=K_, K=M, out=acc[:K_], accumulate=True, splitk=sk, workspace=w)
+        rep(f"gemm wgrad-shape accumulate splitk={sk} ws={w is not None}", acc[:K_], A.float().t() @ A.float() + acc0[:K_], tol=2e-3)
     rep("gemm col_scale", K.gemm(A, B, bias=bias, col_scale=0.25, col_scale_n=64),
         torch.cat([(base + bias)[:, :64] * 0.25, (base + bias)[:, 64:]], 1))
     # row map: 2 clips x 392 slots -> token order, with pads
@@ -417,6 +418,8 @@ def check_misc():
 
 
 def bench_gemm():
+    global WS
+    WS = torch.empty(256 << 20, device=dev, dtype=torch.uint8)
     print("---- gemm timing (ms, TFLOP/s) vs torch.matmul (hipBLASLt ceiling)")
     for (M, N, K_) in [(8192, 8192, 8192), (69120, 3072, 768), (69120, 768, 3072), (802816, 384, 128), (50176, 2048, 512)]:
         A, B = rnd(M, K_), rnd(N, K_)
@@ -434,7 +437,8 @@ def bench_gemm():
         dy = rnd(M, N)
         gw = torch.zeros(N, K_, device=dev)
         for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False)),
-                         ("wgrad", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True))):
+                         ("wgrad", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True)),
+                         ("wgrad ws", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True, workspace=WS))):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
