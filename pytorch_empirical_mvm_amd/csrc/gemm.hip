@@ -114,6 +114,76 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int x16, i
   }
 }
 
+// ---- fused epilogue for 4 consecutive output columns (n..n+3) of row m (see include/vmvm.h for the order) ----------
+struct EpiCtx { bool has_drop; uint32_t thr; float keep_scale; int S, slice, M, N; };
+__device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[4], int m, long dst, int n, float rs) {
+  const bool has_drop = e_.has_drop; const uint32_t thr = e_.thr; const float keep_scale = e_.keep_scale;
+  const int S = e_.S, slice = e_.slice, M = e_.M, N = e_.N;
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    const float bs = p.scale_bias_only ? rs : 1.0f;   // DropPath producer form: A rows already carry the scale
+    v[0] += b.x * bs; v[1] += b.y * bs; v[2] += b.z * bs; v[3] += b.w * bs;
+  }
+  if (n < p.col_scale_n) {                            // q = (x Wq^T + bq) * scale  (video_swin.py:152)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.col_scale;
+  }
+  if (p.act == 1) {
+    if (p.C2) {
+      uint2 pre = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pre;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.act == 3 || p.act == 4) {
+    const uint2 a2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+    float u[4] = {__uint_as_float(a2.x << 16), __uint_as_float(a2.x & 0xffff0000u),
+                  __uint_as_float(a2.y << 16), __uint_as_float(a2.y & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= (p.act == 3) ? gelu_grad_f(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
+  }
+  if (p.row_scale && !p.scale_bias_only) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= rs;
+  }
+  if (has_drop) {
+    const uint64_t e4 = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
+    const uint4 bits = dropout_bits(p.seed, p.offset, e4);
+    v[0] = bits.x < thr ? 0.f : v[0] * keep_scale;
+    v[1] = bits.y < thr ? 0.f : v[1] * keep_scale;
+    v[2] = bits.z < thr ? 0.f : v[2] * keep_scale;
+    v[3] = bits.w < thr ? 0.f : v[3] * keep_scale;
+  }
+  if (p.resid) {
+    const uint2 r2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.resid) + (size_t)dst * p.ldr + n);
+    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+  }
+  if (S > 1) {
+    if (p.workspace) {                               // split-K partial slab [slice][M][N], summed by splitk_reduce_kernel
+      float* c = reinterpret_cast<float*>(p.workspace) + ((size_t)slice * M + dst) * N + n;
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {                                         // no workspace: f32 atomics into the accumulator
+      float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+    }
+  } else if (p.out_fp32) {
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+    if (p.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(c);
+      v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) =
+        make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
+
 template <bool AK, bool BKM, bool TR, bool DIRECT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -212,9 +282,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
 
   // ------------------------------- epilogue -------------------------------
   const int r = lane & 15, g = lane >> 4;
-  const bool has_drop = p.dropout_p > 0.f;
-  const uint32_t thr = dropout_threshold(p.dropout_p);
-  const float keep_scale = has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  EpiCtx ec;
+  ec.has_drop = p.dropout_p > 0.f; ec.thr = dropout_threshold(p.dropout_p);
+  ec.keep_scale = ec.has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  ec.S = S; ec.slice = slice; ec.M = M; ec.N = N;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + r;
@@ -232,69 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
       const int n = n0 + wn * 64 + j * 16 + g * 4;
       if (n >= N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        const float bs = p.scale_bias_only ? rs : 1.0f;   // DropPath producer form: A rows already carry the scale
-        v[0] += b.x * bs; v[1] += b.y * bs; v[2] += b.z * bs; v[3] += b.w * bs;
-      }
-      if (n < p.col_scale_n) {                            // q = (x Wq^T + bq) * scale  (video_swin.py:152)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.col_scale;
-      }
-      if (p.act == 1) {
-        if (p.C2) {
-          uint2 pre = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-          *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pre;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == 3 || p.act == 4) {
-        const uint2 a2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
-        float u[4] = {__uint_as_float(a2.x << 16), __uint_as_float(a2.x & 0xffff0000u),
-                      __uint_as_float(a2.y << 16), __uint_as_float(a2.y & 0xffff0000u)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= (p.act == 3) ? gelu_grad_f(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
-      }
-      if (p.row_scale && !p.scale_bias_only) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= rs;
-      }
-      if (has_drop) {
-        const uint64_t e4 = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
-        const uint4 bits = dropout_bits(p.seed, p.offset, e4);
-        v[0] = bits.x < thr ? 0.f : v[0] * keep_scale;
-        v[1] = bits.y < thr ? 0.f : v[1] * keep_scale;
-        v[2] = bits.z < thr ? 0.f : v[2] * keep_scale;
-        v[3] = bits.w < thr ? 0.f : v[3] * keep_scale;
-      }
-      if (p.resid) {
-        const uint2 r2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.resid) + (size_t)dst * p.ldr + n);
-        v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-        v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-      }
-      if (S > 1) {
-        if (p.workspace) {                               // split-K partial slab [slice][M][N], summed by splitk_reduce_kernel
-          float* c = reinterpret_cast<float*>(p.workspace) + ((size_t)slice * M + dst) * N + n;
-          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {                                         // no workspace: f32 atomics into the accumulator
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
-        }
-      } else if (p.out_fp32) {
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
-        if (p.accumulate) {
-          const float4 o = *reinterpret_cast<const float4*>(c);
-          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-        }
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) =
-            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-      }
+      epi_store(p, ec, v, m, dst, n, rs);
     }
   }
 }
@@ -334,6 +343,165 @@ int launch(const vmvm_gemm_desc& d, hipStream_t st) {
   return VMVM_OK;
 }
 
+// =====================================================================================================================
+// 256x256x64 tile, 512 threads = 8 waves (2 x 4), wave tile 128x64 = 8x4 MFMA tiles (128 accumulator VGPRs).
+// A 128^2 tile needs 64 B/clk/CU of L2->LDS traffic at MFMA peak; the 256^2 tile halves that (128 flop per staged byte),
+// which is what lifts the large fusion-encoder / Swin stage-3 GEMMs above the L2-bandwidth ceiling of the small tile.
+// Direct-to-LDS staging only (buffer_load ... lds, double buffered, one barrier per K tile), transposing reads for
+// m/n-major operands; 128 KiB LDS -> one workgroup per CU, 2 waves per SIMD.
+// =====================================================================================================================
+constexpr int GB = 256;                              // big tile edge
+constexpr int BIG_TILE_BYTES = GB * BK * 2;          // 32 KiB per operand tile
+constexpr int BIG_SMEM_BYTES = 4 * BIG_TILE_BYTES;   // 128 KiB
+
+template <bool KMAJOR>
+__device__ __forceinline__ void issue_tile_big(__amdgpu_buffer_rsrc_t rsrc, int ld, int row0, int k0, unsigned char* lds, int tid) {
+  const int wave_base = (tid & ~63);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + i * 512;                     // 2048 16-byte units per tile
+    unsigned goff;
+    if (KMAJOR) {
+      const int row = u >> 3, cs = u & 7;
+      const int c = cs ^ ((row >> 1) & 7);
+      goff = (unsigned)(((size_t)(row0 + row) * ld + k0 + c * 8) * 2);
+    } else {
+      const int krow = u >> 5, unit = u & 31;        // [64 k][256 x]: 32 units per k-row
+      const int sl = unit >> 1;
+      const int slot = (sl & ~7) | ((sl ^ swz_m(krow)) & 7);
+      goff = (unsigned)(((size_t)(k0 + krow) * ld + row0 + (slot * 2 + (unit & 1)) * 8) * 2);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds + (i * 512 + wave_base) * 16), 16, goff, 0, 0, 0);
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag_big(const unsigned char* lds, int x16, int s, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if (KMAJOR) {
+    const int row = x16 * 16 + r, kc = s * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int krow = s * 32 + g * 8 + (r >> 2), krow2 = krow + 4;
+    const int o1 = krow * 512 + (((x16 & ~7) | ((x16 ^ swz_m(krow)) & 7)) << 5) + (r & 3) * 8;
+    const int o2 = krow2 * 512 + (((x16 & ~7) | ((x16 ^ swz_m(krow2)) & 7)) << 5) + (r & 3) * 8;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const vmvm_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nbn = (N + GB - 1) / GB, nbm = (M + GB - 1) / GB;
+  const int nb = nbm * nbn;
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  const int nbt = nb * S;
+  const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+  const int q2 = nbt >> 3, rr2 = nbt & 7;
+  const int logical = (xcd < rr2 ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2) + idx;
+  const int slice = logical / nb, tile = logical - slice * nb;
+  const int tm = tile / nbn, tn = tile - tm * nbn;
+  const int m0 = tm * GB, n0 = tn * GB;
+  const u16* A = reinterpret_cast<const u16*>(p.A);
+  const u16* B = reinterpret_cast<const u16*>(p.B);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + S - 1) / S;
+  const int kt0 = slice * per;
+  const int nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+  if (kt0 >= nk) return;
+  const size_t bytesA = (size_t)(AK ? M : K) * p.lda * 2, bytesB = (size_t)(BKM ? N : K) * p.ldb * 2;
+  const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A), 0, (int)bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(B), 0, (int)bytesB, 0x00020000);
+  issue_tile_big<AK>(ra_, p.lda, m0, kt0 * BK, smem, tid);
+  issue_tile_big<BKM>(rb_, p.ldb, n0, kt0 * BK, smem + BIG_TILE_BYTES, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const unsigned char* la = smem + cur * 2 * BIG_TILE_BYTES;
+    const unsigned char* lb = la + BIG_TILE_BYTES;
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (cur ^ 1) * 2 * BIG_TILE_BYTES;
+      issue_tile_big<AK>(ra_, p.lda, m0, (kt + 1) * BK, na, tid);
+      issue_tile_big<BKM>(rb_, p.ldb, n0, (kt + 1) * BK, na + BIG_TILE_BYTES, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag_big<BKM>(lb, wn * 4 + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag_big<AK>(la, wm * 8 + i, s, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int r = lane & 15, g = lane >> 4;
+  EpiCtx ec;
+  ec.has_drop = p.dropout_p > 0.f; ec.thr = dropout_threshold(p.dropout_p);
+  ec.keep_scale = ec.has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  ec.S = S; ec.slice = slice; ec.M = M; ec.N = N;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + r;
+    bool valid = m < M;
+    long dst = m;
+    if (valid && p.row_map) {
+      const int mapped = p.row_map[m % p.map_len];
+      valid = mapped >= 0;
+      dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
+    }
+    const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + g * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (valid && n < N) epi_store(p, ec, v, m, dst, n, rs);
+    }
+  }
+}
+
+template <bool AK, bool BKM>
+int launch_big(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int nb = ((d.M + GB - 1) / GB) * ((d.N + GB - 1) / GB) * (d.splitk > 1 ? d.splitk : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_big_kernel<AK, BKM>), dim3(nb), dim3(512), BIG_SMEM_BYTES, st, d);
+  VMVM_CHECK_LAUNCH();
+  if (d.splitk > 1 && d.workspace) {
+    const long n = (long)d.M * (d.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
+                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    VMVM_CHECK_LAUNCH();
+  }
+  return VMVM_OK;
+}
+
 }  // namespace
 
 extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
@@ -356,13 +524,24 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   // ~4 workgroups per CU and combine with f32 atomics into the gradient accumulator.
   const bool plain_acc = dd.out_fp32 && dd.accumulate && !dd.bias && !dd.row_scale && !dd.act && !dd.resid && !dd.row_map &&
                          dd.dropout_p <= 0.f && dd.col_scale_n == 0;
+  // tile choice: the 256^2 kernel (direct staging only) when the problem is large enough to fill the chip with big tiles
+  const size_t bytesA = (size_t)(dd.a_kmajor ? dd.M : dd.K) * dd.lda * 2, bytesB = (size_t)(dd.b_kmajor ? dd.N : dd.K) * dd.ldb * 2;
+  const bool direct = (dd.variant == 0 || dd.variant >= 3) && (dd.K % BK == 0) && bytesA < 0x7fffffffull && bytesB < 0x7fffffffull;
+  const int nk_all_ = (dd.K + BK - 1) / BK;
+  const int tiles_big = ((dd.M + GB - 1) / GB) * ((dd.N + GB - 1) / GB);
+  const int tiles_small = ((dd.M + BM - 1) / BM) * ((dd.N + BN - 1) / BN);
+  // Measured on MI355X (profiles/): with one 8-wave workgroup per CU the 256^2 kernel only wins for long reductions
+  // (8192^3: 1074 vs 862 TF); at the step's K = 128..3072 two co-resident 128^2 workgroups hide each other's
+  // prologue/epilogue better, so auto-dispatch takes the big tile only for K >= 4096 non-split problems.
+  bool big = direct && dd.M >= 1024 && dd.N >= 1024 && dd.K >= 4096 && !(plain_acc && dd.splitk != 1) && tiles_big >= 224;
+  if (dd.variant == 3) big = false;
+  if (dd.variant == 4) big = direct;
+  const int tiles = big ? tiles_big : tiles_small;
   if (dd.splitk == 0) {
     dd.splitk = 1;
     if (plain_acc) {
-      const int tiles = ((dd.M + BM - 1) / BM) * ((dd.N + BN - 1) / BN);
-      const int nk_all = (dd.K + BK - 1) / BK;
-      int s = 1024 / tiles;
-      if (s > nk_all / 4) s = nk_all / 4;
+      int s = (big ? 512 : 1024) / tiles;
+      if (s > nk_all_ / 4) s = nk_all_ / 4;
       if (s > 1) dd.splitk = s;
     }
   } else if (dd.splitk > 1 && !plain_acc) {
@@ -378,8 +557,12 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   }
   // direct-to-LDS staging needs whole 64-wide K tiles for k-major operands (an out-of-extent k chunk would read the next
   // columns, not zeros) and 32-bit byte offsets; everything else takes the register-staged path (variant 2 forces it).
-  const size_t bytesA = (size_t)(dd.a_kmajor ? dd.M : dd.K) * dd.lda * 2, bytesB = (size_t)(dd.b_kmajor ? dd.N : dd.K) * dd.ldb * 2;
-  const bool direct = dd.variant == 0 && (dd.K % BK == 0) && bytesA < 0x7fffffffull && bytesB < 0x7fffffffull;
+  if (big) {
+    if (d->a_kmajor && d->b_kmajor) return launch_big<true, true>(*d, st);
+    if (d->a_kmajor && !d->b_kmajor) return launch_big<true, false>(*d, st);
+    if (!d->a_kmajor && !d->b_kmajor) return launch_big<false, false>(*d, st);
+    return launch_big<false, true>(*d, st);
+  }
   if (d->a_kmajor && d->b_kmajor) return direct ? launch<true, true, true, true>(*d, st) : launch<true, true, true, false>(*d, st);
   if (d->a_kmajor && !d->b_kmajor)
     return direct ? launch<true, false, true, true>(*d, st) : (tr ? launch<true, false, true, false>(*d, st) : launch<true, false, false, false>(*d, st));
