@@ -214,6 +214,10 @@ int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed,
  * Optimizer (agent.py:84-113,181-193): fused global grad-norm + clip + AdamW over a flat f32 arena,
  * also refreshing the bf16 compute copy.  seg_* describe contiguous segments (4 param groups).
  * ------------------------------------------------------------------------------------------ */
+/* batched bf16 transpose over a flat arena: for each tile entry {offset, N, K, (tile_row<<16)|tile_col} (64x64 tiles, N and K
+ * multiples of 8) writes dst[offset + k*N + n] = src[offset + n*K + k] -- keeps W^T copies of all weights so dgrad (dX = dY W) runs
+ * on the k-major fast path */
+int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream);
 int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* stream);
 typedef struct {
   float* param; const float* grad; float* m; float* v; void* param_bf16;

@@ -133,6 +133,7 @@ class Agent_Pretrain:
                 K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
                         beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
                         grad_scale=gscale)
+        S.refresh_transposed()
         self.sched_step += 1
         S.grad.zero_()
 

@@ -60,17 +60,29 @@ __device__ __forceinline__ int k_off_swz(int row, int chunk) {   // row-major [r
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// fill row-major swizzled [lp16][HD] from global rows (zero beyond L)
+// fill row-major swizzled [rows][HD] from global rows (zero beyond L) with direct-to-LDS DMA (buffer_load ... lds): no VGPR
+// round trip, all requests of a thread in flight at once.  The LDS image is lane-linear per wave instruction, so the chunk
+// swizzle is applied to the SOURCE column; rows >= L fall beyond the descriptor's num_records and read as zero.
+// Caller must `s_waitcnt vmcnt(0)` + barrier before reading.
 template <int HD>
-__device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src, int ld, int L, int lp16, int tid, int nthreads) {
+__device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src, int ld, int L, int rows, int tid, int nthreads) {
   constexpr int CPR = HD / 8;
-  for (int i = tid; i < lp16 * CPR; i += nthreads) {
-    const int row = i / CPR, ch = i - row * CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < L) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-    *reinterpret_cast<uint4*>(dst + k_off_swz<HD>(row, ch)) = v;
+  const unsigned bytes = (unsigned)(((size_t)(L - 1) * ld + HD) * 2);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src), 0, (int)bytes, 0x00020000);
+  const int total = rows * CPR;
+  const int wave_base = tid & ~63;
+  typedef __attribute__((address_space(3))) void lds_void;
+  for (int i0 = 0; i0 < total; i0 += nthreads) {
+    const int u = i0 + tid;
+    if (u < total) {
+      const int row = u / CPR, chs = u - row * CPR;
+      const int ch = (HD == 32) ? (chs ^ ((row >> 2) & 3)) : (chs ^ ((row >> 1) & 7));
+      const unsigned goff = (unsigned)(((size_t)row * ld + ch * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + (size_t)(i0 + wave_base) * 16), 16, goff, 0, 0, 0);
+    }
   }
 }
+__device__ __forceinline__ void fill_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bf16x8 load_frag_global(const u16* p, bool valid) {
   uint4 v = make_uint4(0, 0, 0, 0);
   if (valid) v = *reinterpret_cast<const uint4*>(p);
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 
   fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
   fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_wait();
   if (MODE == 0) {
     for (int i = tid; i < sm.lp32; i += NW * 64) {
       rc[i] = i < L ? p.rc[i] : 0;
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
   __syncthreads();                                  // every wave is done with the previous sequence's LDS image
   fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
   fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_wait();
   if (MODE == 0) {
     for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
   } else {
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
     __syncthreads();
     fill_rowmajor<HD>(Ksm, qkv + p.k_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
     fill_rowmajor<HD>(Vsm, qkv + p.v_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
+  fill_wait();
     for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
     __syncthreads();
     if (qt >= nt) continue;                                   // wave-uniform; barriers above are still reached by all waves
@@ -545,6 +560,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 
   fill_rowmajor<HD>(Qsm, qkv + p.q_off + h * HD, p.ld_qkv, L, sm.lp32, tid, NW * 64);
   fill_rowmajor<HD>(dOsm, dO, pb.ld_dout, L, sm.lp32, tid, NW * 64);
+  fill_wait();
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   const float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
   for (int i = tid; i < sm.lp32; i += NW * 64) {
@@ -567,93 +583,120 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
 
-  for (int kt = wave; kt < nt; kt += NW) {
-    const int key = kt * 16 + r;
-    const bool kv = key < L;
-    bf16x8 kf[HD / 32], vf[HD / 32];
+  // each wave owns TWO key tiles at a time: the Q / dO fragments (k = hd) and the transposed Q^T / dO^T fragments
+  // (k = tokens) are read from LDS once and feed both tiles -> half the LDS traffic per MFMA.
+  constexpr int KT = (HD == 32) ? 2 : 1;
+  for (int kp = wave; kp * KT < nt; kp += NW) {
+    int key[KT]; bool kv[KT];
+    bf16x8 kf[KT][HD / 32], vf[KT][HD / 32];
+    int rck[KT], regk[KT];
+    f32x4 dk[KT][HD / 16], dv[KT][HD / 16];
 #pragma unroll
-    for (int s = 0; s < HD / 32; ++s) {
-      kf[s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.k_off + h * HD + g * 8 + s * 32, kv);
-      vf[s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.v_off + h * HD + g * 8 + s * 32, kv);
+    for (int t = 0; t < KT; ++t) {
+      key[t] = (kp * KT + t) * 16 + r;
+      kv[t] = key[t] < L;
+#pragma unroll
+      for (int s = 0; s < HD / 32; ++s) {
+        kf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.k_off + h * HD + g * 8 + s * 32, kv[t]);
+        vf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.v_off + h * HD + g * 8 + s * 32, kv[t]);
+      }
+      rck[t] = (MODE == 0) ? rc[kv[t] ? key[t] : 0] : 0;
+      regk[t] = reg[kv[t] ? key[t] : 0];
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    const int rck = (MODE == 0) ? rc[kv ? key : 0] : 0;
-    const int regk = reg[kv ? key : 0];
-    f32x4 dk[HD / 16], dv[HD / 16];
-#pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     for (int c = 0; c < nt2; ++c) {
-      float pt[2][4], ds[2][4];
+      float pt[KT][2][4], ds[KT][2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * c + u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pt[u][j] = 0.f; ds[u][j] = 0.f; }
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pt[t][u][j] = 0.f; ds[t][u][j] = 0.f; }
         if (qt < nt) {
           const int qrow = qt * 16 + r;            // A-operand row owned by this lane
-          f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 s4[KT], dp4[KT];
+#pragma unroll
+          for (int t = 0; t < KT; ++t) { s4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
           for (int s = 0; s < HD / 32; ++s) {
             const bf16x8 qf = frag_hd<HD>(Qsm, qrow, s * 4 + g);
-            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[s], s4, 0, 0, 0);
             const bf16x8 dof = frag_hd<HD>(dOsm, qrow, s * 4 + g);
-            dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[s], dp4, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              s4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[t][s], s4[t], 0, 0, 0);
+              dp4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[t][s], dp4[t], 0, 0, 0);
+            }
           }
-          // lane now holds (query = qt*16 + 4g + j, key)
+          // lane now holds (query = qt*16 + 4g + j, key[t])
           const int q0 = qt * 16 + g * 4;
           const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
           const float4 d4 = *reinterpret_cast<const float4*>(delta_s + q0);
           const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
           const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
-          uint4 blk = make_uint4(0, 0, 0, 0);
-          if (has_drop) blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q0 >> 2), (uint32_t)(key >> 2));
           if (MODE == 0) {
             const int4 rq = *reinterpret_cast<const int4*>(rc + q0);
             const uchar4 gq = *reinterpret_cast<const uchar4*>(reg + q0);
             const int rqs[4] = {rq.x, rq.y, rq.z, rq.w};
             const int gqs[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float s = s4[j] + tab[rqs[j] - rck + p.rc0] + (gqs[j] != regk ? -100.f : 0.f);
-              const float pr = kv ? __expf(s - ls[j]) : 0.f;
-              pt[u][j] = pr;
-              ds[u][j] = pr * (dp4[j] * seq_scale - dls[j]);
-            }
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float sv = s4[t][j] + tab[rqs[j] - rck[t] + p.rc0] + (gqs[j] != regk[t] ? -100.f : 0.f);
+                const float pr = kv[t] ? __expf(sv - ls[j]) : 0.f;
+                pt[t][u][j] = pr;
+                ds[t][u][j] = pr * (dp4[t][j] * seq_scale - dls[j]);
+              }
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float pr = (kv && regk) ? __expf(s4[j] * p.scale - ls[j]) : 0.f;
-              float dpj = dp4[j] * seq_scale, pj = pr;
-              if (has_drop) {
-                const bool dropped = ((u4_get(blk, j) >> (8 * (key & 3))) & 0xffu) < thr8;
-                dpj = dropped ? 0.f : dpj * keep;
-                pj = dropped ? 0.f : pr * keep;
+            for (int t = 0; t < KT; ++t) {
+              uint4 blk = make_uint4(0, 0, 0, 0);
+              if (has_drop) blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q0 >> 2), (uint32_t)(key[t] >> 2));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float pr = (kv[t] && regk[t]) ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
+                float dpj = dp4[t][j] * seq_scale, pj = pr;
+                if (has_drop) {
+                  const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                  dpj = dropped ? 0.f : dpj * keep;
+                  pj = dropped ? 0.f : pr * keep;
+                }
+                pt[t][u][j] = pj;
+                ds[t][u][j] = pr * (dpj - dls[j]);
               }
-              pt[u][j] = pj;
-              ds[u][j] = pr * (dpj - dls[j]);
             }
           }
         }
       }
-      const bf16x8 pf = frag_from_f32(pt[0], pt[1]);
-      const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
+      bf16x8 pf[KT], dsf[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) { pf[t] = frag_from_f32(pt[t][0], pt[t][1]); dsf[t] = frag_from_f32(ds[t][0], ds[t][1]); }
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         const bf16x8 dof = frag_tokens<HD>(dOsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
         const bf16x8 qf = frag_tokens<HD>(Qsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf, dk[dt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[t], dv[t][dt], 0, 0, 0);
+          dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[t], dk[t][dt], 0, 0, 0);
+        }
       }
     }
-    if (kv) {
-      u16* base = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + key) * pb.ld_dqkv + h * HD + g * 4;
-      const float ksc = (MODE == 1) ? p.scale : 1.0f;
 #pragma unroll
-      for (int dt = 0; dt < HD / 16; ++dt) {
-        *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
-            make_uint2(pack_bf2(dk[dt][0] * ksc, dk[dt][1] * ksc), pack_bf2(dk[dt][2] * ksc, dk[dt][3] * ksc));
-        *reinterpret_cast<uint2*>(base + p.v_off + dt * 16) =
-            make_uint2(pack_bf2(dv[dt][0] * seq_scale, dv[dt][1] * seq_scale), pack_bf2(dv[dt][2] * seq_scale, dv[dt][3] * seq_scale));
+    for (int t = 0; t < KT; ++t) {
+      if (kv[t]) {
+        u16* base = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + key[t]) * pb.ld_dqkv + h * HD + g * 4;
+        const float ksc = (MODE == 1) ? p.scale : 1.0f;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
+              make_uint2(pack_bf2(dk[t][dt][0] * ksc, dk[t][dt][1] * ksc), pack_bf2(dk[t][dt][2] * ksc, dk[t][dt][3] * ksc));
+          *reinterpret_cast<uint2*>(base + p.v_off + dt * 16) =
+              make_uint2(pack_bf2(dv[t][dt][0] * seq_scale, dv[t][dt][1] * seq_scale), pack_bf2(dv[t][dt][2] * seq_scale, dv[t][dt][3] * seq_scale));
+        }
       }
     }
   }

@@ -342,6 +342,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
   }
 }
 
+// ---------------------------------------------------------------- batched bf16 transpose (W [N][K] -> W^T [K][N])
+// One launch transposes every 2-D weight of the arena: table[tile] = {offset, N, K, tile_row*65536 + tile_col}.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __restrict__ src, u16* __restrict__ dst, const int4* __restrict__ table) {
+  __shared__ u16 t[64][72];
+  const int4 e = table[blockIdx.x];
+  const long off = e.x; const int N = e.y, K = e.z, tr = e.w >> 16, tc = e.w & 0xffff;
+  const int r0 = tr * 64, c0 = tc * 64;
+  // load 64 rows x 64 cols (8 chunks of 8) : thread -> (row = tid/8 + 32*i, chunk = tid%8)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + row < N && c0 + ch * 8 < K) v = *reinterpret_cast<const uint4*>(src + off + (long)(r0 + row) * K + c0 + ch * 8);
+    *reinterpret_cast<uint4*>(&t[row][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;      // output row = source column
+    if (c0 + col < K && r0 + ch * 8 < N) {
+      u16 o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = t[ch * 8 + k][col];
+      *reinterpret_cast<uint4*>(dst + off + (long)(c0 + col) * N + r0 + ch * 8) =
+          make_uint4(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16), o[4] | ((uint32_t)o[5] << 16), o[6] | ((uint32_t)o[7] << 16));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- optimizer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float sh[4];
@@ -546,6 +575,13 @@ extern "C" int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx
   if (gy > 256) gy = 256;
   if (gy < 1) gy = 1;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, ST, reinterpret_cast<const u16*>(X), M, N, ldx, row_scale, rows_per_scale, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream) {
+  if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst),
+                     reinterpret_cast<const int4*>(table));
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

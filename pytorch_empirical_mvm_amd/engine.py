@@ -57,6 +57,8 @@ class ParamStore:
         self.m = torch.zeros(off, device=device, dtype=F32)
         self.v = torch.zeros(off, device=device, dtype=F32)
         self.shadow = torch.zeros(off + self.TAIL, device=device, dtype=BF16)
+        self.shadowT = torch.zeros(off + self.TAIL, device=device, dtype=BF16) if torch.device(device).type == "cuda" else None
+        self.tmap, self.ttable = {}, None
 
     def _view(self, buf, n, shape=None):
         o, c, s = self.index[n]
@@ -82,6 +84,45 @@ class ParamStore:
 
     def refresh_shadow(self):
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
+        self.refresh_transposed()
+
+    # ---- W^T copies (bf16) of every Linear weight: dgrad dX = dY W then runs as a k-major x k-major GEMM
+    def build_transpose_table(self):
+        ents = []
+        done = set()
+        names = list(self.index)
+        for n in names:
+            o, c, shp = self.index[n]
+            if n in done or not n.endswith("weight") or len(shp) < 2 or "embeddings" in n or "patch_embed" in n:
+                continue
+            N_, K_ = shp[0], int(np.prod(shp[1:]))
+            if n.endswith("attention.self.query.weight"):                      # fused [3H,H] (query,key,value adjacent)
+                kn, vn = n.replace("query", "key"), n.replace("query", "value")
+                if self.index[kn][0] == o + c and self.index[vn][0] == o + 2 * c:
+                    N_ *= 3
+                    done.update((kn, vn))
+            if N_ % 8 or K_ % 8 or N_ < 8:
+                continue
+            self.tmap[n] = (o, N_, K_)
+            for tr in range(-(-N_ // 64)):
+                for tc in range(-(-K_ // 64)):
+                    ents.append((o, N_, K_, (tr << 16) | tc))
+        self.ttable = torch.tensor(ents, dtype=torch.int32, device=self.device).contiguous() if ents else None
+
+    def refresh_transposed(self):
+        if self.device.type != "cuda":
+            return
+        if self.ttable is None and not self.tmap:
+            self.build_transpose_table()
+        if self.ttable is not None:
+            K.transpose_batched(self.shadow, self.shadowT, self.ttable)
+
+    def bt(self, n):
+        """W^T view [K,N] (or None when the weight has no transposed copy)."""
+        if n not in self.tmap:
+            return None
+        o, N_, K_ = self.tmap[n]
+        return self.shadowT[o:o + N_ * K_].view(K_, N_)
 
     def load_state(self, sd):
         for n, (o, c, s) in self.index.items():
@@ -138,7 +179,7 @@ class VioletEngine:
         return self._idx_cache[key]
 
     def _linear_bwd(self, dy, x, wname, bname, *, w=None, gw=None, gb=None, M=None, row_scale=None, rows_per_scale=0,
-                    need_dx=True, dx_kw=None, wN=None):
+                    need_dx=True, dx_kw=None, wN=None, wT=None):
         """dW += dy^T x ; db += colsum(dy) ; dx = dy W   (all on the MFMA GEMM, no transposed copies)."""
         S = self.store
         w = S.b(wname) if w is None else w
@@ -151,6 +192,9 @@ class VioletEngine:
         K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True)
         if not need_dx:
             return None
+        wt = S.bt(wname) if (wname is not None and wT is None) else wT
+        if wt is not None and wt.shape[1] == N:
+            return K.gemm(dy, wt, b_kmajor=True, M=M or dy.shape[0], N=wt.shape[0], K=N, **(dx_kw or {}))
         return K.gemm(dy, w2, b_kmajor=False, M=M or dy.shape[0], N=w2.shape[1], K=N, **(dx_kw or {}))
 
     # -------------------------------------------------------------- Video-Swin
@@ -366,7 +410,7 @@ class VioletEngine:
             dam = da if dam is None else dam
             dctx = self._linear_bwd(dam, ctx, pre + "attention.output.dense.weight", pre + "attention.output.dense.bias")
             dqkv = K.attention_bwd(dctx, qkv, ctx, lse, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), **akw)
-            dx = self._linear_bwd(dqkv, x, None, None, w=Wqkv, gw=Gqkv, gb=gbqkv, dx_kw=dict(resid=da))
+            dx = self._linear_bwd(dqkv, x, None, None, w=Wqkv, gw=Gqkv, gb=gbqkv, dx_kw=dict(resid=da), wT=S.bt(qn[0]))
             _acc(xv, dx)
         self.tape.append(bwd)
         return out
@@ -474,7 +518,7 @@ class VioletEngine:
         # heads -> gradients of the two encoder outputs
         dcat = torch.empty((B * T * hw + B * X, Hd), device=dev, dtype=BF16)       # [pixel rows ; mlm rows]
         self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
-                         dx_kw=dict(out=dcat[:B * T * hw]))
+                         dx_kw=dict(out=dcat[:B * T * hw]), wT=S.bt("decoder_pixel.0.weight"))
         K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
         K.gemm(dlog, tn, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
         dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)

@@ -258,6 +258,10 @@ def dropout(x, p, seed, offset):
     return y
 
 
+def transpose_batched(src, dst, table):
+    L.check(L.load().vmvm_transpose_batched_bf16(src.data_ptr(), dst.data_ptr(), table.data_ptr(), table.shape[0], L.stream()), "transpose_batched")
+
+
 def sumsq(g, out):
     L.check(L.load().vmvm_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.stream()), "sumsq")
     return out
