@@ -114,6 +114,20 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int x16, i
   }
 }
 
+// Tile rasterisation inside one XCD's run of logical ids: walk GM consecutive M-panels for each N-tile before moving to the
+// next N-tile, so the ~32-64 tiles resident on an XCD at any time share GM activation panels and (32..64)/GM weight tiles --
+// a working set that fits the 4 MiB L2 (PMC before: the fc1 GEMM fetched 1.17 GB per launch, almost all of it the 4.7 MB
+// weight matrix re-streamed through L2 once per M-panel).
+__device__ __forceinline__ void raster(int tile, int nbm, int nbn, int GM, int& tm, int& tn) {
+  const int per_group = GM * nbn;
+  const int grp = tile / per_group;
+  const int first_m = grp * GM;
+  const int gsize = (nbm - first_m < GM) ? (nbm - first_m) : GM;
+  const int in = tile - grp * per_group;
+  tm = first_m + in % gsize;
+  tn = in / gsize;
+}
+
 // ---- fused epilogue for 4 consecutive output columns (n..n+3) of row m (see include/vmvm.h for the order) ----------
 struct EpiCtx { bool has_drop; uint32_t thr; float keep_scale; int S, slice, M, N; };
 __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[4], int m, long dst, int n, float rs) {
@@ -201,7 +215,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   const int q2 = nbt >> 3, rr2 = nbt & 7;
   const int logical = (xcd < rr2 ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2) + idx;
   const int slice = logical / nb, tile = logical - slice * nb;
-  const int tm = tile / nbn, tn = tile - tm * nbn;
+  int tm, tn;
+  raster(tile, nbm, nbn, 8, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   (void)q; (void)rr;
 
@@ -409,7 +424,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const vmvm_gemm_desc p
   const int q2 = nbt >> 3, rr2 = nbt & 7;
   const int logical = (xcd < rr2 ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2) + idx;
   const int slice = logical / nb, tile = logical - slice * nb;
-  const int tm = tile / nbn, tn = tile - tm * nbn;
+  int tm, tn;
+  raster(tile, nbm, nbn, 4, tm, tn);
   const int m0 = tm * GB, n0 = tn * GB;
   const u16* A = reinterpret_cast<const u16*>(p.A);
   const u16* B = reinterpret_cast<const u16*>(p.B);
@@ -502,6 +518,151 @@ int launch_big(const vmvm_gemm_desc& d, hipStream_t st) {
   return VMVM_OK;
 }
 
+// =====================================================================================================================
+// 256x128x64 tile, 512 threads = 8 waves (4 x 2, wave tile 64x64), THREE LDS stages (3 x 48 KiB = 144 KiB, one workgroup
+// per CU) with counted vmcnt: the DMA loads of two K tiles stay in flight across the (raw) barrier while a third is
+// multiplied.  The 2-stage kernels above are latency bound (PMC: 44% of wave cycles in s_waitcnt/barrier, MFMA 25-33%
+// busy, L2 30% busy): one tile of prefetch cannot cover the L2/HBM latency of the next.  One barrier per K tile.
+// =====================================================================================================================
+constexpr int P3_BM = 256, P3_BN = 128;
+constexpr int P3_A_BYTES = P3_BM * BK * 2, P3_B_BYTES = P3_BN * BK * 2;      // 32 KiB + 16 KiB
+constexpr int P3_STAGE = P3_A_BYTES + P3_B_BYTES;
+constexpr int P3_SMEM = 3 * P3_STAGE;
+
+template <bool KMAJOR>
+__device__ __forceinline__ void issue_b128_512(__amdgpu_buffer_rsrc_t rsrc, int ld, int row0, int k0, unsigned char* lds, int tid) {
+  const int wave_base = (tid & ~63);                  // [128 rows][64 k] or [64 k][128 x] : 1024 units, 2 per thread
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * 512;
+    unsigned goff;
+    if (KMAJOR) {
+      const int row = u >> 3, cs = u & 7;
+      const int c = cs ^ ((row >> 1) & 7);
+      goff = (unsigned)(((size_t)(row0 + row) * ld + k0 + c * 8) * 2);
+    } else {
+      const int krow = u >> 4, unit = u & 15;
+      const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
+      goff = (unsigned)(((size_t)(k0 + krow) * ld + row0 + (slot * 2 + (unit & 1)) * 8) * 2);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds + (i * 512 + wave_base) * 16), 16, goff, 0, 0, 0);
+  }
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const vmvm_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nbn = (N + P3_BN - 1) / P3_BN, nbm = (M + P3_BM - 1) / P3_BM;
+  const int nb = nbm * nbn;
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  const int nbt = nb * S;
+  const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+  const int q2 = nbt >> 3, rr2 = nbt & 7;
+  const int logical = (xcd < rr2 ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2) + idx;
+  const int slice = logical / nb, tile = logical - slice * nb;
+  int tm, tn;
+  raster(tile, nbm, nbn, 4, tm, tn);
+  const int m0 = tm * P3_BM, n0 = tn * P3_BN;
+  const u16* A = reinterpret_cast<const u16*>(p.A);
+  const u16* B = reinterpret_cast<const u16*>(p.B);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + S - 1) / S;
+  const int kt0 = slice * per;
+  const int nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+  if (kt0 >= nk) return;
+  const int ntile = nk - kt0;
+  const size_t bytesA = (size_t)(AK ? M : K) * p.lda * 2, bytesB = (size_t)(BKM ? N : K) * p.ldb * 2;
+  const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A), 0, (int)bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(B), 0, (int)bytesB, 0x00020000);
+
+  auto issue = [&](int t) {                            // 6 DMA instructions per thread per tile
+    unsigned char* st = smem + (t % 3) * P3_STAGE;
+    issue_tile_big<AK>(ra_, p.lda, m0, (kt0 + t) * BK, st, tid);
+    issue_b128_512<BKM>(rb_, p.ldb, n0, (kt0 + t) * BK, st + P3_A_BYTES, tid);
+  };
+  issue(0);
+  if (ntile > 1) issue(1);
+  for (int t = 0; t < ntile; ++t) {
+    // tile t landed (this thread's share): at most the 6 loads of tile t+1 may still be outstanding
+    if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // every wave's share landed AND every wave finished tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 2 < ntile) issue(t + 2);                  // overwrites the stage read in iteration t-1
+    const unsigned char* la = smem + (t % 3) * P3_STAGE;
+    const unsigned char* lb = la + P3_A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag_big<AK>(la, wm * 4 + i, s, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKM, true>(lb, wn * 4 + j, s, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int r = lane & 15, g = lane >> 4;
+  EpiCtx ec;
+  ec.has_drop = p.dropout_p > 0.f; ec.thr = dropout_threshold(p.dropout_p);
+  ec.keep_scale = ec.has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  ec.S = S; ec.slice = slice; ec.M = M; ec.N = N;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r;
+    bool valid = m < M;
+    long dst = m;
+    if (valid && p.row_map) {
+      const int mapped = p.row_map[m % p.map_len];
+      valid = mapped >= 0;
+      dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
+    }
+    const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + g * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (valid && n < N) epi_store(p, ec, v, m, dst, n, rs);
+    }
+  }
+}
+
+inline bool tiles_p3_ok(int M, int N) { return ((M + P3_BM - 1) / P3_BM) * ((N + P3_BN - 1) / P3_BN) >= 224; }
+
+template <bool AK, bool BKM>
+int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int nb = ((d.M + P3_BM - 1) / P3_BM) * ((d.N + P3_BN - 1) / P3_BN) * (d.splitk > 1 ? d.splitk : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p3_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_p3_kernel<AK, BKM>), dim3(nb), dim3(512), P3_SMEM, st, d);
+  VMVM_CHECK_LAUNCH();
+  if (d.splitk > 1 && d.workspace) {
+    const long n = (long)d.M * (d.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
+                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    VMVM_CHECK_LAUNCH();
+  }
+  return VMVM_OK;
+}
+
 }  // namespace
 
 extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
@@ -536,11 +697,15 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   bool big = direct && dd.M >= 1024 && dd.N >= 1024 && dd.K >= 4096 && !(plain_acc && dd.splitk != 1) && tiles_big >= 224;
   if (dd.variant == 3) big = false;
   if (dd.variant == 4) big = direct;
-  const int tiles = big ? tiles_big : tiles_small;
+  const int tiles_p3 = ((dd.M + P3_BM - 1) / P3_BM) * ((dd.N + P3_BN - 1) / P3_BN);
+  // 3-stage 256x128 kernel: measured +3..6% on k-major x k-major problems with M >= 1024 (forward and W^T dgrad GEMMs);
+  // m/n-major operands stay on the 2-stage 128^2 kernel (faster there).
+  bool p3 = direct && !big && (dd.variant == 5 || (dd.variant == 0 && dd.a_kmajor && dd.b_kmajor && dd.M >= 1024 && tiles_p3_ok(dd.M, dd.N)));
+  const int tiles = big ? tiles_big : (p3 ? tiles_p3 : tiles_small);
   if (dd.splitk == 0) {
     dd.splitk = 1;
     if (plain_acc) {
-      int s = (big ? 512 : 1024) / tiles;
+      int s = (big ? 512 : (p3 ? 512 : 1024)) / tiles;
       if (s > nk_all_ / 4) s = nk_all_ / 4;
       if (s > 1) dd.splitk = s;
     }
@@ -557,6 +722,12 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   }
   // direct-to-LDS staging needs whole 64-wide K tiles for k-major operands (an out-of-extent k chunk would read the next
   // columns, not zeros) and 32-bit byte offsets; everything else takes the register-staged path (variant 2 forces it).
+  if (p3) {
+    if (d->a_kmajor && d->b_kmajor) return launch_p3<true, true>(*d, st);
+    if (d->a_kmajor && !d->b_kmajor) return launch_p3<true, false>(*d, st);
+    if (!d->a_kmajor && !d->b_kmajor) return launch_p3<false, false>(*d, st);
+    return launch_p3<false, true>(*d, st);
+  }
   if (big) {
     if (d->a_kmajor && d->b_kmajor) return launch_big<true, true>(*d, st);
     if (d->a_kmajor && !d->b_kmajor) return launch_big<true, false>(*d, st);

@@ -73,42 +73,46 @@ def check_gemm_layouts():
                 rep(f"gemm TT(a m-major) v{var} {M}x{N}x{K_}", K.gemm(At, B, a_kmajor=False, variant=var), ref)
 
 
-def check_gemm_big():
-    """256^2-tile kernel (variant 4) on every layout + its epilogue paths + split-K."""
+def check_gemm_big(variant=4, tag="big"):
+    """256^2-tile kernel (variant 4) / 3-stage 256x128 kernel (variant 5) on every layout + epilogue paths + split-K."""
     for (M, N, K_) in [(392 * 3, 768, 128), (1000, 1024, 768), (4096, 512, 2048), (777 * 8, 256, 64)]:
         A, B = rnd(M, K_), rnd(N, K_)
         ref = A.float() @ B.float().t()
         At, Bt = A.t().contiguous(), B.t().contiguous()
-        rep(f"big NT {M}x{N}x{K_}", K.gemm(A, B, variant=4), ref)
-        rep(f"big NN {M}x{N}x{K_}", K.gemm(A, Bt, b_kmajor=False, variant=4), ref)
-        rep(f"big TN {M}x{N}x{K_}", K.gemm(At, Bt, a_kmajor=False, b_kmajor=False, variant=4), ref)
-        rep(f"big TT {M}x{N}x{K_}", K.gemm(At, B, a_kmajor=False, variant=4), ref)
+        rep(f"{tag} NT {M}x{N}x{K_}", K.gemm(A, B, variant=variant), ref)
+        rep(f"{tag} NN {M}x{N}x{K_}", K.gemm(A, Bt, b_kmajor=False, variant=variant), ref)
+        rep(f"{tag} TN {M}x{N}x{K_}", K.gemm(At, Bt, a_kmajor=False, b_kmajor=False, variant=variant), ref)
+        rep(f"{tag} TT {M}x{N}x{K_}", K.gemm(At, B, a_kmajor=False, variant=variant), ref)
     M, N, K_ = 2 * 392 * 2, 512, 256
     A, B = rnd(M, K_), rnd(N, K_, scale=0.1)
     bias = torch.randn(N, device=dev)
     base = A.float() @ B.float().t()
     pre = torch.empty(M, N, device=dev, dtype=BF)
-    rep("big gelu", K.gemm(A, B, bias=bias, act=1, out_preact=pre, variant=4), torch.nn.functional.gelu(base + bias))
-    rep("big gelu preact", pre, base + bias)
+    rep(tag + " gelu", K.gemm(A, B, bias=bias, act=1, out_preact=pre, variant=variant), torch.nn.functional.gelu(base + bias))
+    rep(tag + " gelu preact", pre, base + bias)
     perm = torch.randperm(392, device=dev).int()
     perm[::50] = -1
     resid = rnd(4 * 392, N)
     out = torch.zeros(4 * 392, N, device=dev, dtype=BF)
     rs = torch.rand(4, device=dev) + 0.5
-    K.gemm(A, B, bias=bias, resid=resid, row_map=perm, map_len=392, map_stride=392, out=out, row_scale=rs, rows_per_scale=392, scale_bias_only=True, variant=4)
+    K.gemm(A, B, bias=bias, resid=resid, row_map=perm, map_len=392, map_stride=392, out=out, row_scale=rs, rows_per_scale=392, scale_bias_only=True, variant=variant)
     ref = torch.zeros(4 * 392, N, device=dev)
     pl = perm.long()
     for b in range(4):
         ok = pl >= 0
         ref[b * 392 + pl[ok]] = (base + bias * rs[b])[b * 392:(b + 1) * 392][ok] + resid.float()[b * 392 + pl[ok]]
-    rep("big row_map + resid + scaled bias", out, ref)
+    rep(tag + " row_map + resid + scaled bias", out, ref)
     ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
     for sk, w in ((0, ws), (5, ws), (3, None)):
         acc = torch.randn(N, K_, device=dev)
         acc0 = acc.clone()
         dy = rnd(M, N)
-        K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=acc, accumulate=True, splitk=sk, workspace=w, variant=4)
-        rep(f"big wgrad splitk={sk} ws={w is not None}", acc, dy.float().t() @ A.float() + acc0, tol=2e-3)
+        K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=acc, accumulate=True, splitk=sk, workspace=w, variant=variant)
+        rep(f"{tag} wgrad splitk={sk} ws={w is not None}", acc, dy.float().t() @ A.float() + acc0, tol=2e-3)
+
+
+def check_gemm_p3():
+    check_gemm_big(5, "p3")
 
 
 def check_gemm_epilogues():
@@ -461,7 +465,7 @@ def bench_gemm():
     print("---- gemm timing (ms, TFLOP/s) vs torch.matmul (hipBLASLt ceiling)")
     for (M, N, K_) in [(8192, 8192, 8192), (69120, 3072, 768), (69120, 768, 3072), (802816, 384, 128), (50176, 2048, 512)]:
         A, B = rnd(M, K_), rnd(N, K_)
-        for name, fn in (("vmvm", lambda: K.gemm(A, B)), ("v128", lambda: K.gemm(A, B, variant=3)), ("v256", lambda: K.gemm(A, B, variant=4)), ("torch", lambda: A @ B.t())):
+        for name, fn in (("vmvm", lambda: K.gemm(A, B)), ("v128", lambda: K.gemm(A, B, variant=3)), ("v256", lambda: K.gemm(A, B, variant=4)), ("p3", lambda: K.gemm(A, B, variant=5)), ("torch", lambda: A @ B.t())):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -474,7 +478,8 @@ def bench_gemm():
         At = A.t().contiguous()
         dy = rnd(M, N)
         gw = torch.zeros(N, K_, device=dev)
-        for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False)),
+        for name, fn in (("vmvm NN", lambda: K.gemm(A, Bt, b_kmajor=False)), ("p3 NN", lambda: K.gemm(A, Bt, b_kmajor=False, variant=5)), ("vmvm TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False)), ("p3 TN", lambda: K.gemm(At, Bt, a_kmajor=False, b_kmajor=False, variant=5)),
+                         ("p3 wgrad ws", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True, workspace=WS, variant=5)),
                          ("wgrad", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True)),
                          ("wgrad ws", lambda: K.gemm(dy, A, a_kmajor=False, b_kmajor=False, M=N, N=K_, K=M, out=gw, accumulate=True, workspace=WS))):
             fn(); torch.cuda.synchronize()
@@ -537,7 +542,7 @@ def bench_attn():
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["probe", "gemm", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
-    table = dict(probe=check_probe, gemm=check_gemm_layouts, big=check_gemm_big, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
+    table = dict(probe=check_probe, gemm=check_gemm_layouts, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
                  attnw=check_attn_window, attnb=check_attn_bert, misc=check_misc)
     for w in which:
         if w == "bench":
