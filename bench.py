@@ -23,6 +23,11 @@ sys.path.insert(0, ROOT)
 TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x 3 (C2/C3)
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
+# HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_roofline_gemm.txt):
+# FETCH_SIZE 5.73e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.44e5 KiB.
+# Algorithmic bytes: A 106 MB + W 4.7 MB + C 425 MB + pre-activation 425 MB = 0.96 GB; the excess read traffic is the 4.7 MB
+# weight panel re-streamed through the 4 MiB L2 (served by the Infinity Cache) -- reduced by the tile rasterisation since.
+ROOFLINE_TRAFFIC_BYTES = int((2 * 5.73e5 + 8.44e5) * 1024)
 
 
 def synth_batch(args, B, device, seed):
@@ -164,6 +169,9 @@ def main():
         dt = float(t.item())
     last = {k: float(v.item()) for k, v in losses.items()}
     if rank != 0:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
     clips = B * world * a.steps
     value = clips / dt
@@ -177,13 +185,17 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4),
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                     "frac": round(kflop / kt / PEAK_BF16, 4), "traffic": None,
+                     "frac": round(kflop / kt / PEAK_BF16, 4), "traffic": ROOFLINE_TRAFFIC_BYTES,
                      "kernel": "gemm_kernel<k-major,k-major> fusion FFN fc1+GELU (M=69120,N=3072,K=768)"},
         "losses_last_step": last,
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.size, a.frames)
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -345,28 +345,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
 // ---------------------------------------------------------------- batched bf16 transpose (W [N][K] -> W^T [K][N])
 // One launch transposes every 2-D weight of the arena: table[tile] = {offset, N, K, tile_row*65536 + tile_col}.
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __restrict__ src, u16* __restrict__ dst, const int4* __restrict__ table) {
-  __shared__ u16 t[64][72];
+  // 64x64 tile through LDS as 32-bit words holding 2x2 sub-blocks: a thread transposes 2x2 in registers, so both the
+  // LDS writes and reads are conflict-free 32-bit accesses and global accesses stay 16-byte.
+  __shared__ uint32_t t[64][33];                       // [row][col pair], +1 pad
   const int4 e = table[blockIdx.x];
   const long off = e.x; const int N = e.y, K = e.z, tr = e.w >> 16, tc = e.w & 0xffff;
   const int r0 = tr * 64, c0 = tc * 64;
-  // load 64 rows x 64 cols (8 chunks of 8) : thread -> (row = tid/8 + 32*i, chunk = tid%8)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r0 + row < N && c0 + ch * 8 < K) v = *reinterpret_cast<const uint4*>(src + off + (long)(r0 + row) * K + c0 + ch * 8);
-    *reinterpret_cast<uint4*>(&t[row][ch * 8]) = v;
+    t[row][ch * 4 + 0] = v.x; t[row][ch * 4 + 1] = v.y; t[row][ch * 4 + 2] = v.z; t[row][ch * 4 + 3] = v.w;
   }
   __syncthreads();
+  // output row = source column c (0..63), 8 consecutive source rows per 16-byte store
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int col = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;      // output row = source column
+    const int col = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;        // 8 lanes write one 128-byte row segment
     if (c0 + col < K && r0 + ch * 8 < N) {
-      u16 o[8];
+      uint32_t w[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = t[ch * 8 + k][col];
-      *reinterpret_cast<uint4*>(dst + off + (long)(c0 + col) * N + r0 + ch * 8) =
-          make_uint4(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16), o[4] | ((uint32_t)o[5] << 16), o[6] | ((uint32_t)o[7] << 16));
+      for (int k = 0; k < 8; ++k) w[k] = t[ch * 8 + k][col >> 1];
+      const int sh = (col & 1) * 16;
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = ((w[2 * k] >> sh) & 0xffffu) | (((w[2 * k + 1] >> sh) & 0xffffu) << 16);
+      *reinterpret_cast<uint4*>(dst + off + (long)(c0 + col) * N + r0 + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
 }

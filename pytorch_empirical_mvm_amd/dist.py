@@ -16,7 +16,7 @@ CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 per collective
 def init_from_env(backend=None):
     """utils/dist.py:20-75 : env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world < 2:
+    if world < 2 and not os.environ.get("VMVM_FORCE_DIST"):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
@@ -29,7 +29,8 @@ def init_from_env(backend=None):
 
 
 def is_initialized():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # VMVM_FORCE_DIST=1 keeps the collective path active at world size 1 (exercises RCCL + the side stream on one GPU)
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("VMVM_FORCE_DIST")))
 
 
 def world_size():

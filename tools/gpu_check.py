@@ -440,6 +440,17 @@ def check_misc():
     rs = torch.rand(5, device=dev)
     K.colsum(Xc, o, rs, 1000)
     rep("colsum row-scaled", o, (Xc.float() * rs.repeat_interleave(1000)[:, None]).sum(0), tol=1e-3)
+    # batched transpose
+    src = rnd(4096 + 200 * 136 + 64)
+    dstT = torch.zeros_like(src)
+    ents = []
+    for (o, N_, K_) in ((0, 64, 64), (4096, 200, 136)):
+        for tr in range(-(-N_ // 64)):
+            for tc in range(-(-K_ // 64)):
+                ents.append((o, N_, K_, (tr << 16) | tc))
+    K.transpose_batched(src, dstT, torch.tensor(ents, dtype=torch.int32, device=dev))
+    rep("transpose_batched 64x64", dstT[:4096].view(64, 64), src[:4096].view(64, 64).t(), tol=0)
+    rep("transpose_batched 200x136", dstT[4096:4096 + 200 * 136].view(136, 200), src[4096:4096 + 200 * 136].view(200, 136).t(), tol=0)
     # optimizer
     n = 100003
     p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 3
