@@ -663,6 +663,141 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
   return VMVM_OK;
 }
 
+// =====================================================================================================================
+// Persistent 128x128x64 kernel (direct staging): 2 workgroups per CU walk the (tile, K-slice) list of their XCD in order and
+// issue the DMA loads of the NEXT tile's first K tile before the epilogue of the current one.  Short-K problems (Swin
+// stage 1/2: K = 128..512, i.e. 2..8 K tiles) are otherwise dominated by the load latency of the prologue and by store
+// phases during which nothing is in flight (measured 1.8-2.2 TB/s on HBM-bound shapes = half of what the copy rate allows).
+// =====================================================================================================================
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+  const int nb = nbm * nbn;
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  const int nbt = nb * S;
+  const int nk_all = (K + BK - 1) / BK;
+  const int per = (nk_all + S - 1) / S;
+  // this XCD's contiguous run of logical work items, shared round-robin by its resident workgroups
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;       // gridDim.x is a multiple of 8
+  const int q2 = nbt >> 3, rr2 = nbt & 7;
+  const int x_start = (xcd < rr2) ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2;
+  const int x_cnt = q2 + (xcd < rr2 ? 1 : 0);
+  const u16* A = reinterpret_cast<const u16*>(p.A);
+  const u16* B = reinterpret_cast<const u16*>(p.B);
+  const size_t bytesA = (size_t)(AK ? M : K) * p.lda * 2, bytesB = (size_t)(BKM ? N : K) * p.ldb * 2;
+  const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A), 0, (int)bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(B), 0, (int)bytesB, 0x00020000);
+  const int r = lane & 15, g = lane >> 4;
+  EpiCtx ec;
+  ec.has_drop = p.dropout_p > 0.f; ec.thr = dropout_threshold(p.dropout_p);
+  ec.keep_scale = ec.has_drop ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  ec.S = S; ec.M = M; ec.N = N;
+
+  auto decode = [&](int w, int& slice, int& m0, int& n0, int& kt0, int& nk) {
+    const int logical = x_start + w;
+    slice = logical / nb;
+    int tm, tn;
+    raster(logical - slice * nb, nbm, nbn, 8, tm, tn);
+    m0 = tm * BM; n0 = tn * BN;
+    kt0 = slice * per;
+    nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+  };
+  auto issue = [&](int m0, int n0, int kt, int buf) {
+    unsigned char* st = smem + buf * 2 * TILE_BYTES;
+    issue_tile<AK>(ra_, p.lda, m0, kt * BK, st, tid);
+    issue_tile<BKM>(rb_, p.ldb, n0, kt * BK, st + TILE_BYTES, tid);
+  };
+
+  int w = li;
+  if (w >= x_cnt) return;
+  int slice, m0, n0, kt0, nk;
+  decode(w, slice, m0, n0, kt0, nk);
+  unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
+  issue(m0, n0, kt0, it & 1);
+  while (true) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wn_ = w + per_xcd;
+    const bool more = wn_ < x_cnt;
+    int nslice = 0, nm0 = 0, nn0 = 0, nkt0 = 0, nnk = 0;
+    if (more) decode(wn_, nslice, nm0, nn0, nkt0, nnk);
+    for (int kt = kt0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
+      const int cur = it & 1;
+      if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
+      else if (more) issue(nm0, nn0, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
+      const unsigned char* la = smem + cur * 2 * TILE_BYTES;
+      const unsigned char* lb = la + TILE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK, true>(la, wm * 4 + i, s, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKM, true>(lb, wn * 4 + j, s, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      ++it;
+    }
+    ec.slice = slice;
+    // (An LDS-staged, 16-byte-per-lane coalesced epilogue was measured here: correct but 1.4-1.7x SLOWER on every shape --
+    //  two extra barriers and an LDS round trip per tile cost more than the 32-byte store fragments; kept direct.)
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + r;
+      bool valid = m < M;
+      long dst = m;
+      if (valid && p.row_map) {
+        const int mapped = p.row_map[m % p.map_len];
+        valid = mapped >= 0;
+        dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
+      }
+      const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+#pragma clang loop unroll(full)
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + g * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (valid && n < N) epi_store(p, ec, v, m, dst, n, rs);
+      }
+    }
+    if (!more) break;
+    w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
+  }
+}
+
+template <bool AK, bool BKM>
+int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * (d.splitk > 1 ? d.splitk : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_done = true;
+  }
+  int grid = 512;                                       // 2 workgroups per CU (64 KiB LDS each), multiple of 8
+  if (items < grid) grid = ((items + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  VMVM_CHECK_LAUNCH();
+  if (d.splitk > 1 && d.workspace) {
+    const long n = (long)d.M * (d.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
+                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    VMVM_CHECK_LAUNCH();
+  }
+  return VMVM_OK;
+}
+
 }  // namespace
 
 extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
@@ -722,6 +857,13 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   }
   // direct-to-LDS staging needs whole 64-wide K tiles for k-major operands (an out-of-extent k chunk would read the next
   // columns, not zeros) and 32-bit byte offsets; everything else takes the register-staged path (variant 2 forces it).
+  const bool pers = direct && !big && !p3 && (dd.variant == 6 || dd.variant == 0);
+  if (pers) {
+    if (d->a_kmajor && d->b_kmajor) return launch_pers<true, true>(*d, st);
+    if (d->a_kmajor && !d->b_kmajor) return launch_pers<true, false>(*d, st);
+    if (!d->a_kmajor && !d->b_kmajor) return launch_pers<false, false>(*d, st);
+    return launch_pers<false, true>(*d, st);
+  }
   if (p3) {
     if (d->a_kmajor && d->b_kmajor) return launch_p3<true, true>(*d, st);
     if (d->a_kmajor && !d->b_kmajor) return launch_p3<true, false>(*d, st);
