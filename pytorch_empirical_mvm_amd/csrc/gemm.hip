@@ -61,7 +61,12 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const ui
 // ---- direct global -> LDS staging (buffer_load_dwordx4 ... lds): no VGPR round trip, no ds_write.  The LDS image is
 // lane-linear per wave instruction (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // offset (same involution as the read side).  Out-of-range rows fall beyond num_records and read as zero.
-template <bool KMAJOR>
+// k-major chunk swizzle: rows of one fragment read must map to distinct 16-byte slots.  Plain fragments read 16 consecutive
+// rows (swizzle by (row>>1)&7); the N-permuted B fragments read rows {8a + 4hf + b} (swizzle by b/2 | a<<1).
+template <bool PERM>
+__device__ __forceinline__ int kswz(int row) { return PERM ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : ((row >> 1) & 7); }
+
+template <bool KMAJOR, bool PERM = false>
 __device__ __forceinline__ void issue_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, int row0, int k0, unsigned char* lds, int tid) {
   const int wave_base = (tid & ~63);
 #pragma unroll
@@ -70,7 +75,7 @@ __device__ __forceinline__ void issue_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, 
     unsigned goff;
     if (KMAJOR) {
       const int row = u >> 3, cs = u & 7;
-      const int c = cs ^ ((row >> 1) & 7);
+      const int c = cs ^ kswz<PERM>(row);
       goff = (unsigned)(((size_t)(row0 + row) * ld + k0 + c * 8) * 2);
     } else {
       const int krow = u >> 4, unit = u & 15;
@@ -195,6 +200,104 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
   } else {
     *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) =
         make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
+
+// ---- 8-wide epilogue: the persistent kernel permutes the N index inside each 32-column block (operand rows / transposing-
+// read pieces are free to permute) so that a lane's accumulators of an MFMA tile PAIR are 8 CONSECUTIVE output columns:
+// one 16-byte bf16 store (two for f32) instead of two 8-byte ones, and 16/32-byte bias / residual / aux loads.  The bf16
+// epilogue was store-ISSUE bound: f32 output (2x the bytes, same instruction count) cost only +15% on HBM-bound shapes.
+__device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid) {
+  if (nvalid < 8) {                                      // N % 8 == 4 edge: fall back to the 4-wide path
+    float a[4] = {v[0], v[1], v[2], v[3]};
+    epi_store(p, e_, a, m, dst, n, rs);
+    return;
+  }
+  if (p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    const float bs = p.scale_bias_only ? rs : 1.0f;
+    v[0] += b0.x * bs; v[1] += b0.y * bs; v[2] += b0.z * bs; v[3] += b0.w * bs;
+    v[4] += b1.x * bs; v[5] += b1.y * bs; v[6] += b1.z * bs; v[7] += b1.w * bs;
+  }
+  if (n < p.col_scale_n) {                               // col_scale_n is a multiple of 8 for every caller (C of qkv)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
+  }
+  if (p.act == 1) {
+    if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack_bf8(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.act == 3 || p.act == 4) {
+    float u[8];
+    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= (p.act == 3) ? gelu_grad_f(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
+  }
+  if (p.row_scale && !p.scale_bias_only) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= rs;
+  }
+  if (e_.has_drop) {
+    const uint64_t e4 = ((uint64_t)m * (uint64_t)e_.N + (uint64_t)n) >> 2;
+    const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
+    const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bits[e] < e_.thr ? 0.f : v[e] * e_.keep_scale;
+  }
+  if (p.resid) {
+    float rr[8];
+    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)dst * p.ldr + n), rr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+  }
+  if (e_.S > 1) {
+    if (p.workspace) {
+      float* c = reinterpret_cast<float*>(p.workspace) + ((size_t)e_.slice * e_.M + dst) * e_.N + n;
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
+    }
+  } else if (p.out_fp32) {
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
+    if (p.accumulate) {
+      const float4 o0 = *reinterpret_cast<const float4*>(c), o1 = *reinterpret_cast<const float4*>(c + 4);
+      v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) = pack_bf8(v);
+  }
+}
+
+// B-operand fragment with the permuted N index: MFMA tile (jb, hf) of a 32-column block covers columns
+// 32*jb + 8*(q/4) + 4*hf + q%4 for operand lane q, so D' row 4g+e of the tile pair is column 32*jb + 8g + 4*hf + e.
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag_bperm(const unsigned char* lds, int col_base, int hf, int s, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if (KMAJOR) {
+    const int row = col_base + 8 * (r >> 2) + 4 * hf + (r & 3), kc = s * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ kswz<true>(row)) << 4));
+  } else {
+    // transposing read: the 4 lanes p = r&3 of a k-row supply the 4 x 8-byte pieces; piece p now comes from columns
+    // col_base + 8p + 4hf .. +3 (instead of 4p..4p+3), which realises the same column permutation
+    const int col = col_base + 8 * (r & 3) + 4 * hf;
+    const int slot = col >> 4, sub = (col & 15) * 2;
+    const int krow = s * 32 + g * 8 + (r >> 2), krow2 = krow + 4;
+    const int o1 = krow * 256 + (((slot ^ swz_m(krow)) & 7) << 5) + sub;
+    const int o2 = krow2 * 256 + (((slot ^ swz_m(krow2)) & 7) << 5) + sub;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
   }
 }
 
@@ -709,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   auto issue = [&](int m0, int n0, int kt, int buf) {
     unsigned char* st = smem + buf * 2 * TILE_BYTES;
     issue_tile<AK>(ra_, p.lda, m0, kt * BK, st, tid);
-    issue_tile<BKM>(rb_, p.ldb, n0, kt * BK, st + TILE_BYTES, tid);
+    issue_tile<BKM, true>(rb_, p.ldb, n0, kt * BK, st + TILE_BYTES, tid);
   };
 
   int w = li;
@@ -742,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK, true>(la, wm * 4 + i, s, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKM, true>(lb, wn * 4 + j, s, lane);
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag_bperm<BKM>(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -766,10 +869,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       }
       const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
 #pragma clang loop unroll(full)
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + g * 4;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (valid && n < N) epi_store(p, ec, v, m, dst, n, rs);
+      for (int jb = 0; jb < 2; ++jb) {
+        const int n = n0 + wn * 64 + jb * 32 + g * 8;
+        float v[8] = {acc[i][2 * jb][0], acc[i][2 * jb][1], acc[i][2 * jb][2], acc[i][2 * jb][3],
+                      acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
+        if (valid && n < N) epi_store8(p, ec, v, m, dst, n, rs, N - n);
       }
     }
     if (!more) break;
@@ -833,9 +937,9 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (dd.variant == 3) big = false;
   if (dd.variant == 4) big = direct;
   const int tiles_p3 = ((dd.M + P3_BM - 1) / P3_BM) * ((dd.N + P3_BN - 1) / P3_BN);
-  // 3-stage 256x128 kernel: measured +3..6% on k-major x k-major problems with M >= 1024 (forward and W^T dgrad GEMMs);
-  // m/n-major operands stay on the 2-stage 128^2 kernel (faster there).
-  bool p3 = direct && !big && (dd.variant == 5 || (dd.variant == 0 && dd.a_kmajor && dd.b_kmajor && dd.M >= 1024 && tiles_p3_ok(dd.M, dd.N)));
+  // The 3-stage 256x128 kernel (variant 5) and the 256^2 kernel (variant 4) are kept as tested alternatives; after the
+  // persistent kernel got cross-tile prefetch and 16-byte stores it is faster than both on every shape of the step.
+  bool p3 = direct && !big && dd.variant == 5;
   const int tiles = big ? tiles_big : (p3 ? tiles_p3 : tiles_small);
   if (dd.splitk == 0) {
     dd.splitk = 1;
