@@ -111,10 +111,27 @@ class Agent_Pretrain:
             self.backward_step()
             self.global_step += 1
         else:
+            # evaluation branch of the reference (main_pretrain.py:574-586): accuracies for MLM / VTM, masked L1 for MVM
             losses, outs = eng.forward_backward(b, negatives=negatives, train=False, want_outputs=True, backward=False)
+            pred_m = outs["out_mtm"].argmax(-1)
+            ans_m = b["ans_mtm"]
+            nm = int((ans_m != -1).sum().item())
+            ac_mtm = float(((pred_m == ans_m) & (ans_m != -1)).sum().item()) / nm if nm > 0 else -1
+            ac_vtm = float((outs["out_vtm"].argmax(-1) == 0).float().mean().item())
+            return {"mtm": ac_mtm, "vtm": ac_vtm, "mvm_pixel": float(losses["mvm"].item())}
         if not sync:
             return losses
         return {"mtm": float(losses["mtm"].item()), "mvm": float(losses["mvm"].item()), "vtm": float(losses["vtm"].item()), "smtm": -1}
+
+    def go_dl(self, ep, dl, is_train):
+        """main_pretrain.py:588-610 : one pass over a loader of {img, txt, mask} batches; returns rank-averaged means."""
+        ret = {}
+        for batch in dl:
+            masked = self.masking(batch["img"], batch["txt"], batch["mask"], batch.get("vq"))
+            r = self.step(self.prepare_batch(masked), is_train)
+            for k, v in r.items():
+                ret.setdefault(k, []).append(v)
+        return {k: self.reduce_mean(float(np.mean([x for x in v if x == x]))) for k, v in ret.items()}
 
     def backward_step(self):
         """all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:186-193)"""

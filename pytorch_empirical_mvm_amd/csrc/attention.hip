@@ -121,7 +121,13 @@ __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int HD, int MODE, int NT_MAX, int NW>
+// NX > 0: the number of 16-key tiles is a compile-time constant (the step's shapes: 392 -> 25, 196 -> 13, 432 -> 27, 232 -> 15),
+// so the fully unrolled tile loops carry no runtime guards / exec-mask juggling and only the LAST tile checks key < L.
+// MASK = false: un-shifted window block (no region compare).
+#define TILE_ON(t) (NX ? ((t) < NX) : ((t) < nt))
+#define PAIR_ON(c) (NX ? ((c) < (NX + 1) / 2) : ((c) < nt2))
+#define KEY_OK(t, key) ((NX && (t) < NX - 1) ? true : ((key) < L))
+template <int HD, int MODE, int NT_MAX, int NW, int NX, bool MASK>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) {
       acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+      if (TILE_ON(t)) {
         const int row = t * 16 + r;
 #pragma unroll
         for (int s = 0; s < HD / 32; ++s) {
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     float mx = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) {
-      if (t < nt) {
+      if (TILE_ON(t)) {
         const int key0 = t * 16 + g * 4;
         if (MODE == 0) {
           const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
@@ -193,8 +199,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float s = acc[t][j] + tab[rcq - rks[j] + p.rc0] + (regq != gks[j] ? -100.f : 0.f);
-            s = (key0 + j < L) ? s : NEG_INF;
+            float s = acc[t][j] + tab[rcq - rks[j] + p.rc0];
+            if (MASK) s += (regq != gks[j] ? -100.f : 0.f);
+            s = KEY_OK(t, key0 + j) ? s : NEG_INF;
             acc[t][j] = s; mx = fmaxf(mx, s);
           }
         } else {
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     if (has_drop) {
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
           const uint4 blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)(t * 4 + g));
           const uint32_t w = u4_get(blk, q & 3);
 #pragma unroll
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     for (int dt = 0; dt < HD / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NT_MAX / 2; ++c) {
-      if (c < nt2) {
+      if (PAIR_ON(c)) {
         float a[4] = {acc[2 * c][0], acc[2 * c][1], acc[2 * c][2], acc[2 * c][3]};
         float b[4] = {acc[2 * c + 1][0], acc[2 * c + 1][1], acc[2 * c + 1][2], acc[2 * c + 1][3]};
         const bf16x8 pf = frag_from_f32(a, b);
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
 // scatter into the relative-position table (rc[i]-rc[j]+rc0) happens once per workgroup instead of once per window:
 // per-element LDS atomics were 50% of the backward attention time.
 // ================================================================================================
-template <int NT_MAX, int NW>
+template <int NT_MAX, int NW, int NX, bool MASK>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqg) {
   constexpr int HD = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -473,14 +480,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
     f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int c = 0; c < NT_MAX / 2; ++c) {
-      if (c < nt2) {
+      if (PAIR_ON(c)) {
         float ds[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int t = 2 * c + u;
 #pragma unroll
           for (int j = 0; j < 4; ++j) ds[u][j] = 0.f;
-          if (t < nt) {
+          if (TILE_ON(t)) {
             const int row = t * 16 + r;
             f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Ksm, row, g), qf, s4, 0, 0, 0);
@@ -492,8 +499,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
             const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float sv = s4[j] + tab[rcq - rks[j] + p.rc0] + (regq != gks[j] ? -100.f : 0.f);
-              const float pr = (key0 + j < L && qv) ? __expf(sv - lse) : 0.f;
+              float sv = s4[j] + tab[rcq - rks[j] + p.rc0];
+              if (MASK) sv += (regq != gks[j] ? -100.f : 0.f);
+              const float pr = (KEY_OK(t, key0 + j) && qv) ? __expf(sv - lse) : 0.f;
               const float d = pr * (dp4[j] * seq_scale - dl);
               ds[u][j] = d;
               racc[t][j] += d;
@@ -519,11 +527,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
       const int rcq = rc[q];
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
           const int key0 = t * 16 + g * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (key0 + j < L) atomicAdd(&dtab[rcq - rc[key0 + j] + p.rc0], racc[t][j]);
+            if (KEY_OK(t, key0 + j)) atomicAdd(&dtab[rcq - rc[key0 + j] + p.rc0], racc[t][j]);
         }
       }
     }
@@ -727,11 +735,11 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
 
 }  // namespace
 
-#define LAUNCH_FWD(HD, MODE, NTM, NW)                                                        \
+#define LAUNCH_FWD(HD, MODE, NTM, NW, NX, MASK)                                              \
   do {                                                                                       \
-    int rc_ = set_smem(attn_fwd_kernel<HD, MODE, NTM, NW>, sm.total);                        \
+    int rc_ = set_smem(attn_fwd_kernel<HD, MODE, NTM, NW, NX, MASK>, sm.total);              \
     if (rc_) return rc_;                                                                     \
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE, NTM, NW>), dim3(nb), dim3(NW * 64), sm.total, st, *d); \
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE, NTM, NW, NX, MASK>), dim3(nb), dim3(NW * 64), sm.total, st, *d); \
   } while (0)
 
 extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
@@ -740,10 +748,16 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Smem sm = smem_layout(d->L, d->head_dim, d->mode, d->table_len, 0);
   const int nb = d->nseq * d->heads;
+  const bool mask = d->region != nullptr;
   if (d->mode == 0) {
-    if (sm.nt <= 16) LAUNCH_FWD(32, 0, 16, 4); else LAUNCH_FWD(32, 0, 28, 4);
+    if (sm.nt == 25) { if (mask) LAUNCH_FWD(32, 0, 26, 4, 25, true); else LAUNCH_FWD(32, 0, 26, 4, 25, false); }
+    else if (sm.nt == 13) { if (mask) LAUNCH_FWD(32, 0, 14, 4, 13, true); else LAUNCH_FWD(32, 0, 14, 4, 13, false); }
+    else if (sm.nt <= 16) LAUNCH_FWD(32, 0, 16, 4, 0, true);
+    else LAUNCH_FWD(32, 0, 28, 4, 0, true);
   } else {
-    if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4); else LAUNCH_FWD(64, 1, 28, 8);
+    // (exact-NT instantiations of the head_dim-64 kernel spill: the hoisted loads of 27 unguarded tiles exceed 256 VGPRs)
+    if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4, 0, true);
+    else LAUNCH_FWD(64, 1, 28, 8, 0, true);
   }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
@@ -785,15 +799,17 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     int nch = 768 / (d->f.heads * nqg);
     if (nch < 1) nch = 1;
     if (nch > d->f.nseq) nch = d->f.nseq;
-    if (s_.nt <= 16) {
-      int rc_ = set_smem(attn_bwd_dq_win_kernel<16, 4>, s_.total);
-      if (rc_) return rc_;
-      hipLaunchKernelGGL((attn_bwd_dq_win_kernel<16, 4>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg);
-    } else {
-      int rc_ = set_smem(attn_bwd_dq_win_kernel<28, 4>, s_.total);
-      if (rc_) return rc_;
-      hipLaunchKernelGGL((attn_bwd_dq_win_kernel<28, 4>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg);
-    }
+#define LAUNCH_DQW(NTM, NX, MASK)                                                                                   \
+    do {                                                                                                            \
+      int rc_ = set_smem(attn_bwd_dq_win_kernel<NTM, 4, NX, MASK>, s_.total);                                        \
+      if (rc_) return rc_;                                                                                          \
+      hipLaunchKernelGGL((attn_bwd_dq_win_kernel<NTM, 4, NX, MASK>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg); \
+    } while (0)
+    const bool mask = d->f.region != nullptr;
+    if (s_.nt == 25) { if (mask) LAUNCH_DQW(26, 25, true); else LAUNCH_DQW(26, 25, false); }
+    else if (s_.nt == 13) { if (mask) LAUNCH_DQW(14, 13, true); else LAUNCH_DQW(14, 13, false); }
+    else if (s_.nt <= 16) LAUNCH_DQW(16, 0, true);
+    else LAUNCH_DQW(28, 0, true);
     VMVM_CHECK_LAUNCH();
     LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2);
   } else {
