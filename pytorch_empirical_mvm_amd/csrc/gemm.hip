@@ -944,7 +944,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (dd.splitk == 0) {
     dd.splitk = 1;
     if (plain_acc) {
-      int s = (big ? 512 : (p3 ? 512 : 1024)) / tiles;
+      int s = (big ? 512 : (p3 ? 512 : (direct ? 512 : 1024))) / tiles;      // persistent kernel: 512 resident workgroups
       if (s > nk_all_ / 4) s = nk_all_ / 4;
       if (s > 1) dd.splitk = s;
     }

@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvmvm.so")
+LIB_PATH = os.environ.get("VMVM_LIB") or os.path.join(_HERE, "libvmvm.so")      # VMVM_LIB: experiment builds only
 
 c_void_p, c_int, c_float, c_u64, c_i64 = C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_int64
 
