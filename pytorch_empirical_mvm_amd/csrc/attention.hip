@@ -82,6 +82,31 @@ __device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src
     }
   }
 }
+// K and V images of one (sequence, head) with PRECOMPUTED per-thread source offsets (goff[i] = 0xffffffff: beyond the image)
+template <int NF, int STEP>
+__device__ __forceinline__ void fill_pre(unsigned char* dst, int kv_bytes, const u16* ksrc, const u16* vsrc, unsigned bytes, const uint32_t* goff) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(ksrc), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vsrc), 0, (int)bytes, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    if (i < NF - 1 || goff[i] != 0xffffffffu) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(dst + i * STEP), 16, goff[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes + i * STEP), 16, goff[i], 0, 0, 0);
+    }
+  }
+}
+// one 16-byte request of each image (the caller spreads the NF requests over its compute loop: the texture addresser takes
+// ~16 cycles per 1-KiB wave request, so 8 waves issuing a whole fill back to back serialise for ~1500 cycles)
+__device__ __forceinline__ void fill_one(unsigned char* dst, int kv_bytes, const u16* ksrc, const u16* vsrc, unsigned bytes, uint32_t goff, bool guard) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(ksrc), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vsrc), 0, (int)bytes, 0x00020000);
+  if (!guard || goff != 0xffffffffu) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)dst, 16, goff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes), 16, goff, 0, 0, 0);
+  }
+}
 __device__ __forceinline__ void fill_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bf16x8 load_frag_global(const u16* p, bool valid) {
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -108,6 +133,23 @@ __device__ __forceinline__ bf16x8 frag_tokens(const unsigned char* img, int dt, 
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_hd(const unsigned char* img, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(img + k_off_swz<HD>(row, chunk));
+}
+
+
+// ---- transposing LDS reads through inline asm (asynchronous: results are valid only after tr_wait*) ----
+// The ds_read_tr builtin carries no memory operand, so the compiler's wait-count pass assumes it may alias any in-flight
+// direct-to-LDS load and drains vmcnt before it; kernels that overlap the next fill with compute must issue it this way.
+__device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+  return (uint32_t)(size_t)(lds_u8*)p;
+}
+__device__ __forceinline__ void tr_read4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1, uint32_t pa, uint32_t pc) {
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:1024\n\t"
+               "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:1024"
+               : "=&v"(a0), "=&v"(a1), "=&v"(c0), "=&v"(c1) : "v"(pa), "v"(pc) : "memory");
+}
+__device__ __forceinline__ void tr_wait4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
 }
 
 __device__ __forceinline__ uint32_t drop_thr8(float p) { return (uint32_t)(p * 256.f + 0.5f); }
@@ -544,6 +586,281 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
 }
 
 // ================================================================================================
+// backward A'' (window mode, exact tile count): persistent over the BATCH for a fixed (window position, head, query tile).
+// Relative-position bias + shift mask of a wave's score block are constant across clips, so they are built ONCE into registers
+// (packed bf16) and the per-clip work per score element drops to: add, fma+exp2, fma+mul, accumulate.  K/V of the next clip
+// stream into the other LDS buffer (direct-to-LDS DMA) while the current one is processed; the next clip's Q / dO / O
+// fragments are prefetched into registers.  A query tile is shared by TWO waves (one per half of the key tiles) so the
+// register-resident state (bias 2x13 + dS sums 4x13 VGPRs) leaves room for 3+ waves per SIMD; the two dQ partials are
+// combined through LDS at the next loop-top barrier.  7 query tiles x 2 = 14 waves per workgroup.
+// ================================================================================================
+constexpr int win2_rows(int nx, int ns) {               // LDS rows per K/V image: the last split's last tile PAIR may reach past nx
+  const int nh = (nx + ns - 1) / ns;
+  return ((ns - 1) * nh + 2 * ((nh + 1) / 2)) * 16;
+}
+template <int NX, bool MASK, int NQ, int NS>
+__global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vmvm_attn_bwd_desc pb, const int nqg, const int nch) {
+  constexpr int HD = 32, NWV = NQ * NS, NH = (NX + NS - 1) / NS;       // NH key tiles per split (the last split may have fewer)
+  constexpr int NPH = (NH + 1) / 2;                                     // tile pairs per split
+  constexpr int LP32 = win2_rows(NX, NS), KV = LP32 * HD * 2;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nqg);
+  const int qg = logical % nqg;
+  const int t1 = logical / nqg;
+  const int ch = t1 % nch;
+  const int h = t1 / nch;
+  const int tl4 = (p.table_len + 3) & ~3, lr4 = (L + 3) & ~3;
+  float* dtab = reinterpret_cast<float*>(smem + 4 * KV);
+  float* xch = dtab + tl4;                                              // [NS-1][NQ][64 lanes][8] f32 : dQ partials of splits 1..
+  float* tabs = xch + (NS - 1) * NQ * 64 * 8;                           // this head's bias-table column
+  int* rcs = reinterpret_cast<int*>(tabs + tl4);
+  unsigned char* regs = reinterpret_cast<unsigned char*>(rcs + lr4);    // region ids of the current window position
+  const bool want_dtab = pb.dbias_table != nullptr;
+  const int ql = wave % NQ, kh = wave / NQ;                             // query tile slot, key split
+  const int qt = qg * NQ + ql;
+  const int q = qt * 16 + r;
+  const bool active = qt < NX;
+  const bool qv = active && (q < L);
+  const int tbase = kh * NH;                                            // first key tile of this split
+  const int ntl = (NX - tbase < NH) ? NX - tbase : NH;                  // tiles in this split
+
+  for (int i = tid; i < p.table_len; i += NWV * 64) { dtab[i] = 0.f; tabs[i] = p.bias_table[(size_t)i * heads + h]; }
+  for (int i = tid; i < L; i += NWV * 64) rcs[i] = p.rc[i];
+  uint32_t bm[NH * 2];
+  auto build_bm = [&]() {                                 // bias + shift mask of this wave's score block, packed bf16 (from LDS)
+    const int rcq = rcs[qv ? q : 0] + p.rc0;
+    const int regq = MASK ? regs[qv ? q : 0] : 0;
+#pragma unroll
+    for (int tl = 0; tl < NH; ++tl) {
+      float b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = (tbase + tl) * 16 + g * 4 + j;
+        float b = NEG_INF;
+        if (tl < ntl && key < L) {
+          b = tabs[rcq - rcs[key]];
+          if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+        }
+        b4[j] = b;
+      }
+      bm[2 * tl] = pack_bf2(b4[0], b4[1]);
+      bm[2 * tl + 1] = pack_bf2(b4[2], b4[3]);
+    }
+  };
+  f32x2 racc[NH][2];
+#pragma unroll
+  for (int tl = 0; tl < NH; ++tl) { racc[tl][0] = f32x2{0.f, 0.f}; racc[tl][1] = f32x2{0.f, 0.f}; }
+
+  // this workgroup's run of sequences, WINDOW-major (i = w * B + clip): the bias block only changes with the window position
+  const int total = nWin * B;
+  const int per = (total + nch - 1) / nch;
+  const int b0 = ch * per, b1 = (b0 + per < total) ? b0 + per : total;
+  // Address generation is kept out of the per-sequence path (it was ~35% of the loop): per-lane element offsets inside a
+  // sequence and the DMA source offsets are computed once; per sequence only wave-uniform bases change.
+  const int w0 = b0 / B;
+  int w_nx = w0, c_nx = b0 - w0 * B;                    // (window position, clip) of the NEXT sequence to request
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == B) { c_nx = 0; ++w_nx; } };
+  const uint32_t off_q = (uint32_t)q * p.ld_qkv + p.q_off + h * HD + g * 8;
+  const uint32_t off_do = (uint32_t)q * pb.ld_dout + h * HD + g * 8;
+  const uint32_t off_o = (uint32_t)q * p.ld_out + h * HD + g * 8;
+  const uint32_t off_dq = (uint32_t)q * pb.ld_dqkv + p.q_off + h * HD + g * 4;
+  const uint32_t off_ls = (uint32_t)h * L + q;
+  constexpr int NF = (LP32 * 4 + NWV * 64 - 1) / (NWV * 64);            // 16-byte DMA requests per thread per image
+  static_assert(NF <= NPH, "the fill requests are spread over the tile pairs");
+  uint32_t goff[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
+    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ ((row >> 2) & 3)) << 3)) * 2) : 0xffffffffu;   // (beyond the image: out of range -> no-op)
+  }
+  const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
+  auto issue = [&](size_t seq, int buf) {
+    const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + h * HD;
+    fill_pre<NF, NWV * 64 * 16>(smem + buf * 2 * KV + (tid & ~63) * 16, KV, qkv + p.k_off, qkv + p.v_off, fill_bytes, goff);
+  };
+  bf16x8 qf, dof, of;
+  float lse_n = 0.f, ss_n = 1.0f;                       // raw prefetched values: NO arithmetic on them before the next iteration
+  auto fetch = [&](size_t seq) {
+    const u16* qb = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv;
+    const u16* dob = reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout;
+    const u16* ob = reinterpret_cast<const u16*>(p.out) + seq * L * p.ld_out;
+    qf = load_frag_global(qb + off_q, qv);
+    dof = load_frag_global(dob + off_do, qv);
+    of = load_frag_global(ob + off_o, qv);
+    lse_n = qv ? (p.lse + seq * heads * L)[off_ls] : __builtin_huge_valf();      // (a use here would drain the whole DMA queue)
+    ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  };
+  if (b0 < b1) { issue(seq_nx(), 0); fetch(seq_nx()); advance(); }
+
+  f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // this half's partial of the PREVIOUS clip (kh == 0 keeps it)
+  auto flush_prev = [&](size_t seq) {                    // split 0: add the other splits' partials (in LDS) and store dQ of clip bprev
+    if (kh == 0 && qv) {
+      float4 x0 = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]), x1 = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+#pragma unroll
+      for (int o = 0; o < NS - 1; ++o) {
+        const float* x = xch + ((o * NQ + ql) * 64 + lane) * 8;
+        const float4 y0 = *reinterpret_cast<const float4*>(x), y1 = *reinterpret_cast<const float4*>(x + 4);
+        x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+        x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+      }
+      u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv + off_dq;
+      const float sc = p.scale;
+      *reinterpret_cast<uint2*>(dqp) = make_uint2(pack_bf2(x0.x * sc, x0.y * sc), pack_bf2(x0.z * sc, x0.w * sc));
+      *reinterpret_cast<uint2*>(dqp + 16) = make_uint2(pack_bf2(x1.x * sc, x1.y * sc), pack_bf2(x1.z * sc, x1.w * sc));
+    }
+  };
+
+  int wprev = -1, w_cu = w0, c_cu = b0 - w0 * B;        // (window position, clip) of the sequence being processed
+  size_t seq_pv = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    fill_wait();
+    __syncthreads();                                      // sequence b landed; other buffer free; partials of b-1 visible; tables staged
+    if (b > b0) flush_prev(seq_pv);
+    seq_pv = seq;
+    const int wcur = w_cu;
+    if (++c_cu == B) { c_cu = 0; ++w_cu; }
+    if (wcur != wprev) {                                  // (workgroup-uniform) new window position: rebuild the bias + mask block
+      wprev = wcur;
+      if (MASK) {
+        __syncthreads();                                  // everyone is done with the previous window's region row
+        for (int i = tid; i < L; i += NWV * 64) regs[i] = p.region[(size_t)wcur * L + i];
+        __syncthreads();
+      }
+      if (MASK || b == b0) build_bm();
+    }
+    const bf16x8 cqf = qf, cdof = dof, cof = of;
+    const float clse2 = lse_n * LOG2E, seq_scale = ss_n;
+    const bool has_next = b + 1 < b1;                      // next sequence: Q/dO/O fragments now, the K/V fill spread over the tile loop
+    const u16* kv_nx = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    unsigned char* dst_nx = smem + (cur ^ 1) * 2 * KV + (tid & ~63) * 16;
+    if (has_next) {
+      fetch(seq_nx());
+      advance();
+      if (!active) fill_pre<NF, NWV * 64 * 16>(dst_nx, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: __syncthreads() would also drain the DMA / prefetch queue
+    __builtin_amdgcn_s_barrier();                         // xch has been consumed before the other splits overwrite it
+    if (!active) continue;
+    const unsigned char* Ksm = smem + cur * 2 * KV;
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)cdof[e] * (float)cof[e];
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (kh == 0 && g == 0 && qv) (pb.delta + seq * heads * L)[off_ls] = dl;
+    dq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // broadcast operands of the packed math as REAL register pairs: with an op_sel broadcast the compiler pairs the scalar with
+    // an arbitrary neighbour register, and when that neighbour is the landing register of a prefetch load the hazard pass
+    // inserts s_waitcnt vmcnt(0) in the middle of the tile loop (draining the DMA queue every sequence)
+    f32x2 nl2 = {-clse2, -clse2}, ss2 = {seq_scale, seq_scale}, ndl2 = {-dl, -dl};
+    asm volatile("" : "+v"(nl2), "+v"(ss2), "+v"(ndl2));
+    // lane bases: every tile of this half is a compile-time immediate away (the 16-byte chunk swizzle only depends on row % 16)
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const unsigned char* kb = Ksm + k_off_swz<HD>(tbase * 16 + r, g);
+    const unsigned char* tk0 = Ksm + k_off_swz<HD>(tbase * 16 + g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
+    const unsigned char* tk1 = Ksm + k_off_swz<HD>(tbase * 16 + g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    // software pipeline over tile pairs: the K / V fragments of pair c+1 and the transposed K operand of pair c are requested
+    // before the VALU work on pair c, so the LDS latency sits under the exp / multiply chain instead of in front of the MFMAs
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kf[u] = *reinterpret_cast<const bf16x8*>(kb + u * 1024);
+      vf[u] = *reinterpret_cast<const bf16x8*>(kb + KV + u * 1024);
+    }
+#pragma unroll
+    for (int c = 0; c < NPH; ++c) {
+      f32x4 s4[2], dp4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tl = 2 * c + u;
+        if (tl < NH) {                                    // (tl >= ntl in the last split: bias = -inf -> p = 0, rows are zero-filled)
+          float b0f, b1f, b2f, b3f;                       // volatile: keeps the unpack inside the loop (else 4*NH VGPRs get hoisted)
+          asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b0f) : "v"(bm[2 * tl]));
+          asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b1f) : "v"(bm[2 * tl]));
+          asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b2f) : "v"(bm[2 * tl + 1]));
+          asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b3f) : "v"(bm[2 * tl + 1]));
+          s4[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], cqf, f32x4{b0f, b1f, b2f, b3f}, 0, 0, 0);
+          dp4[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], cdof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+      }
+      // transposed K operand of this pair.  Inline asm, not the builtin: the compiler treats the builtin as "may alias the
+      // in-flight LDS DMA" and puts s_waitcnt vmcnt(0) in front of it, i.e. drains the next sequence's K/V fill every pair.
+      s16x4 a0, a1, c0, c1;
+      tr_read4(a0, a1, c0, c1, lds_addr(tk0 + c * 2048), lds_addr(tk1 + c * 2048));
+      if (c < NF && has_next)
+        fill_one(dst_nx + c * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[c], c == NF - 1);
+      if (c + 1 < NPH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (2 * c + 2 + u < NH) {
+            kf[u] = *reinterpret_cast<const bf16x8*>(kb + (2 * c + 2 + u) * 1024);
+            vf[u] = *reinterpret_cast<const bf16x8*>(kb + KV + (2 * c + 2 + u) * 1024);
+          }
+        }
+      }
+      // explicit 2-wide f32 math (v_pk_fma / v_pk_mul / v_pk_add) on the accumulator register pairs; the running dS sums are
+      // updated in place (volatile asm: the compiler otherwise sinks all 4*NH adds below the loop and keeps every dS alive)
+      uint32_t dsw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tl = 2 * c + u;
+        if (tl < NH) {
+#pragma unroll
+          for (int hj = 0; hj < 2; ++hj) {
+            const f32x2 sv = {s4[u][2 * hj], s4[u][2 * hj + 1]}, dpv = {dp4[u][2 * hj], dp4[u][2 * hj + 1]};
+            const f32x2 e = __builtin_elementwise_fma(sv, f32x2{LOG2E, LOG2E}, nl2);
+            const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            const f32x2 d = pr * __builtin_elementwise_fma(dpv, ss2, ndl2);
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(racc[tl][hj]) : "v"(d));
+            dsw[2 * u + hj] = pack_bf2v(d);
+          }
+        }
+      }
+      const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(dsw[0], dsw[1], dsw[2], dsw[3]));
+      tr_wait4(a0, a1, c0, c1);
+      const s16x8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const s16x8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      dq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), dsf, dq[0], 0, 0, 0);
+      dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), dsf, dq[1], 0, 0, 0);
+    }
+    if (kh > 0) {                                         // splits 1.. publish their partials; split 0 adds them after the next barrier
+      float* x = xch + (((kh - 1) * NQ + ql) * 64 + lane) * 8;
+      *reinterpret_cast<float4*>(x) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
+      *reinterpret_cast<float4*>(x + 4) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+    }
+  }
+  __syncthreads();
+  if (b1 > b0 && active) flush_prev(seq_pv);
+  if (want_dtab) {
+    if (qv) {
+      const int rcq = rcs[q] + p.rc0;
+#pragma unroll
+      for (int tl = 0; tl < NH; ++tl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = (tbase + tl) * 16 + g * 4 + j;
+          if (tl < ntl && key < L) atomicAdd(&dtab[rcq - rcs[key]], racc[tl][j >> 1][j & 1]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.table_len; i += NWV * 64) {
+      const float v = dtab[i];
+      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+    }
+  }
+}
+
+// ================================================================================================
 // backward B: dK, dV (per key tile; probabilities recomputed from lse; delta from kernel A)
 // ================================================================================================
 template <int HD, int MODE, int NW>
@@ -806,7 +1123,37 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       hipLaunchKernelGGL((attn_bwd_dq_win_kernel<NTM, 4, NX, MASK>), dim3(nch * d->f.heads * nqg), dim3(256), s_.total, st, *d, nch, nqg); \
     } while (0)
     const bool mask = d->f.region != nullptr;
-    if (s_.nt == 25) { if (mask) LAUNCH_DQW(26, 25, true); else LAUNCH_DQW(26, 25, false); }
+    const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
+    // batch-persistent kernel: exact tile counts of the step's windows (392 / 196 tokens) and everything fits the 160 KB LDS
+    const int nq = s_.nt == 25 ? 4 : 7, ns = s_.nt == 25 ? 2 : 1;
+    const int lp32 = win2_rows(s_.nt, ns);
+    const int tl4 = (d->f.table_len + 3) & ~3, lr4 = (d->f.L + 3) & ~3;
+    const int smem2 = 4 * lp32 * 64 + 2 * tl4 * 4 + (ns - 1) * nq * 64 * 8 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
+    const bool pers_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && smem2 <= 160 * 1024;
+    if (pers_ok) {
+      // nt = 25 (392-token window): 4 query tiles x 2 key splits (8 waves, ~220 VGPRs, no spill); nt = 13: 7 tiles x 1 split.
+      // Measured alternatives on MI355X (stage-3 shape, B=32): (5,2)/(6,2) spill, (4,3) is 15% slower.
+      const int nqg2 = (s_.nt + nq - 1) / nq;
+      // chunks of the (window position x clip) sequence range per (head, query group): whole rounds of the 256 CUs (one
+      // workgroup per CU: the LDS images fill it) x sequences per round, plus ~10 sequence-times of per-workgroup set-up
+      // (table staging, bias block, table-gradient flush through LDS atomics)
+      const int base = d->f.heads * nqg2;
+      int nbc = 1; float best = 1e30f;
+      for (int c = 1; c <= 64 && c <= d->f.nseq; ++c) {
+        const float cost = (float)((base * c + 255) / 256) * ((float)((d->f.nseq + c - 1) / c) + 10.f);
+        if (cost < best - 1e-6f) { best = cost; nbc = c; }
+      }
+      const int grid2 = base * nbc;
+#define LAUNCH_DQW2(NX, MASK, NQ, NS)                                                                               \
+      do {                                                                                                          \
+        int rc_ = set_smem(attn_bwd_dq_win2_kernel<NX, MASK, NQ, NS>, smem2);                                        \
+        if (rc_) return rc_;                                                                                        \
+        hipLaunchKernelGGL((attn_bwd_dq_win2_kernel<NX, MASK, NQ, NS>), dim3(grid2), dim3(NQ * NS * 64), smem2, st, *d, nqg2, nbc); \
+      } while (0)
+#define LAUNCH_DQW2_M(NX, NQ, NS) do { if (mask) LAUNCH_DQW2(NX, true, NQ, NS); else LAUNCH_DQW2(NX, false, NQ, NS); } while (0)
+      if (s_.nt == 25) LAUNCH_DQW2_M(25, 4, 2); else LAUNCH_DQW2_M(13, 7, 1);
+    }
+    else if (s_.nt == 25) { if (mask) LAUNCH_DQW(26, 25, true); else LAUNCH_DQW(26, 25, false); }
     else if (s_.nt == 13) { if (mask) LAUNCH_DQW(14, 13, true); else LAUNCH_DQW(14, 13, false); }
     else if (s_.nt <= 16) LAUNCH_DQW(16, 0, true);
     else LAUNCH_DQW(28, 0, true);

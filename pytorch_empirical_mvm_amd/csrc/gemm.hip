@@ -301,6 +301,46 @@ __device__ __forceinline__ bf16x8 read_frag_bperm(const unsigned char* lds, int 
   }
 }
 
+
+// ---- asynchronous transposing reads (inline asm) --------------------------------------------------------------------------
+// The ds_read_tr builtin carries no memory operand, so the compiler's wait-count pass assumes it may alias an in-flight
+// direct-to-LDS load and emits s_waitcnt vmcnt(0) in front of it -- which drains the NEXT K tile's DMA right after it was
+// issued (no load/compute overlap inside a workgroup).  Issued through asm the reads are invisible to that pass; the halves
+// are only valid after tr_wait8 (s_waitcnt lgkmcnt(0)), which also ties the registers so no use can be scheduled early.
+__device__ __forceinline__ uint32_t lds_addr32(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+  return (uint32_t)(size_t)(lds_u8*)p;
+}
+__device__ __forceinline__ void tr_issue2(s16x4& lo, s16x4& hi, uint32_t a1, uint32_t a2) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a1), "v"(a2) : "memory");
+}
+__device__ __forceinline__ void tr_wait8(s16x4* lo, s16x4* hi) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+__device__ __forceinline__ bf16x8 tr_cat(const s16x4& a, const s16x4& b) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// m-major operand, slot x16 (same addressing as read_frag<false, true>)
+__device__ __forceinline__ void tr_issue_frag(const unsigned char* lds, int x16, int s, int lane, s16x4& lo, s16x4& hi) {
+  const int r = lane & 15, g = lane >> 4;
+  const int krow = s * 32 + g * 8 + (r >> 2), krow2 = krow + 4;
+  const int o1 = krow * 256 + (((x16 ^ swz_m(krow)) & 7) << 5) + (r & 3) * 8;
+  const int o2 = krow2 * 256 + (((x16 ^ swz_m(krow2)) & 7) << 5) + (r & 3) * 8;
+  tr_issue2(lo, hi, lds_addr32(lds + o1), lds_addr32(lds + o2));
+}
+// n-major B operand with the column permutation of read_frag_bperm<false>
+__device__ __forceinline__ void tr_issue_bperm(const unsigned char* lds, int col_base, int hf, int s, int lane, s16x4& lo, s16x4& hi) {
+  const int r = lane & 15, g = lane >> 4;
+  const int col = col_base + 8 * (r & 3) + 4 * hf;
+  const int slot = col >> 4, sub = (col & 15) * 2;
+  const int krow = s * 32 + g * 8 + (r >> 2), krow2 = krow + 4;
+  const int o1 = krow * 256 + (((slot ^ swz_m(krow)) & 7) << 5) + sub;
+  const int o2 = krow2 * 256 + (((slot ^ swz_m(krow2)) & 7) << 5) + sub;
+  tr_issue2(lo, hi, lds_addr32(lds + o1), lds_addr32(lds + o2));
+}
+
 template <bool AK, bool BKM, bool TR, bool DIRECT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -842,10 +882,27 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 fa[4], fb[4];
+        s16x4 alo[4], ahi[4], blo[4], bhi[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK, true>(la, wm * 4 + i, s, lane);
+        for (int i = 0; i < 4; ++i) {
+          if (AK) fa[i] = read_frag<true, true>(la, wm * 4 + i, s, lane);
+          else tr_issue_frag(la, wm * 4 + i, s, lane, alo[i], ahi[i]);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = read_frag_bperm<BKM>(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane);
+        for (int j = 0; j < 4; ++j) {
+          if (BKM) fb[j] = read_frag_bperm<true>(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane);
+          else tr_issue_bperm(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane, blo[j], bhi[j]);
+        }
+        if (!AK) {
+          tr_wait8(alo, ahi);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[i] = tr_cat(alo[i], ahi[i]);
+        }
+        if (!BKM) {
+          tr_wait8(blo, bhi);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[j] = tr_cat(blo[j], bhi[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -505,31 +505,36 @@ def bench_gemm():
 
 def bench_attn():
     print("---- attention timing")
-    B, heads, N = 32, 16, 392
-    nW = 4
-    nseq = B * nW
-    C_ = heads * 32
-    qkv = rnd(nseq * N, 3 * C_)
-    rc, rc0 = SI.rc_codes(N, (8, 7, 7))
-    rc_t = torch.from_numpy(rc).to(dev)
-    table = torch.randn(2535, heads, device=dev) * 0.1
-    reg = torch.from_numpy(SI.region_ids(8, 14, 14, (8, 7, 7), (0, 3, 3))).to(dev)
-    f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
-    out, lse = f()
-    dout = rnd(nseq * N, C_)
-    dtab = torch.zeros_like(table)
-    b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab)
-    fl = 4.0 * nseq * heads * N * N * 32
-    b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None)
-    for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5), ("win bwd (no table grad)", b0, 2.5)):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF (stage-3 shape, B=32)")
+    # the four Swin-B stages of the C2 workload (8 frames, each doubled -> D=8 -> window (8,7,7) = 392 tokens) + a half-depth window
+    for label, B, heads, N, ws, dims in (("stage-1", 32, 4, 392, (8, 7, 7), (8, 56, 56)), ("stage-2", 32, 8, 392, (8, 7, 7), (8, 28, 28)),
+                                         ("stage-3", 32, 16, 392, (8, 7, 7), (8, 14, 14)), ("stage-4", 32, 32, 392, (8, 7, 7), (8, 7, 7)),
+                                         ("stage-3/D=4", 32, 16, 196, (4, 7, 7), (4, 14, 14))):
+        shift = (0, 3, 3) if dims[1] > 7 else (0, 0, 0)
+        nW = (dims[1] // 7) * (dims[2] // 7)
+        nseq = B * nW
+        C_ = heads * 32
+        qkv = rnd(nseq * N, 3 * C_)
+        rc, rc0 = SI.rc_codes(N, (8, 7, 7))
+        rc_t = torch.from_numpy(rc).to(dev)
+        table = torch.randn(2535, heads, device=dev) * 0.1
+        reg = torch.from_numpy(SI.region_ids(dims[0], dims[1], dims[2], ws, shift)).to(dev) if any(shift) else None
+        f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
+        out, lse = f()
+        dout = rnd(nseq * N, C_)
+        dtab = torch.zeros_like(table)
+        b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab)
+        fl = 4.0 * nseq * heads * N * N * 32
+        b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None)
+        for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5), ("win bwd (no table grad)", b0, 2.5)):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF ({label} shape, B={B})")
+        del qkv, out, lse, dout
     nseq, Lq, heads = 160, 432, 12
     Hd = 768
     qkv = rnd(nseq * Lq, 3 * Hd)
