@@ -109,6 +109,9 @@ typedef struct {
   /* optional second output dX2 = dropout_mask(seed, offset + m*C+c) * dX / (1-p)  (HF hidden dropout backward) */
   void* dX2; int32_t lddx2; float dropout_p; uint64_t seed, offset;
   int32_t x_fp32;
+  /* optional scratch for the dgamma/dbeta partials (>= 1280 * 2C floats): per-workgroup partials are stored
+   * and summed by a second small kernel instead of 2C global atomics per workgroup.  NULL: atomics. */
+  void* workspace; uint64_t workspace_bytes;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
 

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
     if (p.src && p.pad_mode == 0 && p.src[ml] < 0) continue;     // pad slot: constant zero output
     float xh[NCH][8], gdy[NCH][8];
     long srow[NCH]; int within[NCH];
+    uint4 addv[NCH];                                      // residual-path gradient, requested WITH x / dY (not after the row reduction)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
         }
         float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
         if (srow[i] >= 0) load_x8<XF32>(p.X, (size_t)srow[i] * p.ldx + within[i], xv);
+        addv[i] = make_uint4(0, 0, 0, 0);
+        if (ADD && srow[i] >= 0) addv[i] = *reinterpret_cast<const uint4*>(ADD + (size_t)srow[i] * p.ldadd + within[i]);
         unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col), dyv);
         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
         for (int e = 0; e < 8; ++e) o[e] = rstd * (gdy[i][e] - s1 - xh[i][e] * s2);
         if (ADD) {
           float a[8];
-          unpack_bf8(*reinterpret_cast<const uint4*>(ADD + (size_t)srow[i] * p.ldadd + within[i]), a);
+          unpack_bf8(addv[i], a);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += a[e];
         }
@@ -186,24 +189,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
       }
     }
   }
-  // block reduction of dgamma/dbeta partials, then one atomic per column
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // block reduction of the dgamma/dbeta partials: one LDS slab per wave (plain stores, no LDS atomics), then either one partial
+  // row per workgroup in the scratch buffer (summed by ln_colreduce_kernel) or, without scratch, one global atomic per column
+  float* redw = red + wave * 2 * C;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
     if (c < nch) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[c * 8 + e], dg[i][e]);
-        atomicAdd(&red[C + c * 8 + e], db[i][e]);
-      }
+      *reinterpret_cast<float4*>(redw + c * 8) = make_float4(dg[i][0], dg[i][1], dg[i][2], dg[i][3]);
+      *reinterpret_cast<float4*>(redw + c * 8 + 4) = make_float4(dg[i][4], dg[i][5], dg[i][6], dg[i][7]);
+      *reinterpret_cast<float4*>(redw + C + c * 8) = make_float4(db[i][0], db[i][1], db[i][2], db[i][3]);
+      *reinterpret_cast<float4*>(redw + C + c * 8 + 4) = make_float4(db[i][4], db[i][5], db[i][6], db[i][7]);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(p.dgamma + i, red[i]);
-    atomicAdd(p.dbeta + i, red[C + i]);
+  float* ws = reinterpret_cast<float*>(p.workspace);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const float v = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+    if (ws) ws[(size_t)blockIdx.x * 2 * C + i] = v;
+    else atomicAdd(i < C ? p.dgamma + i : p.dbeta + (i - C), v);
+  }
+}
+
+// dgamma[c] += sum_rows ws[row][c], dbeta[c] += sum_rows ws[row][C + c] : 64 columns x 4 row lanes per workgroup, blockIdx.y
+// splits the rows 8 ways (8 atomics per column in total)
+__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* ws, int rows, int C, float* dgamma, float* dbeta) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  float acc = 0.f;
+  if (col < 2 * C)
+    for (int r = r0 + rl; r < r1; r += 4) acc += ws[(size_t)r * 2 * C + col];
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && col < 2 * C) {
+    const float v = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+    atomicAdd(col < C ? dgamma + col : dbeta + (col - C), v);
   }
 }
 
@@ -237,16 +260,32 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->dX2 && d->src) return VMVM_ENOSUPPORT;
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
+  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 3 : 2;
   int grid = (d->M + 3) / 4;
-  if (grid > 2048) grid = 2048;
-  const size_t sm = (size_t)2 * d->C * sizeof(float);
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  const size_t sm = (size_t)8 * d->C * sizeof(float);   // 4 wave slabs x [2][C]
+  vmvm_ln_bwd_desc dd = *d;
+  if (dd.workspace && dd.workspace_bytes < (uint64_t)grid * 2 * d->C * sizeof(float)) dd.workspace = nullptr;
+#define LAUNCH_LNB(NCH, XF)                                                                                            \
+  do {                                                                                                                  \
+    if (sm > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<NCH, XF>),                   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)       \
+      return VMVM_EHIP;                                                                                                 \
+    hipLaunchKernelGGL((ln_bwd_kernel<NCH, XF>), dim3(grid), dim3(256), sm, st, dd);                                    \
+  } while (0)
   if (d->x_fp32) {
     if (d->C > 512) return VMVM_ENOSUPPORT;
-    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), sm, st, *d);
-  } else if (d->C <= 512) hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), sm, st, *d);
-  else if (d->C <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), sm, st, *d);
-  else if (d->C <= 2048) hipLaunchKernelGGL((ln_bwd_kernel<4, false>), dim3(grid), dim3(256), sm, st, *d);
-  else hipLaunchKernelGGL((ln_bwd_kernel<6, false>), dim3(grid), dim3(256), sm, st, *d);
+    LAUNCH_LNB(1, true);
+  } else if (d->C <= 512) LAUNCH_LNB(1, false);
+  else if (d->C <= 1024) LAUNCH_LNB(2, false);
+  else if (d->C <= 2048) LAUNCH_LNB(4, false);
+  else LAUNCH_LNB(6, false);
+  if (dd.workspace) {
+    VMVM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * d->C + 63) / 64, 8), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(dd.workspace), grid, d->C, d->dgamma, d->dbeta);
+  }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -104,6 +104,8 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
     d.dX2, d.lddx2 = L.ptr(dX2), Cc
     d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
     d.x_fp32 = int(X.dtype == F32)
+    ws = _WORKSPACE.get(dY.device)
+    d.workspace, d.workspace_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
     L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
     return dX, dX2
 

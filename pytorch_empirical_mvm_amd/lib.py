@@ -45,7 +45,8 @@ class LnBwdDesc(C.Structure):
                 ("src", c_void_p), ("rows_out_per_batch", c_int), ("rows_in_per_batch", c_int),
                 ("pad_mode", c_int),
                 ("dX_add", c_void_p), ("ldadd", c_int),
-                ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int)]
+                ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int),
+                ("workspace", c_void_p), ("workspace_bytes", c_u64)]
 
 
 class AttnFwdDesc(C.Structure):

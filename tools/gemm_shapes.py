@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-shape GEMM time inside one real training step: wraps kernels.gemm with HIP-event timing (one sync per call, so the
+step itself runs slowly; the per-call durations are what is reported)."""
+import collections
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pytorch_empirical_mvm_amd import config as CFG
+from pytorch_empirical_mvm_amd import kernels as K
+from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = "cuda:0"
+torch.cuda.set_device(0)
+args = CFG.get_args(vis_backbone_size="base", size_frame=8, max_size_frame=8, size_img=224, size_txt=32, mvm_target=["pixel"], max_iter=10000, seed=88)
+model = VIOLET_Pretrain(args, None, device=dev)
+agent = Agent_Pretrain(args, model)
+agent.sched_step = 500
+img, txt, mask = bench.synth_batch(args, B, dev, 88)
+mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
+for _ in range(2):
+    agent.step(mb, is_train=True, sync=False)
+torch.cuda.synchronize()
+stats = collections.defaultdict(lambda: [0, 0.0])
+orig = K.gemm
+
+
+def timed(A, Bm, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig(A, Bm, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ak, bk = kw.get("a_kmajor", True), kw.get("b_kmajor", True)
+    M = kw.get("M") or (A.shape[0] if ak else A.shape[1])
+    Kd = kw.get("K") or (A.shape[1] if ak else A.shape[0])
+    N = kw.get("N") or (Bm.shape[0] if bk else Bm.shape[1])
+    flags = ("T" if ak else "N") + ("T" if bk else "N")
+    epi = "+".join(x for x, c in (("bias", kw.get("bias") is not None), ("act%d" % kw.get("act", 0), kw.get("act", 0)), ("aux", kw.get("aux") is not None),
+                                  ("pre", kw.get("out_preact") is not None), ("res", kw.get("resid") is not None), ("map", kw.get("row_map") is not None),
+                                  ("rs", kw.get("row_scale") is not None), ("drop", kw.get("dropout_p", 0) > 0), ("acc", kw.get("accumulate", False)),
+                                  ("f32", kw.get("out_dtype", None) == torch.float32 or (kw.get("out") is not None and kw["out"].dtype == torch.float32))) if c)
+    s = stats[(M, N, Kd, flags, epi)]
+    s[0] += 1
+    s[1] += e0.elapsed_time(e1)
+    return out
+
+
+K.gemm = timed
+import pytorch_empirical_mvm_amd.engine as E
+E.K.gemm = timed
+agent.step(mb, is_train=True, sync=False)
+torch.cuda.synchronize()
+tot = sum(v[1] for v in stats.values())
+print(f"GEMM total {tot:.1f} ms over {sum(v[0] for v in stats.values())} calls (B={B})")
+print(f"{'M':>8} {'N':>6} {'K':>8} lay {'n':>4} {'ms':>8} {'avg_us':>8} {'TF':>7}  epilogue")
+for (M, N, Kd, fl, epi), (n, ms) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+    print(f"{M:8d} {N:6d} {Kd:8d} {fl}  {n:4d} {ms:8.2f} {ms / n * 1e3:8.1f} {2.0 * M * N * Kd * n / ms / 1e9:7.1f}  {epi}")

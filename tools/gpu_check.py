@@ -175,8 +175,12 @@ def check_gemm_epilogues():
 
 # ------------------------------------------------------------------ layernorm
 def check_ln():
-    for C_ in (96, 128, 512, 768, 1024, 2048, 3072):
-        M = 777
+    for C_, with_ws in ((96, False), (128, True), (512, False), (512, True), (768, True), (768, False), (1024, True), (2048, True), (3072, False), (3072, True)):
+        # with_ws: dgamma/dbeta partials through the scratch buffer + column-reduce kernel ; without: global atomics
+        K._WORKSPACE.clear()
+        if with_ws:
+            K.set_workspace(torch.empty(64 << 20, device=dev, dtype=torch.uint8))
+        M = 777 if C_ != 768 else 5000
         x = rnd(M, C_)
         g = torch.randn(C_, device=dev) * 0.1 + 1
         b = torch.randn(C_, device=dev) * 0.1
@@ -191,14 +195,15 @@ def check_ln():
         add = rnd(M, C_)
         dx, dx2 = K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dX_add=add, want_dX2=True, dropout_p=0.1, seed=5, offset=3)
         rep(f"ln bwd dx(+add) C={C_}", dx, xf.grad + add.float())
-        rep(f"ln bwd dgamma C={C_}", dg, gf.grad)
-        rep(f"ln bwd dbeta C={C_}", db, bf.grad)
-        if C_ == 768:
+        rep(f"ln bwd dgamma C={C_} ws={with_ws}", dg, gf.grad)
+        rep(f"ln bwd dbeta C={C_} ws={with_ws}", db, bf.grad)
+        if C_ == 768 and with_ws:
             # dX2 must equal the GEMM-epilogue dropout mask pattern (same seed/offset, N=C)
             A = torch.eye(128, device=dev, dtype=BF)
             ones = K.gemm(torch.ones(M, 128, device=dev, dtype=BF), torch.ones(C_, 128, device=dev, dtype=BF), dropout_p=0.1, seed=5, offset=3)
             mask = (ones.float() != 0)
             rep("ln bwd dX2 mask consistent with gemm dropout", dx2, torch.where(mask, dx.float() / 0.9, torch.zeros_like(dx.float())))
+    K._WORKSPACE.clear()
 
 
 def check_ln_gather():
@@ -555,6 +560,26 @@ def bench_attn():
         print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF (B=32 x 5 seqs)")
 
 
+def bench_ln():
+    print("---- layernorm timing (ms, algorithmic GB/s = bf16 tensors touched)")
+    K.set_workspace(torch.empty(64 << 20, device=dev, dtype=torch.uint8))
+    for (M, Cc) in [(69120, 768), (50176, 512), (200704, 256), (802816, 128), (12544, 1024)]:
+        x, dy, add = rnd(M, Cc), rnd(M, Cc), rnd(M, Cc)
+        g, b = torch.randn(Cc, device=dev), torch.randn(Cc, device=dev)
+        y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5)
+        dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+        for name, fn, nt in (("ln fwd", lambda: K.layernorm_fwd(x, g, b, 1e-5), 2), ("ln bwd", lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dg, db), 3),
+                             ("ln bwd+add", lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dX_add=add), 4)):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"     {name:10s} {M}x{Cc}: {ms:.3f} ms  {nt * M * Cc * 2 / ms / 1e6:.0f} GB/s")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["probe", "gemm", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
@@ -563,6 +588,8 @@ if __name__ == "__main__":
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
+        elif w == "benchln":
+            run(bench_ln)
         else:
             run(table[w])
     bad = [r for r in RESULTS if r[3]]

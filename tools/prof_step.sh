@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the default bench step; writes the per-kernel summary to gpurun_out/
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_step
+rocprofv3 --kernel-trace -d /tmp/prof_step -- python3 $GRAFT_REPO_ROOT/bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /tmp/prof_step.log 2>&1
+tail -1 /tmp/prof_step.log | cut -c1-200
+DB=$(find /tmp/prof_step -name "*.db" | head -1)
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_shapes.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_shapes.txt 2>&1
+head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
