@@ -25,8 +25,9 @@ __device__ __forceinline__ u16 f2bf(float f) {
   __bf16 b = (__bf16)f;                      // RNE; v_cvt_pk_bf16_f32 on gfx950
   return __builtin_bit_cast(u16, b);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {          // one v_cvt_pk_bf16_f32 (RNE)
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, bf16x2));
 }
 __device__ __forceinline__ uint32_t pack_bf2v(f32x2 v) {          // one v_cvt_pk_bf16_f32
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -68,6 +69,32 @@ __device__ __forceinline__ float erf_poly(float z) {
   p = fmaf(p, t, 1.1279515e+00f);
   const float e = p * z;
   return fabsf(z) > 3.0f ? copysignf(1.0f, z) : fminf(fmaxf(e, -1.0f), 1.0f);
+}
+// two elements at a time: the polynomial is a pure FMA chain, so it runs on the packed-f32 pipe (v_pk_fma_f32) at half the
+// instruction count; the |z| > 3 select becomes a clamp of the argument (v_med3_f32) plus a clamp of the result
+__device__ __forceinline__ f32x2 erf_poly2(f32x2 z) {
+  z = f32x2{__builtin_amdgcn_fmed3f(z[0], -3.0f, 3.0f), __builtin_amdgcn_fmed3f(z[1], -3.0f, 3.0f)};
+  const f32x2 t = z * z;
+  f32x2 p = f32x2{-4.0375596e-07f, -4.0375596e-07f};
+  p = __builtin_elementwise_fma(p, t, f32x2{1.7119051e-05f, 1.7119051e-05f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-3.1437373e-04f, -3.1437373e-04f});
+  p = __builtin_elementwise_fma(p, t, f32x2{3.3201380e-03f, 3.3201380e-03f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-2.2705898e-02f, -2.2705898e-02f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.0779675e-01f, 1.0779675e-01f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-3.7335253e-01f, -3.7335253e-01f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.1279515e+00f, 1.1279515e+00f});
+  const f32x2 e = p * z;
+  return f32x2{__builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f), __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f)};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  const f32x2 h = x * f32x2{0.5f, 0.5f};
+  return __builtin_elementwise_fma(h, erf_poly2(x * f32x2{0.70710678118654752f, 0.70710678118654752f}), h);
+}
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  const f32x2 a = x * x * f32x2{-0.72134752044448170f, -0.72134752044448170f};           // -0.5 * log2(e) * x^2
+  const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} * f32x2{0.39894228040143268f, 0.39894228040143268f};
+  const f32x2 cdf = __builtin_elementwise_fma(erf_poly2(x * f32x2{0.70710678118654752f, 0.70710678118654752f}), f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
+  return __builtin_elementwise_fma(x, pdf, cdf);
 }
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.0f + erf_poly(x * 0.70710678118654752f));

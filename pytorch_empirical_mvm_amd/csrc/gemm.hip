@@ -226,15 +226,20 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
   if (p.act == 1) {
     if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack_bf8(v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
   } else if (p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if (p.act == 3 || p.act == 4) {
+  } else if (p.act == 3) {
     float u[8];
     unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n), u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= (p.act == 3) ? gelu_grad_f(u[e]) : (u[e] > 0.f ? 1.f : 0.f);
+    for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+  } else if (p.act == 4) {
+    float u[8];
+    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= (u[e] > 0.f ? 1.f : 0.f);
   }
   if (p.row_scale && !p.scale_bias_only) {
 #pragma unroll

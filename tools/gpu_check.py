@@ -578,6 +578,19 @@ def bench_ln():
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 10
             print(f"     {name:10s} {M}x{Cc}: {ms:.3f} ms  {nt * M * Cc * 2 / ms / 1e6:.0f} GB/s")
+    for (M, N) in [(55296, 3072), (55296, 768), (50176, 2048), (50176, 512), (802816, 512), (802816, 128)]:
+        x = rnd(M, N)
+        out = torch.zeros(N, device=dev)
+        rs = torch.ones(M // 392 + 1, device=dev)
+        for name, fn in (("colsum", lambda: K.colsum(x, out)), ("colsum rs", lambda: K.colsum(x, out, row_scale=rs, rows_per_scale=392))):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"     {name:10s} {M}x{N}: {ms:.3f} ms  {M * N * 2 / ms / 1e6:.0f} GB/s")
 
 
 if __name__ == "__main__":
