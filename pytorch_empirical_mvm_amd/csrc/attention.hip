@@ -107,6 +107,22 @@ __device__ __forceinline__ void fill_one(unsigned char* dst, int kv_bytes, const
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes), 16, goff, 0, 0, 0);
   }
 }
+// DMA helpers for kernels that precompute per-thread source offsets (0xffffffff: beyond the image -> skipped when `guard`)
+__device__ __forceinline__ void dma16_pair(unsigned char* dst, int img_bytes, const u16* src0, unsigned bytes0, uint32_t off0,
+                                           const u16* src1, unsigned bytes1, uint32_t off1, bool guard) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src0), 0, (int)bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src1), 0, (int)bytes1, 0x00020000);
+  if (!guard || off0 != 0xffffffffu) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_void*)dst, 16, off0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(dst + img_bytes), 16, off1, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void dma16_one(unsigned char* dst, const float* src, unsigned bytes, uint32_t off) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_void*)dst, 16, off, 0, 0, 0);
+}
 __device__ __forceinline__ void fill_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bf16x8 load_frag_global(const u16* p, bool valid) {
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -143,10 +159,12 @@ __device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) {
   typedef __attribute__((address_space(3))) const unsigned char lds_u8;
   return (uint32_t)(size_t)(lds_u8*)p;
 }
-__device__ __forceinline__ void tr_read4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1, uint32_t pa, uint32_t pc) {
-  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:1024\n\t"
-               "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:1024"
-               : "=&v"(a0), "=&v"(a1), "=&v"(c0), "=&v"(c1) : "v"(pa), "v"(pc) : "memory");
+__device__ __forceinline__ void tr_read4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1, uint32_t pa, uint32_t pc, const int off) {
+  // `off` must fold to a constant after inlining / unrolling: it becomes the instruction's immediate offset (one base VGPR
+  // per operand instead of one address VGPR per tile)
+  asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+               "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+               : "=&v"(a0), "=&v"(a1), "=&v"(c0), "=&v"(c1) : "v"(pa), "v"(pc), "i"(off), "i"(off + 1024) : "memory");
 }
 __device__ __forceinline__ void tr_wait4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
@@ -768,6 +786,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
     const unsigned char* kb = Ksm + k_off_swz<HD>(tbase * 16 + r, g);
     const unsigned char* tk0 = Ksm + k_off_swz<HD>(tbase * 16 + g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
     const unsigned char* tk1 = Ksm + k_off_swz<HD>(tbase * 16 + g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    const uint32_t tk0a = lds_addr(tk0), tk1a = lds_addr(tk1);
     // software pipeline over tile pairs: the K / V fragments of pair c+1 and the transposed K operand of pair c are requested
     // before the VALU work on pair c, so the LDS latency sits under the exp / multiply chain instead of in front of the MFMAs
     bf16x8 kf[2], vf[2];
@@ -795,7 +814,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
       // transposed K operand of this pair.  Inline asm, not the builtin: the compiler treats the builtin as "may alias the
       // in-flight LDS DMA" and puts s_waitcnt vmcnt(0) in front of it, i.e. drains the next sequence's K/V fill every pair.
       s16x4 a0, a1, c0, c1;
-      tr_read4(a0, a1, c0, c1, lds_addr(tk0 + c * 2048), lds_addr(tk1 + c * 2048));
+      tr_read4(a0, a1, c0, c1, tk0a, tk1a, c * 2048);
       if (c < NF && has_next)
         fill_one(dst_nx + c * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[c], c == NF - 1);
       if (c + 1 < NPH) {
@@ -1027,6 +1046,246 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   }
 }
 
+
+// ================================================================================================
+// backward B' (window mode, exact tile count): batch-persistent dK / dV, the transposed twin of attn_bwd_dq_win2_kernel.
+// A workgroup = (head, key group, chunk of window-major sequences); each of its 7 waves owns TWO key tiles whose K / V
+// fragments live in registers, and whose bias + shift-mask block against ALL query tiles is built once per window position
+// into packed-bf16 registers (the score MFMA's C operand).  Per sequence the Q / dO images plus lse / delta stream into the
+// other LDS buffer by direct-to-LDS DMA spread over the query-tile loop; the next sequence's K / V fragments are prefetched
+// into registers.  Per score element: unpack, fma + exp2, packed fma / mul, two bf16 conversions.
+// ================================================================================================
+template <int NX, bool MASK, int KT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_attn_bwd_desc pb, const int nkg, const int nch) {
+  constexpr int HD = 32, NPQ = (NX + 1) / 2;                            // NPQ query-tile pairs
+  constexpr int LP32 = NPQ * 32, IMG = LP32 * HD * 2;                   // rows / bytes of one Q or dO image
+  constexpr int LV = 512;                                               // floats reserved for lse / delta (L <= 512)
+  constexpr int BUF = 2 * IMG + 2 * LV * 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nkg);
+  const int kg = logical % nkg;
+  const int t1 = logical / nkg;
+  const int ch = t1 % nch;
+  const int h = t1 / nch;
+  const int tl4 = (p.table_len + 3) & ~3, lr4 = (L + 3) & ~3;
+  float* tabs = reinterpret_cast<float*>(smem + 2 * BUF);               // this head's bias-table column
+  int* rcs = reinterpret_cast<int*>(tabs + tl4);
+  unsigned char* regs = reinterpret_cast<unsigned char*>(rcs + lr4);    // region ids of the current window position
+  const int kp = kg * NWV + wave;                                       // key-tile pair of this wave
+  const bool active = kp * KT < NX;
+  int key[KT]; bool kv[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) { key[t] = (kp * KT + t) * 16 + r; kv[t] = active && key[t] < L; }
+
+  for (int i = tid; i < p.table_len; i += NWV * 64) tabs[i] = p.bias_table[(size_t)i * heads + h];
+  for (int i = tid; i < L; i += NWV * 64) rcs[i] = p.rc[i];
+  uint32_t bm[KT][NX][2];
+  auto build_bm = [&]() {                                 // bias + mask of (query tiles x this wave's keys), packed bf16 (from LDS)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int rck = rcs[kv[t] ? key[t] : 0] - p.rc0;
+      const int regk = MASK ? regs[kv[t] ? key[t] : 0] : 0;
+#pragma unroll
+      for (int qt = 0; qt < NX; ++qt) {
+        float b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = qt * 16 + g * 4 + j;
+          float b = NEG_INF;
+          if (kv[t] && q < L) {
+            b = tabs[rcs[q] - rck];
+            if (MASK) b += (regs[q] != regk) ? -100.f : 0.f;
+          }
+          b4[j] = b;
+        }
+        bm[t][qt][0] = pack_bf2(b4[0], b4[1]);
+        bm[t][qt][1] = pack_bf2(b4[2], b4[3]);
+      }
+    }
+  };
+
+  const int total = nWin * B;
+  const int per = (total + nch - 1) / nch;
+  const int b0 = ch * per, b1 = (b0 + per < total) ? b0 + per : total;
+  const int w0 = b0 / B;
+  int w_nx = w0, c_nx = b0 - w0 * B;                    // (window position, clip) of the NEXT sequence to request
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == B) { c_nx = 0; ++w_nx; } };
+  // per-lane constant offsets (elements) inside one sequence; per sequence only wave-uniform bases change
+  uint32_t off_k[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) off_k[t] = (uint32_t)key[t] * p.ld_qkv + h * HD + g * 8;
+  uint32_t off_dk[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) off_dk[t] = (uint32_t)key[t] * pb.ld_dqkv + h * HD + g * 4;
+  constexpr int NF = (LP32 * 4 + NWV * 64 - 1) / (NWV * 64);            // 16-byte DMA requests per thread per image
+  static_assert(NF + 1 <= NPQ, "the fill requests are spread over the query-tile pairs");
+  uint32_t goq[NF], god[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3, cs = (chs ^ ((row >> 2) & 3)) << 3;
+    goq[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + cs) * 2) : 0xffffffffu;
+    god[i] = (u < LP32 * 4) ? (uint32_t)((row * pb.ld_dout + cs) * 2) : 0xffffffffu;
+  }
+  const unsigned q_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2), do_bytes = (unsigned)(((size_t)(L - 1) * pb.ld_dout + HD) * 2);
+  // requests of the next sequence's images; step i in [0, NF) = image chunk i, step NF = lse (waves 0-1) / delta (waves 2-3)
+  auto dma_step = [&](size_t seq, int buf, int i) {
+    unsigned char* dst = smem + buf * BUF;
+    if (i < NF) {
+      const u16* qsrc = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + p.q_off + h * HD;
+      const u16* dsrc = reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout + h * HD;
+      dma16_pair(dst + (tid & ~63) * 16 + i * NWV * 64 * 16, IMG, qsrc, q_bytes, goq[i], dsrc, do_bytes, god[i], i == NF - 1);
+    } else if (wave < 4) {
+      const float* src = ((wave < 2) ? p.lse : pb.delta) + (seq * heads + h) * L;
+      dma16_one(dst + 2 * IMG + (wave >> 1) * LV * 4 + (wave & 1) * 1024, src, (unsigned)(L * 4), (uint32_t)(((wave & 1) * 64 + lane) * 16));
+    }
+  };
+  bf16x8 kf[KT], vf[KT];                                 // prefetched K / V fragments of the next sequence
+  float ss_n = 1.0f;
+  auto fetch = [&](size_t seq) {
+    const u16* qb = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      kf[t] = load_frag_global(qb + p.k_off + off_k[t], kv[t]);
+      vf[t] = load_frag_global(qb + p.v_off + off_k[t], kv[t]);
+    }
+    ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  };
+  if (b0 < b1) {
+#pragma unroll
+    for (int i = 0; i <= NF; ++i) dma_step(seq_nx(), 0, i);
+    fetch(seq_nx());
+    advance();
+  }
+
+  int wprev = -1, w_cu = w0, c_cu = b0 - w0 * B;        // (window position, clip) of the sequence being processed
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    fill_wait();
+    __syncthreads();                                      // sequence b landed for everyone; everyone left the other buffer
+    const int wcur = w_cu;
+    if (++c_cu == B) { c_cu = 0; ++w_cu; }
+    if (wcur != wprev) {                                  // (workgroup-uniform) new window position: rebuild the bias + mask block
+      wprev = wcur;
+      if (MASK) {
+        if (b > b0) __syncthreads();                      // everyone is done with the previous window's region row
+        for (int i = tid; i < L; i += NWV * 64) regs[i] = p.region[(size_t)wcur * L + i];
+        __syncthreads();
+      }
+      if (MASK || b == b0) build_bm();
+    }
+    bf16x8 ckf[KT], cvf[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { ckf[t] = kf[t]; cvf[t] = vf[t]; }
+    const float seq_scale = ss_n;
+    const bool has_next = b + 1 < b1;
+    const size_t sq_nx = seq_nx();
+    if (has_next) {
+      fetch(sq_nx);
+      advance();
+      if (!active) {
+#pragma unroll
+        for (int i = 0; i <= NF; ++i) dma_step(sq_nx, cur ^ 1, i);
+      }
+    }
+    if (!active) continue;
+    const unsigned char* Qs = smem + cur * BUF;
+    const unsigned char* dOs = Qs + IMG;
+    const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * IMG);
+    const float* delta_s = lse_s + LV;
+    f32x4 dk[KT][2], dv[KT][2];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x2 ss2 = {seq_scale, seq_scale};
+    asm volatile("" : "+v"(ss2));                         // real register pair (see attn_bwd_dq_win2_kernel)
+    // lane bases: every query tile is a compile-time immediate away (the chunk swizzle only depends on row % 16)
+    const unsigned char* qb_ = Qs + k_off_swz<HD>(r, g);
+    const unsigned char* tq0 = Qs + k_off_swz<HD>(g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
+    const unsigned char* tq1 = Qs + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    const uint32_t tq0a = lds_addr(tq0), tq1a = lds_addr(tq1);
+#pragma unroll
+    for (int c = 0; c < NPQ; ++c) {
+      uint32_t pw[KT][4], dw[KT][4];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { pw[t][x] = 0u; dw[t][x] = 0u; }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * c + u;
+        if (qt < NX) {
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qb_ + qt * 1024);
+          const bf16x8 dof = *reinterpret_cast<const bf16x8*>(qb_ + IMG + qt * 1024);
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + g * 4);
+          const float4 d4 = *reinterpret_cast<const float4*>(delta_s + qt * 16 + g * 4);
+          f32x2 nl[2] = {f32x2{-l4.x * LOG2E, -l4.y * LOG2E}, f32x2{-l4.z * LOG2E, -l4.w * LOG2E}};
+          f32x2 nd[2] = {f32x2{-d4.x, -d4.y}, f32x2{-d4.z, -d4.w}};
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            float b0f, b1f, b2f, b3f;                     // volatile: keeps the unpack inside the loop (else 4x the registers get hoisted)
+            asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b0f) : "v"(bm[t][qt][0]));
+            asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b1f) : "v"(bm[t][qt][0]));
+            asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b2f) : "v"(bm[t][qt][1]));
+            asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b3f) : "v"(bm[t][qt][1]));
+            const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, ckf[t], f32x4{b0f, b1f, b2f, b3f}, 0, 0, 0);
+            const f32x4 dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, cvf[t], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+              const f32x2 sv = {s4[2 * hj], s4[2 * hj + 1]}, dpv = {dp4[2 * hj], dp4[2 * hj + 1]};
+              const f32x2 e = __builtin_elementwise_fma(sv, f32x2{LOG2E, LOG2E}, nl[hj]);
+              const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+              const f32x2 d = pr * __builtin_elementwise_fma(dpv, ss2, nd[hj]);
+              pw[t][2 * u + hj] = pack_bf2v(pr);
+              dw[t][2 * u + hj] = pack_bf2v(d);
+            }
+          }
+        }
+      }
+      // transposed Q / dO operands of this query-tile pair (asm reads: see tr_read4)
+      s16x4 a0, a1, c0, c1, e0, e1, f0, f1;
+      tr_read4(a0, a1, c0, c1, tq0a, tq1a, c * 2048);
+      tr_read4(e0, e1, f0, f1, tq0a, tq1a, IMG + c * 2048);
+      if (c <= NF && has_next) dma_step(sq_nx, cur ^ 1, c);
+      tr_wait4(a0, a1, c0, c1);
+      tr_wait4(e0, e1, f0, f1);
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 q0v = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const s16x8 q1v = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      const s16x8 d0v = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+      const s16x8 d1v = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[t][0], pw[t][1], pw[t][2], pw[t][3]));
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(dw[t][0], dw[t][1], dw[t][2], dw[t][3]));
+        dv[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d0v), pf, dv[t][0], 0, 0, 0);
+        dv[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d1v), pf, dv[t][1], 0, 0, 0);
+        dk[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q0v), dsf, dk[t][0], 0, 0, 0);
+        dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q1v), dsf, dk[t][1], 0, 0, 0);
+      }
+    }
+    u16* dbase = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      if (kv[t]) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          *reinterpret_cast<uint2*>(dbase + off_dk[t] + p.k_off + dt * 16) = make_uint2(pack_bf2(dk[t][dt][0], dk[t][dt][1]), pack_bf2(dk[t][dt][2], dk[t][dt][3]));
+          *reinterpret_cast<uint2*>(dbase + off_dk[t] + p.v_off + dt * 16) =
+              make_uint2(pack_bf2(dv[t][dt][0] * seq_scale, dv[t][dt][1] * seq_scale), pack_bf2(dv[t][dt][2] * seq_scale, dv[t][dt][3] * seq_scale));
+        }
+      }
+    }
+  }
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes > 160 * 1024) return VMVM_ENOSUPPORT;
@@ -1158,7 +1417,35 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     else if (s_.nt <= 16) LAUNCH_DQW(16, 0, true);
     else LAUNCH_DQW(28, 0, true);
     VMVM_CHECK_LAUNCH();
-    LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2);
+    {
+      // dK / dV: batch-persistent kernel for the step's exact window shapes, generic per-(sequence, head) kernel otherwise
+      const int npq = (s_.nt + 1) / 2, img = npq * 32 * 64;
+      const int smem3 = 2 * (2 * img + 2 * 512 * 4) + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
+      const bool dkv_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && d->f.L <= 512 && smem3 <= 160 * 1024;
+      if (dkv_ok) {
+        // key tiles per wave: 2 for the 196-token window (K / V register fragments serve twice the MFMAs per LDS read); 1 for
+        // the 392-token window, where two tiles' bias blocks (100 VGPRs) spill -- measured 12% slower than one tile per wave
+        const int kt_ = s_.nt == 25 ? 1 : 2, nw_ = 7;
+        const int nkg = (s_.nt + kt_ * nw_ - 1) / (kt_ * nw_);
+        const int base = d->f.heads * nkg;
+        int nch = 1; float best = 1e30f;
+        for (int c = 1; c <= 64 && c <= d->f.nseq; ++c) {
+          const float cost = (float)((base * c + 255) / 256) * ((float)((d->f.nseq + c - 1) / c) + 3.f);
+          if (cost < best - 1e-6f) { best = cost; nch = c; }
+        }
+#define LAUNCH_DKV2_(NX, MASK, KT, NWV)                                                                              \
+        do {                                                                                                        \
+          int rc_ = set_smem(attn_bwd_dkv_win2_kernel<NX, MASK, KT, NWV>, smem3);                                    \
+          if (rc_) return rc_;                                                                                      \
+          hipLaunchKernelGGL((attn_bwd_dkv_win2_kernel<NX, MASK, KT, NWV>), dim3(base * nch), dim3(NWV * 64), smem3, st, *d, nkg, nch); \
+        } while (0)
+        if (s_.nt == 25) { if (mask) LAUNCH_DKV2_(25, true, 1, 7); else LAUNCH_DKV2_(25, false, 1, 7); }
+        else { if (mask) LAUNCH_DKV2_(13, true, 2, 7); else LAUNCH_DKV2_(13, false, 2, 7); }
+        VMVM_CHECK_LAUNCH();
+      } else {
+        LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2);
+      }
+    }
   } else {
     LAUNCH_BWD_DQ(64, 1, 8);
     LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2);
