@@ -604,6 +604,185 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_win_kernel(const vmvm_att
 }
 
 // ================================================================================================
+// forward (window mode, exact tile count): batch-persistent twin of the backward kernels above.  A workgroup = (head, query
+// group, chunk of window-major sequences); each of its 7 waves owns one query tile, holds the whole 16 x L score block in
+// accumulators (exact two-pass softmax) and keeps the bias + shift-mask block as packed-bf16 registers feeding the score MFMA's
+// C operand.  K / V of the next sequence stream into the other LDS buffer (DMA requests spread over the tile loop).
+// ================================================================================================
+template <int NX, bool MASK>
+__global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_desc p, const int nqg, const int nch) {
+  constexpr int HD = 32, NWV = 7, NPK = (NX + 1) / 2;                   // NPK key-tile pairs
+  constexpr int LP32 = NPK * 32, KV = LP32 * HD * 2;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nqg);
+  const int qg = logical % nqg;
+  const int t1 = logical / nqg;
+  const int ch = t1 % nch;
+  const int h = t1 / nch;
+  const int tl4 = (p.table_len + 3) & ~3, lr4 = (L + 3) & ~3;
+  float* tabs = reinterpret_cast<float*>(smem + 4 * KV);                // this head's bias-table column
+  int* rcs = reinterpret_cast<int*>(tabs + tl4);
+  unsigned char* regs = reinterpret_cast<unsigned char*>(rcs + lr4);    // region ids of the current window position
+  const int qt = qg * NWV + wave;
+  const int q = qt * 16 + r;
+  const bool active = qt < NX;
+  const bool qv = active && (q < L);
+
+  for (int i = tid; i < p.table_len; i += NWV * 64) tabs[i] = p.bias_table[(size_t)i * heads + h];
+  for (int i = tid; i < L; i += NWV * 64) rcs[i] = p.rc[i];
+  uint32_t bm[NX * 2];
+  auto build_bm = [&]() {                                 // bias + shift mask of this wave's score block, packed bf16 (from LDS)
+    const int rcq = rcs[qv ? q : 0] + p.rc0;
+    const int regq = MASK ? regs[qv ? q : 0] : 0;
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      float b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = t * 16 + g * 4 + j;
+        float b = NEG_INF;
+        if (key < L) {
+          b = tabs[rcq - rcs[key]];
+          if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+        }
+        b4[j] = b;
+      }
+      bm[2 * t] = pack_bf2(b4[0], b4[1]);
+      bm[2 * t + 1] = pack_bf2(b4[2], b4[3]);
+    }
+  };
+
+  const int total = nWin * B;
+  const int per = (total + nch - 1) / nch;
+  const int b0 = ch * per, b1 = (b0 + per < total) ? b0 + per : total;
+  const int w0 = b0 / B;
+  int w_nx = w0, c_nx = b0 - w0 * B;                    // (window position, clip) of the NEXT sequence to request
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == B) { c_nx = 0; ++w_nx; } };
+  const uint32_t off_q = (uint32_t)q * p.ld_qkv + p.q_off + h * HD + g * 8;
+  const uint32_t off_o = (uint32_t)q * p.ld_out + h * HD + g * 4;
+  const uint32_t off_ls = (uint32_t)h * L + q;
+  constexpr int NF = (LP32 * 4 + NWV * 64 - 1) / (NWV * 64);            // 16-byte DMA requests per thread per image
+  static_assert(NF <= NX, "the fill requests are spread over the key tiles");
+  uint32_t goff[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
+    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ ((row >> 2) & 3)) << 3)) * 2) : 0xffffffffu;
+  }
+  const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
+  bf16x8 qf;
+  float ss_n = 1.0f;
+  auto fetch = [&](size_t seq) {
+    qf = load_frag_global(reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + off_q, qv);
+    ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  };
+  if (b0 < b1) {
+    const u16* kv0 = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    fill_pre<NF, NWV * 64 * 16>(smem + (tid & ~63) * 16, KV, kv0 + p.k_off, kv0 + p.v_off, fill_bytes, goff);
+    fetch(seq_nx());
+    advance();
+  }
+
+  int wprev = -1, w_cu = w0, c_cu = b0 - w0 * B;        // (window position, clip) of the sequence being processed
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    fill_wait();
+    __syncthreads();                                      // sequence b landed for everyone; everyone left the other buffer
+    const int wcur = w_cu;
+    if (++c_cu == B) { c_cu = 0; ++w_cu; }
+    if (wcur != wprev) {                                  // (workgroup-uniform) new window position: rebuild the bias + mask block
+      wprev = wcur;
+      if (MASK) {
+        if (b > b0) __syncthreads();                      // everyone is done with the previous window's region row
+        for (int i = tid; i < L; i += NWV * 64) regs[i] = p.region[(size_t)wcur * L + i];
+        __syncthreads();
+      }
+      if (MASK || b == b0) build_bm();
+    }
+    const bf16x8 cqf = qf;
+    const float seq_scale = ss_n;
+    const bool has_next = b + 1 < b1;
+    const u16* kv_nx = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    unsigned char* dst_nx = smem + (cur ^ 1) * 2 * KV + (tid & ~63) * 16;
+    if (has_next) {
+      fetch(seq_nx());
+      advance();
+      if (!active) fill_pre<NF, NWV * 64 * 16>(dst_nx, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff);
+    }
+    if (!active) continue;
+    const unsigned char* Ksm = smem + cur * 2 * KV;
+    const unsigned char* kb = Ksm + k_off_swz<HD>(r, g);
+    const unsigned char* tv0 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
+    const unsigned char* tv1 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    const uint32_t tv0a = lds_addr(tv0), tv1a = lds_addr(tv1);
+    // pass 1: scores (+ bias through the C operand) for the whole row block, running maximum
+    f32x4 acc[NX];
+    float mx = NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      float b0f, b1f, b2f, b3f;                           // volatile: keeps the unpack next to its MFMA (else 4*NX VGPRs get hoisted)
+      asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b0f) : "v"(bm[2 * t]));
+      asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b1f) : "v"(bm[2 * t]));
+      asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b2f) : "v"(bm[2 * t + 1]));
+      asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b3f) : "v"(bm[2 * t + 1]));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 1024), cqf, f32x4{b0f, b1f, b2f, b3f}, 0, 0, 0);
+      if (t < NF && has_next) fill_one(dst_nx + t * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[t], t == NF - 1);
+    }
+#pragma unroll
+    for (int t = 0; t < NX; ++t) mx = fmaxf(fmaxf(mx, fmaxf(acc[t][0], acc[t][1])), fmaxf(acc[t][2], acc[t][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    f32x2 nm2 = {-mx * LOG2E, -mx * LOG2E};
+    asm volatile("" : "+v"(nm2));                         // real register pair (see attn_bwd_dq_win2_kernel)
+    // pass 2: p = exp2((s - max) * log2 e), row sum, P V with P as the B operand (the MFMA k-slot order is free)
+    f32x2 sum2 = {0.f, 0.f};
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < NPK; ++c) {
+      s16x4 a0, a1, c0, c1;
+      tr_read4(a0, a1, c0, c1, tv0a, tv1a, c * 2048);
+      uint32_t pw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * c + u;
+        if (t < NX) {
+#pragma unroll
+          for (int hj = 0; hj < 2; ++hj) {
+            const f32x2 e = __builtin_elementwise_fma(f32x2{acc[t][2 * hj], acc[t][2 * hj + 1]}, f32x2{LOG2E, LOG2E}, nm2);
+            const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            sum2 += pr;
+            pw[2 * u + hj] = pack_bf2v(pr);
+          }
+        }
+      }
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+      tr_wait4(a0, a1, c0, c1);
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const s16x8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), pf, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), pf, o[1], 0, 0, 0);
+    }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (qv) {
+      const float inv = seq_scale / sum;
+      u16* op = reinterpret_cast<u16*>(p.out) + seq * L * p.ld_out + off_o;
+      *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf2(o[0][0] * inv, o[0][1] * inv), pack_bf2(o[0][2] * inv, o[0][3] * inv));
+      *reinterpret_cast<uint2*>(op + 16) = make_uint2(pack_bf2(o[1][0] * inv, o[1][1] * inv), pack_bf2(o[1][2] * inv, o[1][3] * inv));
+      if (g == 0) (p.lse + seq * heads * L)[off_ls] = mx + __builtin_amdgcn_logf(sum) * LN2;
+    }
+  }
+}
+
+// ================================================================================================
 // backward A'' (window mode, exact tile count): persistent over the BATCH for a fixed (window position, head, query tile).
 // Relative-position bias + shift mask of a wave's score block are constant across clips, so they are built ONCE into registers
 // (packed bf16) and the per-clip work per score element drops to: add, fma+exp2, fma+mul, accumulate.  K/V of the next clip
@@ -1326,7 +1505,29 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   const int nb = d->nseq * d->heads;
   const bool mask = d->region != nullptr;
   if (d->mode == 0) {
-    if (sm.nt == 25) { if (mask) LAUNCH_FWD(32, 0, 26, 4, 25, true); else LAUNCH_FWD(32, 0, 26, 4, 25, false); }
+    // batch-persistent kernel for the step's exact window shapes (392 / 196 tokens); per-(sequence, head) kernel otherwise
+    const int nwin = d->n_win > 0 ? d->n_win : 1;
+    const int npk = (sm.nt + 1) / 2, tl4 = (d->table_len + 3) & ~3, lr4 = (d->L + 3) & ~3;
+    const int smem2 = 4 * npk * 32 * 64 + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
+    const bool pers_ok = (d->nseq % nwin == 0) && (sm.nt == 25 || sm.nt == 13) && d->dropout_p == 0.f && smem2 <= 160 * 1024;
+    if (pers_ok) {
+      const int nqg = (sm.nt + 6) / 7;
+      const int base = d->heads * nqg;
+      int nch = 1; float best = 1e30f;
+      for (int c = 1; c <= 64 && c <= d->nseq; ++c) {
+        const float cost = (float)((base * c + 255) / 256) * ((float)((d->nseq + c - 1) / c) + 3.f);
+        if (cost < best - 1e-6f) { best = cost; nch = c; }
+      }
+#define LAUNCH_FWD2(NX, MASK)                                                                                        \
+      do {                                                                                                           \
+        int rc_ = set_smem(attn_fwd_win2_kernel<NX, MASK>, smem2);                                                    \
+        if (rc_) return rc_;                                                                                         \
+        hipLaunchKernelGGL((attn_fwd_win2_kernel<NX, MASK>), dim3(base * nch), dim3(448), smem2, st, *d, nqg, nch);    \
+      } while (0)
+      if (sm.nt == 25) { if (mask) LAUNCH_FWD2(25, true); else LAUNCH_FWD2(25, false); }
+      else { if (mask) LAUNCH_FWD2(13, true); else LAUNCH_FWD2(13, false); }
+    }
+    else if (sm.nt == 25) { if (mask) LAUNCH_FWD(32, 0, 26, 4, 25, true); else LAUNCH_FWD(32, 0, 26, 4, 25, false); }
     else if (sm.nt == 13) { if (mask) LAUNCH_FWD(32, 0, 14, 4, 13, true); else LAUNCH_FWD(32, 0, 14, 4, 13, false); }
     else if (sm.nt <= 16) LAUNCH_FWD(32, 0, 16, 4, 0, true);
     else LAUNCH_FWD(32, 0, 28, 4, 0, true);

@@ -207,58 +207,66 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
 // read pieces are free to permute) so that a lane's accumulators of an MFMA tile PAIR are 8 CONSECUTIVE output columns:
 // one 16-byte bf16 store (two for f32) instead of two 8-byte ones, and 16/32-byte bias / residual / aux loads.  The bf16
 // epilogue was store-ISSUE bound: f32 output (2x the bytes, same instruction count) cost only +15% on HBM-bound shapes.
-__device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid) {
-  if (nvalid < 8) {                                      // N % 8 == 4 edge: fall back to the 4-wide path
+// Epilogue feature mask: the persistent kernel is instantiated per mask so that each instantiation carries only the code of the
+// features its problems use.  (One generic epilogue inlined at 8 call sites is ~9000 instructions; streaming that through the
+// instruction cache every tile cost 10-25% on the short-K shapes of this model.)  EF_ALL = everything, any descriptor.
+enum : int { EF_BIAS = 1, EF_COLSCALE = 2, EF_ACT1 = 4, EF_ACT24 = 8, EF_ACT3 = 16, EF_RS = 32, EF_DROP = 64, EF_RESID = 128,
+             EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095 };
+template <int F>
+__device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid,
+                                           const float (&bz)[8], const uint4& auxv, const uint4& resv) {
+  // bz / auxv / resv: bias, saved activation and residual of this fragment, requested by the caller BEFORE the tile's first
+  // store (loads cannot be hoisted over stores by the compiler: the pointers may alias)
+  if ((F & EF_EDGE4) && nvalid < 8) {                    // N % 8 == 4 edge: fall back to the 4-wide path
     float a[4] = {v[0], v[1], v[2], v[3]};
     epi_store(p, e_, a, m, dst, n, rs);
     return;
   }
-  if (p.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-    const float bs = p.scale_bias_only ? rs : 1.0f;
-    v[0] += b0.x * bs; v[1] += b0.y * bs; v[2] += b0.z * bs; v[3] += b0.w * bs;
-    v[4] += b1.x * bs; v[5] += b1.y * bs; v[6] += b1.z * bs; v[7] += b1.w * bs;
+  if ((F & EF_BIAS) && p.bias) {
+    const float bs = ((F & EF_RS) && p.scale_bias_only) ? rs : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(bz[e], bs, v[e]);
   }
-  if (n < p.col_scale_n) {                               // col_scale_n is a multiple of 8 for every caller (C of qkv)
+  if ((F & EF_COLSCALE) && n < p.col_scale_n) {          // col_scale_n is a multiple of 8 for every caller (C of qkv)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
   }
-  if (p.act == 1) {
+  if ((F & EF_ACT1) && p.act == 1) {
     if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack_bf8(v);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
-  } else if (p.act == 2) {
+  } else if ((F & EF_ACT24) && p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if (p.act == 3) {
+  } else if ((F & EF_ACT3) && p.act == 3) {
     float u[8];
-    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n), u);
+    unpack_bf8(auxv, u);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
-  } else if (p.act == 4) {
+  } else if ((F & EF_ACT24) && p.act == 4) {
     float u[8];
-    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n), u);
+    unpack_bf8(auxv, u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= (u[e] > 0.f ? 1.f : 0.f);
   }
-  if (p.row_scale && !p.scale_bias_only) {
+  if ((F & EF_RS) && p.row_scale && !p.scale_bias_only) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= rs;
   }
-  if (e_.has_drop) {
+  if ((F & EF_DROP) && e_.has_drop) {
     const uint64_t e4 = ((uint64_t)m * (uint64_t)e_.N + (uint64_t)n) >> 2;
     const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
     const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = bits[e] < e_.thr ? 0.f : v[e] * e_.keep_scale;
   }
-  if (p.resid) {
+  if ((F & EF_RESID) && p.resid) {
     float rr[8];
-    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)dst * p.ldr + n), rr);
+    unpack_bf8(resv, rr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += rr[e];
   }
-  if (e_.S > 1) {
+  if ((F & EF_SPLIT) && e_.S > 1) {
     if (p.workspace) {
       float* c = reinterpret_cast<float*>(p.workspace) + ((size_t)e_.slice * e_.M + dst) * e_.N + n;
       *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
@@ -268,7 +276,7 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
 #pragma unroll
       for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
     }
-  } else if (p.out_fp32) {
+  } else if ((F & EF_F32) && p.out_fp32) {
     float* c = reinterpret_cast<float*>(p.C) + (size_t)dst * p.ldc + n;
     if (p.accumulate) {
       const float4 o0 = *reinterpret_cast<const float4*>(c), o1 = *reinterpret_cast<const float4*>(c + 4);
@@ -817,7 +825,7 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // stage 1/2: K = 128..512, i.e. 2..8 K tiles) are otherwise dominated by the load latency of the prologue and by store
 // phases during which nothing is in flight (measured 1.8-2.2 TB/s on HBM-bound shapes = half of what the copy rate allows).
 // =====================================================================================================================
-template <bool AK, bool BKM>
+template <bool AK, bool BKM, int F>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -919,23 +927,52 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     ec.slice = slice;
     // (An LDS-staged, 16-byte-per-lane coalesced epilogue was measured here: correct but 1.4-1.7x SLOWER on every shape --
     //  two extra barriers and an LDS round trip per tile cost more than the 32-byte store fragments; kept direct.)
+    // epilogue in three passes: row bookkeeping, ALL loads of the tile (bias, saved activation, residual), then math + stores
+    bool rvalid[4]; long rdst[4]; float rrs[4];
 #pragma clang loop unroll(full)
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + i * 16 + r;
       bool valid = m < M;
       long dst = m;
-      if (valid && p.row_map) {
+      if ((F & EF_MAP) && valid && p.row_map) {
         const int mapped = p.row_map[m % p.map_len];
         valid = mapped >= 0;
         dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
       }
-      const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      rvalid[i] = valid; rdst[i] = dst;
+      rrs[i] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    }
+    float bz[2][8];
+    uint4 auxv[4][2], resv[4][2];
+#pragma clang loop unroll(full)
+    for (int jb = 0; jb < 2; ++jb) {
+      const int n = n0 + wn * 64 + jb * 32 + g * 8;
+      const bool full = n + 8 <= N;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bz[jb][e] = 0.f;
+      if ((F & EF_BIAS) && p.bias && full) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bz[jb][0] = b0.x; bz[jb][1] = b0.y; bz[jb][2] = b0.z; bz[jb][3] = b0.w; bz[jb][4] = b1.x; bz[jb][5] = b1.y; bz[jb][6] = b1.z; bz[jb][7] = b1.w;
+      }
+#pragma clang loop unroll(full)
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        auxv[i][jb] = make_uint4(0, 0, 0, 0); resv[i][jb] = make_uint4(0, 0, 0, 0);
+        if ((F & (EF_ACT3 | EF_ACT24)) && p.act >= 3 && rvalid[i] && full)
+          auxv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+        if ((F & EF_RESID) && p.resid && rvalid[i] && full)
+          resv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)rdst[i] * p.ldr + n);
+      }
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + r;
 #pragma clang loop unroll(full)
       for (int jb = 0; jb < 2; ++jb) {
         const int n = n0 + wn * 64 + jb * 32 + g * 8;
         float v[8] = {acc[i][2 * jb][0], acc[i][2 * jb][1], acc[i][2 * jb][2], acc[i][2 * jb][3],
                       acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
-        if (valid && n < N) epi_store8(p, ec, v, m, dst, n, rs, N - n);
+        if (rvalid[i] && n < N) epi_store8<F>(p, ec, v, m, rdst[i], n, rrs[i], N - n, bz[jb], auxv[i][jb], resv[i][jb]);
       }
     }
     if (!more) break;
@@ -943,17 +980,17 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   }
 }
 
-template <bool AK, bool BKM>
-int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
+template <bool AK, bool BKM, int F>
+int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
   const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * (d.splitk > 1 ? d.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr_done = true;
   }
   int grid = 512;                                       // 2 workgroups per CU (64 KiB LDS each), multiple of 8
   if (items < grid) grid = ((items + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
     const long n = (long)d.M * (d.N >> 2);
@@ -962,6 +999,44 @@ int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
+}
+
+// epilogue features this descriptor needs (see EF_*)
+static int epi_need(const vmvm_gemm_desc& d) {
+  int f = 0;
+  if (d.bias) f |= EF_BIAS;
+  if (d.col_scale_n > 0) f |= EF_COLSCALE;
+  if (d.act == 1) f |= EF_ACT1;
+  if (d.act == 2 || d.act == 4) f |= EF_ACT24;
+  if (d.act == 3) f |= EF_ACT3;
+  if (d.row_scale) f |= EF_RS;
+  if (d.dropout_p > 0.f) f |= EF_DROP;
+  if (d.resid) f |= EF_RESID;
+  if (d.splitk > 1) f |= EF_SPLIT;
+  if (d.out_fp32) f |= EF_F32;
+  if (d.row_map) f |= EF_MAP;
+  if (d.N & 7) f |= EF_EDGE4;
+  return f;
+}
+
+// The instantiations cover the epilogue classes of the training step (plain; qkv = bias + q scale; fc1 = bias + GELU + saved
+// pre-activation; fc2 dgrad = GELU' x saved; proj / fc2 = bias + dropout + residual (+ window un-gather); wgrad = f32 split-K)
+// and fall back to the all-features build for anything else.
+template <bool AK, bool BKM>
+int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int need = epi_need(d);
+#define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_pers_f<AK, BKM, (MASK)>(d, st)
+  if constexpr (AK && BKM) {
+    TRY_EPI(0);
+    TRY_EPI(EF_BIAS | EF_COLSCALE | EF_RS);
+    TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS);
+    TRY_EPI(EF_ACT3 | EF_RS);
+    TRY_EPI(EF_BIAS | EF_RESID | EF_DROP | EF_RS | EF_MAP);
+  } else if constexpr (!AK && !BKM) {
+    TRY_EPI(EF_SPLIT | EF_F32);
+  }
+#undef TRY_EPI
+  return launch_pers_f<AK, BKM, EF_ALL>(d, st);
 }
 
 }  // namespace
