@@ -888,40 +888,51 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
       const int cur = it & 1;
-      if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
-      else if (more) issue(nm0, nn0, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
       const unsigned char* la = smem + cur * 2 * TILE_BYTES;
       const unsigned char* lb = la + TILE_BYTES;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 fa[4], fb[4];
-        s16x4 alo[4], ahi[4], blo[4], bhi[4];
+      // software pipeline over the two 32-wide k-slices: slice 0's fragment reads go out right after the barrier (ahead of the
+      // next tile's DMA requests), slice 1's reads are issued before slice 0's MFMAs so their LDS latency sits under the MFMAs
+      bf16x8 fa[2][4], fb[2][4];
+      s16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+      auto load_set = [&](int s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (AK) fa[i] = read_frag<true, true>(la, wm * 4 + i, s, lane);
-          else tr_issue_frag(la, wm * 4 + i, s, lane, alo[i], ahi[i]);
+          if (AK) fa[s][i] = read_frag<true, true>(la, wm * 4 + i, s, lane);
+          else tr_issue_frag(la, wm * 4 + i, s, lane, alo[s][i], ahi[s][i]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (BKM) fb[j] = read_frag_bperm<true>(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane);
-          else tr_issue_bperm(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane, blo[j], bhi[j]);
+          if (BKM) fb[s][j] = read_frag_bperm<true>(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane);
+          else tr_issue_bperm(lb, wn * 64 + (j >> 1) * 32, j & 1, s, lane, blo[s][j], bhi[s][j]);
         }
+      };
+      auto finish_set = [&](int s) {                      // transposing (asm) reads: wait + assemble; k-major reads: compiler-managed
         if (!AK) {
-          tr_wait8(alo, ahi);
+          tr_wait8(alo[s], ahi[s]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) fa[i] = tr_cat(alo[i], ahi[i]);
+          for (int i = 0; i < 4; ++i) fa[s][i] = tr_cat(alo[s][i], ahi[s][i]);
         }
         if (!BKM) {
-          tr_wait8(blo, bhi);
+          tr_wait8(blo[s], bhi[s]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) fb[j] = tr_cat(blo[j], bhi[j]);
+          for (int j = 0; j < 4; ++j) fb[s][j] = tr_cat(blo[s][j], bhi[s][j]);
         }
+      };
+      auto mfma_set = [&](int s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+      };
+      load_set(0);
+      if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
+      else if (more) issue(nm0, nn0, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
+      finish_set(0);
+      load_set(1);
+      mfma_set(0);
+      finish_set(1);
+      mfma_set(1);
       ++it;
     }
     ec.slice = slice;
