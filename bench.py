@@ -24,10 +24,10 @@ TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
 # HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_roofline_gemm.txt):
-# FETCH_SIZE 3.86e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.70e5 KiB.
+# FETCH_SIZE 3.94e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.39e5 KiB.
 # Algorithmic bytes: A 106 MB + W 4.7 MB + C 425 MB + pre-activation 425 MB = 0.96 GB; the excess read traffic is the
 # 4.7 MB weight panel re-streamed through the 4 MiB L2 (served by the Infinity Cache), 1.17 GB before the tile rasterisation.
-ROOFLINE_TRAFFIC_BYTES = int((2 * 3.86e5 + 8.70e5) * 1024)
+ROOFLINE_TRAFFIC_BYTES = int((2 * 3.94e5 + 8.39e5) * 1024)
 
 
 def synth_batch(args, B, device, seed):
@@ -186,7 +186,7 @@ def main():
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4),
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4), "traffic": ROOFLINE_TRAFFIC_BYTES,
-                     "kernel": "gemm_pers_kernel<k-major,k-major> fusion FFN fc1+bias+GELU (M=69120,N=3072,K=768), 2*M*N*K flop per launch"},
+                     "kernel": "gemm_pers_kernel<k-major,k-major,F=bias|GELU|rowscale> fusion FFN fc1+bias+GELU (M=69120,N=3072,K=768), 2*M*N*K flop per launch"},
         "losses_last_step": last,
     }
     if world == 1 and not a.no_cpu_baseline:
