@@ -177,6 +177,18 @@ __device__ __forceinline__ uint4 drop_block(uint64_t seed, uint64_t offset, uint
   return philox4x32_7(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0xa77eu, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
 }
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+// The four lanes of a quad (4 consecutive query rows in the forward / dQ layout, 4 consecutive keys in the dK/dV layout) need the
+// SAME 4x4 block of random bytes for a tile, so one Philox evaluation per tile wastes 3/4 of the wave's work.  Instead quad lane i
+// evaluates the block of tile t0+i (one Philox call per FOUR tiles) and the quad reads it back with a DPP quad broadcast.
+template <int I>
+__device__ __forceinline__ uint4 quad_bcast(const uint4& b) {
+  constexpr int ctrl = I | (I << 2) | (I << 4) | (I << 6);             // quad_perm:[I,I,I,I]
+  return make_uint4((uint32_t)__builtin_amdgcn_mov_dpp((int)b.x, ctrl, 0xf, 0xf, false), (uint32_t)__builtin_amdgcn_mov_dpp((int)b.y, ctrl, 0xf, 0xf, false),
+                    (uint32_t)__builtin_amdgcn_mov_dpp((int)b.z, ctrl, 0xf, 0xf, false), (uint32_t)__builtin_amdgcn_mov_dpp((int)b.w, ctrl, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint4 quad_bcast_i(const uint4& b, int i) {   // i is a constant after unrolling
+  return i == 0 ? quad_bcast<0>(b) : i == 1 ? quad_bcast<1>(b) : i == 2 ? quad_bcast<2>(b) : quad_bcast<3>(b);
+}
 
 // ================================================================================================
 // forward
@@ -290,10 +302,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     sum += __shfl_xor(sum, 32, 64);
     if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = mx + __logf(sum);
     if (has_drop) {
+      uint4 own = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
+        if ((t & 3) == 0 && TILE_ON(t))                   // quad lane i: block of tile t+i  (block id = (sequence-head, q/4, key/4))
+          own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g));
         if (TILE_ON(t)) {
-          const uint4 blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)(t * 4 + g));
+          const uint4 blk = quad_bcast_i(own, t & 3);
           const uint32_t w = u4_get(blk, q & 3);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
@@ -401,6 +416,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint4 own = make_uint4(0, 0, 0, 0);               // quad-shared dropout block (see quad_bcast)
     for (int c = 0; c < nt2; ++c) {
       float ds[2][4];
 #pragma unroll
@@ -421,7 +437,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
           const int key0 = t * 16 + g * 4;
           uint32_t w = 0;
           if (has_drop) {
-            const uint4 blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)(t * 4 + g));
+            if ((t & 3) == 0) own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g));
+            const uint4 blk = (c & 1) ? (u ? quad_bcast<3>(own) : quad_bcast<2>(own)) : (u ? quad_bcast<1>(own) : quad_bcast<0>(own));
             w = u4_get(blk, q & 3);
           }
           if (MODE == 0) {
@@ -1129,6 +1146,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
       for (int dt = 0; dt < HD / 16; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
 
+    uint4 own[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) own[t] = make_uint4(0, 0, 0, 0);
     for (int c = 0; c < nt2; ++c) {
       float pt[KT][2][4], ds[KT][2][4];
 #pragma unroll
@@ -1177,7 +1197,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
               uint4 blk = make_uint4(0, 0, 0, 0);
-              if (has_drop) blk = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q0 >> 2), (uint32_t)(key[t] >> 2));
+              if (has_drop) {                               // quad lane i evaluates the block of query tile (qt & ~3) + i
+                if ((qt & 3) == 0) own[t] = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)((qt + (lane & 3)) * 4 + g), (uint32_t)(key[t] >> 2));
+                blk = (c & 1) ? (u ? quad_bcast<3>(own[t]) : quad_bcast<2>(own[t])) : (u ? quad_bcast<1>(own[t]) : quad_bcast<0>(own[t]));
+              }
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float pr = (kv[t] && regk[t]) ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
