@@ -67,6 +67,9 @@ typedef struct {
   int32_t splitk;         /* 0 = auto (split the reduction when C is a plain f32 accumulator), 1 = off, >1 = K slices */
   void* workspace; int64_t workspace_bytes;   /* optional caller-owned scratch for split-K slabs (splitk*M*N f32); without it
                                                  the slices combine with f32 atomics */
+  float* colsum;          /* optional, a_kmajor=0 only: colsum[m] += sum_k A(m,k)  (f32 [M]).  The bias gradient of a Linear is the
+                             column sum of dY, and dY is the A operand of its weight-gradient GEMM dW = dY^T X: fused, the extra
+                             pass over dY (vmvm_colsum_bf16) disappears into one more MFMA per fragment on the first N tile. */
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 

@@ -211,7 +211,8 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
 // features its problems use.  (One generic epilogue inlined at 8 call sites is ~9000 instructions; streaming that through the
 // instruction cache every tile cost 10-25% on the short-K shapes of this model.)  EF_ALL = everything, any descriptor.
 enum : int { EF_BIAS = 1, EF_COLSCALE = 2, EF_ACT1 = 4, EF_ACT24 = 8, EF_ACT3 = 16, EF_RS = 32, EF_DROP = 64, EF_RESID = 128,
-             EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095 };
+             EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095,
+             EF_COLSUM = 4096 /* fused column sum of the m-major A operand (not part of EF_ALL: only the wgrad build carries it) */ };
 template <int F>
 __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid,
                                            const float (&bz)[8], const uint4& auxv, const uint4& resv) {
@@ -880,6 +881,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fused column sum (bias gradient): on the first N tile the wn == 0 waves also multiply their A fragments with an all-ones
+    // operand; every row of that product is sum_k A(m,k) for the lane's column m
+    f32x4 cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = (F & EF_COLSUM) && p.colsum && n0 == 0 && wn == 0;
     const int wn_ = w + per_xcd;
     const bool more = wn_ < x_cnt;
     int nslice = 0, nm0 = 0, nn0 = 0, nkt0 = 0, nnk = 0;
@@ -924,6 +931,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+        if ((F & EF_COLSUM) && do_cs) {
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 o8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};      // bf16 1.0
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o8), fa[s][i], cs[i], 0, 0, 0);
+        }
       };
       load_set(0);
       if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
@@ -938,6 +951,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     ec.slice = slice;
     // (An LDS-staged, 16-byte-per-lane coalesced epilogue was measured here: correct but 1.4-1.7x SLOWER on every shape --
     //  two extra barriers and an LDS round trip per tile cost more than the 32-byte store fragments; kept direct.)
+    if ((F & EF_COLSUM) && do_cs && g == 0) {            // lanes 0-15: column m = m0 + wm*64 + i*16 + r (all 16 rows of the product are equal)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        if (m < M) atomicAdd(p.colsum + m, cs[i][0]);
+      }
+    }
     // epilogue in three passes: row bookkeeping, ALL loads of the tile (bias, saved activation, residual), then math + stores
     bool rvalid[4]; long rdst[4]; float rrs[4];
 #pragma clang loop unroll(full)
@@ -1044,7 +1064,8 @@ int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
     TRY_EPI(EF_ACT3 | EF_RS);
     TRY_EPI(EF_BIAS | EF_RESID | EF_DROP | EF_RS | EF_MAP);
   } else if constexpr (!AK && !BKM) {
-    TRY_EPI(EF_SPLIT | EF_F32);
+    if (d.colsum) { if ((need & ~(EF_SPLIT | EF_F32)) == 0) return launch_pers_f<AK, BKM, (EF_SPLIT | EF_F32 | EF_COLSUM)>(d, st); }
+    else TRY_EPI(EF_SPLIT | EF_F32);
   }
 #undef TRY_EPI
   return launch_pers_f<AK, BKM, EF_ALL>(d, st);
@@ -1110,6 +1131,16 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   // direct-to-LDS staging needs whole 64-wide K tiles for k-major operands (an out-of-extent k chunk would read the next
   // columns, not zeros) and 32-bit byte offsets; everything else takes the register-staged path (variant 2 forces it).
   const bool pers = direct && !big && !p3 && (dd.variant == 6 || dd.variant == 0);
+  if (dd.colsum) {
+    if (dd.a_kmajor) return VMVM_ENOSUPPORT;
+    const bool plain_wgrad = !dd.b_kmajor && dd.out_fp32 && !dd.bias && !dd.col_scale_n && !dd.act && !dd.row_scale && dd.dropout_p <= 0.f &&
+                             !dd.resid && !dd.row_map && !(dd.N & 7);
+    if (!(pers && plain_wgrad)) {                        // not the fused build: one separate pass over A (= X of the column sum)
+      const int rc_ = vmvm_colsum_bf16(dd.A, dd.K, dd.M, dd.lda, nullptr, 0, dd.colsum, 1, stream);
+      if (rc_) return rc_;
+      dd.colsum = nullptr;
+    }
+  }
   if (pers) {
     if (d->a_kmajor && d->b_kmajor) return launch_pers<true, true>(*d, st);
     if (d->a_kmajor && !d->b_kmajor) return launch_pers<true, false>(*d, st);

@@ -187,9 +187,14 @@ class VioletEngine:
         w2 = w.view(w.shape[0], -1)
         gw2 = gw.view(gw.shape[0], -1)
         N = wN or w2.shape[0]
+        gbias = None
         if bname is not None or gb is not None:
-            K.colsum(dy, S.g(bname) if gb is None else gb, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
-        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True)
+            gbias = S.g(bname) if gb is None else gb
+            if row_scale is not None:                     # DropPath-weighted column sum: separate pass (the fused form is unweighted)
+                K.colsum(dy, gbias, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
+                gbias = None
+        # db = colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
+        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gbias)
         if not need_dx:
             return None
         wt = S.bt(wname) if (wname is not None and wT is None) else wT

@@ -73,6 +73,22 @@ def check_gemm_layouts():
                 rep(f"gemm TT(a m-major) v{var} {M}x{N}x{K_}", K.gemm(At, B, a_kmajor=False, variant=var), ref)
 
 
+def check_gemm_colsum():
+    """bias gradient fused into the weight-gradient GEMM (colsum of the m-major A operand) + the unfused fallback paths"""
+    for (rows, n_out, k_in, ws) in [(4096, 768, 768, True), (50176, 512, 2048, True), (5000, 200, 136, False), (13824, 2304, 768, True), (1000, 30528, 768, True)]:
+        K._WORKSPACE.clear()
+        if ws:
+            K.set_workspace(torch.empty(256 << 20, device=dev, dtype=torch.uint8))
+        dy, x = rnd(rows, n_out), rnd(rows, k_in)
+        gw = torch.randn(n_out, k_in, device=dev)
+        gb = torch.randn(n_out, device=dev)
+        gw0, gb0 = gw.clone(), gb.clone()
+        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=n_out, N=k_in, K=rows, out=gw, accumulate=True, colsum=gb)
+        rep(f"wgrad+colsum dW rows={rows} {n_out}x{k_in} ws={ws}", gw, gw0 + dy.float().t() @ x.float())
+        rep(f"wgrad+colsum db rows={rows} {n_out}x{k_in} ws={ws}", gb, gb0 + dy.float().sum(0))
+    K._WORKSPACE.clear()
+
+
 def check_gemm_big(variant=4, tag="big"):
     """256^2-tile kernel (variant 4) / 3-stage 256x128 kernel (variant 5) on every layout + epilogue paths + split-K."""
     for (M, N, K_) in [(392 * 3, 768, 128), (1000, 1024, 768), (4096, 512, 2048), (777 * 8, 256, 64)]:
@@ -595,8 +611,8 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
-    table = dict(probe=check_probe, gemm=check_gemm_layouts, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
+    table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
                  attnw=check_attn_window, attnb=check_attn_bert, misc=check_misc)
     for w in which:
         if w == "bench":
