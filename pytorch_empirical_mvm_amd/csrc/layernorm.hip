@@ -211,6 +211,181 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Packed variants for narrow rows (C <= 256: Video-Swin stages 1-2 and the patch embedding).  With one row per wave only C/8 of
+// the 64 lanes hold data (16 of 64 at C = 128), so the kernels above run at a quarter of the HBM rate there.  Here a wave owns
+// 64/LPR rows: lane = sub * LPR + cl, row = base + sub, chunk = cl; row statistics are segmented xor-shuffle sums over the LPR
+// lanes of a row.  All row-level exits become per-lane predicates (every lane must reach the shuffles).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR, bool XF32>
+__global__ __launch_bounds__(256) void ln_fwd_pk_kernel(const vmvm_ln_fwd_desc p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, cl = lane % LPR;
+  const long m = ((long)blockIdx.x * 4 + wave) * RPW + sub;
+  const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
+  const bool rowok = m < p.M;
+  const bool act = rowok && cl < nch;
+  const long mm = rowok ? m : 0;
+  u16* Y = reinterpret_cast<u16*>(p.Y) + (size_t)mm * p.ldy;
+  long b = 0, ml = mm;
+  if (p.src) { b = mm / p.rows_out_per_batch; ml = mm - b * p.rows_out_per_batch; }
+  const int col = cl * 8;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = 0.f;
+  float s = 0.f, nvalid = (p.src == nullptr) ? 1.f : 0.f;
+  if (act) {
+    long srow = mm; int within = col;
+    if (p.src) {
+      const int seg = col / cseg; within = col - seg * cseg;
+      const int sr = p.src[ml * p.nseg + seg];
+      srow = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
+    }
+    if (srow >= 0) {
+      nvalid = 1.f;
+      load_x8<XF32>(p.X, (size_t)srow * p.ldx + within, x);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e];
+  }
+  // window map: the row is either fully valid or a pad slot (zero OUTPUT row)
+  const bool padrow = p.src && p.pad_mode == 0 && seg_sum<LPR>(nvalid) == 0.f;
+  const float mean = seg_sum<LPR>(s) / (float)C;
+  float q = 0.f;
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(seg_sum<LPR>(q) / (float)C + p.eps);
+  if (rowok && cl == 0) { p.mean[m] = padrow ? 0.f : mean; p.rstd[m] = padrow ? 0.f : rstd; }
+  if (act) {
+    if (padrow) { *reinterpret_cast<uint4*>(Y + col) = make_uint4(0, 0, 0, 0); return; }
+    const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.beta + col), b1 = *reinterpret_cast<const float4*>(p.beta + col + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (x[e] - mean) * rstd * gg[e] + bb[e];
+    *reinterpret_cast<uint4*>(Y + col) = pack_bf8(o);
+  }
+}
+
+template <int LPR, bool XF32>
+__global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p) {
+  constexpr int RPW = 64 / LPR;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // 4 wave slabs x [2][C] partial dgamma/dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, cl = lane % LPR;
+  const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
+  const u16* dY = reinterpret_cast<const u16*>(p.dY);
+  u16* dX = reinterpret_cast<u16*>(p.dX);
+  const u16* ADD = reinterpret_cast<const u16*>(p.dX_add);
+  u16* dX2 = reinterpret_cast<u16*>(p.dX2);
+  const bool has_drop = dX2 != nullptr && p.dropout_p > 0.f;
+  const uint32_t thr = dropout_threshold(p.dropout_p);
+  const float keep_scale = has_drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  const int col = cl * 8;
+  float dg[8], db[8], gg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+  if (cl < nch) {
+    const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+    gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+  }
+  const long stride = (long)gridDim.x * 4 * RPW;
+  for (long mb = ((long)blockIdx.x * 4 + wave) * RPW; mb < p.M; mb += stride) {       // wave-uniform loop: every lane reaches the shuffles
+    const long m = mb + sub;
+    const bool rowok = m < p.M;
+    const long mm = rowok ? m : 0;
+    const float mean = p.mean[mm], rstd = p.rstd[mm];
+    long b = 0, ml = mm;
+    if (p.src) { b = mm / p.rows_out_per_batch; ml = mm - b * p.rows_out_per_batch; }
+    const bool padrow = p.src && p.pad_mode == 0 && p.src[ml] < 0;     // pad slot: constant zero output, no gradient
+    const bool act = rowok && !padrow && cl < nch;
+    float xh[8], gdy[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xh[e] = 0.f; gdy[e] = 0.f; }
+    long srow = -1; int within = col;
+    uint4 addv = make_uint4(0, 0, 0, 0);
+    float s1 = 0.f, s2 = 0.f;
+    if (act) {
+      srow = mm;
+      if (p.src) {
+        const int seg = col / cseg; within = col - seg * cseg;
+        const int sr = p.src[ml * p.nseg + seg];
+        srow = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
+      }
+      float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
+      if (srow >= 0) load_x8<XF32>(p.X, (size_t)srow * p.ldx + within, xv);
+      if (ADD && srow >= 0) addv = *reinterpret_cast<const uint4*>(ADD + (size_t)srow * p.ldadd + within);
+      unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)mm * p.lddy + col), dyv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[e] = (xv[e] - mean) * rstd;
+        gdy[e] = dyv[e] * gg[e];
+        dg[e] += dyv[e] * xh[e];
+        db[e] += dyv[e];
+        s1 += gdy[e];
+        s2 += gdy[e] * xh[e];
+      }
+    }
+    s1 = seg_sum<LPR>(s1) / (float)C;
+    s2 = seg_sum<LPR>(s2) / (float)C;
+    if (act && srow >= 0) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (gdy[e] - s1 - xh[e] * s2);
+      if (ADD) {
+        float a[8];
+        unpack_bf8(addv, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += a[e];
+      }
+      *reinterpret_cast<uint4*>(dX + (size_t)srow * p.lddx + within) = pack_bf8(o);
+      if (dX2) {
+        if (has_drop) {
+          const uint64_t e4 = ((uint64_t)mm * (uint64_t)C + (uint64_t)col) >> 2;
+          const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
+          const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
+        }
+        *reinterpret_cast<uint4*>(dX2 + (size_t)mm * p.lddx2 + col) = pack_bf8(o);
+      }
+    }
+  }
+  // the RPW row slots of a wave hold partials of the same columns: fold them, then the per-wave slab reduction of ln_bwd_kernel
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
+  }
+  float* redw = red + wave * 2 * C;
+  if (sub == 0 && cl < nch) {
+    *reinterpret_cast<float4*>(redw + col) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+    *reinterpret_cast<float4*>(redw + col + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+    *reinterpret_cast<float4*>(redw + C + col) = make_float4(db[0], db[1], db[2], db[3]);
+    *reinterpret_cast<float4*>(redw + C + col + 4) = make_float4(db[4], db[5], db[6], db[7]);
+  }
+  __syncthreads();
+  float* ws = reinterpret_cast<float*>(p.workspace);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const float v = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+    if (ws) ws[(size_t)blockIdx.x * 2 * C + i] = v;
+    else atomicAdd(i < C ? p.dgamma + i : p.dbeta + (i - C), v);
+  }
+}
+
 // dgamma[c] += sum_rows ws[row][c], dbeta[c] += sum_rows ws[row][C + c] : 64 columns x 4 row lanes per workgroup, blockIdx.y
 // splits the rows 8 ways (8 atomics per column in total)
 __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* ws, int rows, int C, float* dgamma, float* dbeta) {
@@ -241,7 +416,17 @@ extern "C" int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream) {
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = (d->M + 3) / 4;
-  if (d->x_fp32) {
+  if (d->C <= 256) {                                    // narrow rows: 4 (C <= 128) or 2 rows per wave
+    const int rpw = d->C <= 128 ? 4 : 2;
+    const int gridp = (d->M + 4 * rpw - 1) / (4 * rpw);
+    if (d->x_fp32) {
+      if (rpw == 4) hipLaunchKernelGGL((ln_fwd_pk_kernel<16, true>), dim3(gridp), dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL((ln_fwd_pk_kernel<32, true>), dim3(gridp), dim3(256), 0, st, *d);
+    } else {
+      if (rpw == 4) hipLaunchKernelGGL((ln_fwd_pk_kernel<16, false>), dim3(gridp), dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL((ln_fwd_pk_kernel<32, false>), dim3(gridp), dim3(256), 0, st, *d);
+    }
+  } else if (d->x_fp32) {
     if (d->C > 512) return VMVM_ENOSUPPORT;
     hipLaunchKernelGGL((ln_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, st, *d);
   } else if (d->C <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, st, *d);
@@ -274,7 +459,18 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
       return VMVM_EHIP;                                                                                                 \
     hipLaunchKernelGGL((ln_bwd_kernel<NCH, XF>), dim3(grid), dim3(256), sm, st, dd);                                    \
   } while (0)
-  if (d->x_fp32) {
+  if (d->C <= 256) {
+    const int rpw = d->C <= 128 ? 4 : 2;
+    const int gmax = (d->M + 4 * rpw - 1) / (4 * rpw);
+    if (grid > gmax) { grid = gmax; if (dd.workspace && dd.workspace_bytes < (uint64_t)grid * 2 * d->C * sizeof(float)) dd.workspace = nullptr; }
+    if (d->x_fp32) {
+      if (rpw == 4) hipLaunchKernelGGL((ln_bwd_pk_kernel<16, true>), dim3(grid), dim3(256), sm, st, dd);
+      else hipLaunchKernelGGL((ln_bwd_pk_kernel<32, true>), dim3(grid), dim3(256), sm, st, dd);
+    } else {
+      if (rpw == 4) hipLaunchKernelGGL((ln_bwd_pk_kernel<16, false>), dim3(grid), dim3(256), sm, st, dd);
+      else hipLaunchKernelGGL((ln_bwd_pk_kernel<32, false>), dim3(grid), dim3(256), sm, st, dd);
+    }
+  } else if (d->x_fp32) {
     if (d->C > 512) return VMVM_ENOSUPPORT;
     LAUNCH_LNB(1, true);
   } else if (d->C <= 512) LAUNCH_LNB(1, false);

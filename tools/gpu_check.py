@@ -191,7 +191,7 @@ def check_gemm_epilogues():
 
 # ------------------------------------------------------------------ layernorm
 def check_ln():
-    for C_, with_ws in ((96, False), (128, True), (512, False), (512, True), (768, True), (768, False), (1024, True), (2048, True), (3072, False), (3072, True)):
+    for C_, with_ws in ((96, False), (128, True), (256, True), (256, False), (512, False), (512, True), (768, True), (768, False), (1024, True), (2048, True), (3072, False), (3072, True)):
         # with_ws: dgamma/dbeta partials through the scratch buffer + column-reduce kernel ; without: global atomics
         K._WORKSPACE.clear()
         if with_ws:
