@@ -116,9 +116,22 @@ __device__ __forceinline__ uint4 philox4x32_7(uint4 c, uint2 k) {
   }
   return c;
 }
-// random bits for the 4 consecutive elements starting at element index e4*4
-__device__ __forceinline__ uint4 dropout_bits(uint64_t seed, uint64_t offset, uint64_t e4) {
-  uint64_t c = offset + e4;
+// Dropout randomness: one Philox4x32-7 evaluation per block of EIGHT consecutive elements, 16 random bits per element (compared
+// as the top half of a 32-bit word against the 32-bit threshold, i.e. p is quantised to 1/65536).  dropout_bits8 serves the
+// 16-byte (8-element) consumers, dropout_bits the 4-element ones: element e of the tensor gets the same bits either way.
+__device__ __forceinline__ uint4 dropout_block8(uint64_t seed, uint64_t offset, uint64_t e8) {
+  const uint64_t c = offset + e8;
   return philox4x32_7(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x5eedu, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ void dropout_bits8(uint64_t seed, uint64_t offset, uint64_t e8, uint32_t (&bits)[8]) {
+  const uint4 b = dropout_block8(seed, offset, e8);
+  bits[0] = b.x << 16; bits[1] = b.x & 0xffff0000u; bits[2] = b.y << 16; bits[3] = b.y & 0xffff0000u;
+  bits[4] = b.z << 16; bits[5] = b.z & 0xffff0000u; bits[6] = b.w << 16; bits[7] = b.w & 0xffff0000u;
+}
+// the 4 consecutive elements starting at element index e4*4 (= half of block e4 >> 1)
+__device__ __forceinline__ uint4 dropout_bits(uint64_t seed, uint64_t offset, uint64_t e4) {
+  const uint4 b = dropout_block8(seed, offset, e4 >> 1);
+  const uint32_t lo = (e4 & 1) ? b.z : b.x, hi = (e4 & 1) ? b.w : b.y;
+  return make_uint4(lo << 16, lo & 0xffff0000u, hi << 16, hi & 0xffff0000u);
 }
 __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(fminf(fmaxf(p, 0.f), 1.f) * 4294967295.0f); }

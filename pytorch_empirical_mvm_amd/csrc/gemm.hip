@@ -255,9 +255,14 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
     for (int e = 0; e < 8; ++e) v[e] *= rs;
   }
   if ((F & EF_DROP) && e_.has_drop) {
-    const uint64_t e4 = ((uint64_t)m * (uint64_t)e_.N + (uint64_t)n) >> 2;
-    const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
-    const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const uint64_t el = (uint64_t)m * (uint64_t)e_.N + (uint64_t)n;
+    uint32_t bits[8];
+    if ((F & EF_EDGE4) && (el & 7)) {                     // N % 8 != 0: this 8-run straddles two blocks
+      const uint4 b0 = dropout_bits(p.seed, p.offset, el >> 2), b1 = dropout_bits(p.seed, p.offset, (el >> 2) + 1);
+      bits[0] = b0.x; bits[1] = b0.y; bits[2] = b0.z; bits[3] = b0.w; bits[4] = b1.x; bits[5] = b1.y; bits[6] = b1.z; bits[7] = b1.w;
+    } else {
+      dropout_bits8(p.seed, p.offset, el >> 3, bits);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = bits[e] < e_.thr ? 0.f : v[e] * e_.keep_scale;
   }

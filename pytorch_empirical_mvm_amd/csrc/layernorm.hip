@@ -178,9 +178,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
         *reinterpret_cast<uint4*>(dX + (size_t)srow[i] * p.lddx + within[i]) = pack_bf8(o);
         if (dX2) {
           if (has_drop) {
-            const uint64_t e4 = ((uint64_t)m * (uint64_t)C + (uint64_t)(c * 8)) >> 2;
-            const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
-            const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t bits[8];
+            dropout_bits8(p.seed, p.offset, ((uint64_t)m * (uint64_t)C + (uint64_t)(c * 8)) >> 3, bits);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
           }
@@ -354,9 +353,8 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
       *reinterpret_cast<uint4*>(dX + (size_t)srow * p.lddx + within) = pack_bf8(o);
       if (dX2) {
         if (has_drop) {
-          const uint64_t e4 = ((uint64_t)mm * (uint64_t)C + (uint64_t)col) >> 2;
-          const uint4 b0 = dropout_bits(p.seed, p.offset, e4), b1 = dropout_bits(p.seed, p.offset, e4 + 1);
-          const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+          uint32_t bits[8];
+          dropout_bits8(p.seed, p.offset, ((uint64_t)mm * (uint64_t)C + (uint64_t)col) >> 3, bits);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
         }

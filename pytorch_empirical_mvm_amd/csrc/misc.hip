@@ -309,8 +309,8 @@ __global__ void dropout_kernel(const u16* __restrict__ x, u16* __restrict__ y, l
   if (i >= n) return;
   const uint32_t thr = dropout_threshold(p);
   const float ks = 1.f / (1.f - p);
-  const uint4 b0 = dropout_bits(seed, offset, (uint64_t)(i >> 2)), b1 = dropout_bits(seed, offset, (uint64_t)(i >> 2) + 1);
-  const uint32_t bits[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  uint32_t bits[8];
+  dropout_bits8(seed, offset, (uint64_t)(i >> 3), bits);
   for (int e = 0; e < 8 && i + e < n; ++e) y[i + e] = bits[e] < thr ? (u16)0 : f2bf(bf2f(x[i + e]) * ks);
 }
 
