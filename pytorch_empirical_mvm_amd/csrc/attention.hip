@@ -254,6 +254,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc[t], 0, 0, 0);
         }
+        if (NX && HD == 64 && (t & 3) == 3) asm volatile("" ::: "memory");   // exact-tile build: keep the K fragment loads from being hoisted en bloc
       }
     }
     // ---- scores: bias / masks, row max
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 // ================================================================================================
 // backward A: dQ (+ delta, + relative-position-bias table gradient)
 // ================================================================================================
-template <int HD, int MODE, int NW>
+template <int HD, int MODE, int NW, int NXB>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bwd_desc pb, const int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -417,14 +418,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
     for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 own = make_uint4(0, 0, 0, 0);               // quad-shared dropout block (see quad_bcast)
-    for (int c = 0; c < nt2; ++c) {
+    // NXB > 0: exact tile count -> fully unrolled, immediate LDS offsets, no per-tile guards
+#pragma unroll
+    for (int c = 0; c < (NXB ? (NXB + 1) / 2 : nt2); ++c) {
       float ds[2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * c + u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ds[u][j] = 0.f;
-        if (t < nt) {
+        if (NXB ? (t < NXB) : (t < nt)) {
           const int row = t * 16 + r;
           f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
 // ================================================================================================
 // backward B: dK, dV (per key tile; probabilities recomputed from lse; delta from kernel A)
 // ================================================================================================
-template <int HD, int MODE, int NW>
+template <int HD, int MODE, int NW, int NXB>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -1149,7 +1152,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
     uint4 own[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) own[t] = make_uint4(0, 0, 0, 0);
-    for (int c = 0; c < nt2; ++c) {
+#pragma unroll
+    for (int c = 0; c < (NXB ? (NXB + 1) / 2 : nt2); ++c) {
       float pt[KT][2][4], ds[KT][2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -1158,7 +1162,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
         for (int t = 0; t < KT; ++t)
 #pragma unroll
           for (int j = 0; j < 4; ++j) { pt[t][u][j] = 0.f; ds[t][u][j] = 0.f; }
-        if (qt < nt) {
+        if (NXB ? (qt < NXB) : (qt < nt)) {
           const int qrow = qt * 16 + r;            // A-operand row owned by this lane
           f32x4 s4[KT], dp4[KT];
 #pragma unroll
@@ -1230,6 +1234,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
           dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[t], dk[t][dt], 0, 0, 0);
         }
       }
+      if (NXB) asm volatile("" ::: "memory");             // exact-tile build: keep the unrolled pairs' LDS reads from being hoisted en bloc
     }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -1555,28 +1560,30 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     else if (sm.nt <= 16) LAUNCH_FWD(32, 0, 16, 4, 0, true);
     else LAUNCH_FWD(32, 0, 28, 4, 0, true);
   } else {
-    // (exact-NT instantiations of the head_dim-64 kernel spill: the hoisted loads of 27 unguarded tiles exceed 256 VGPRs)
+    // (exact-NT instantiations of the head_dim-64 kernel need the compiler barrier in the score loop: hoisted en bloc, the K
+    //  fragment loads of 27 unguarded tiles exceed 256 VGPRs)
     if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4, 0, true);
+    else if (sm.nt == 27) LAUNCH_FWD(64, 1, 28, 8, 27, true);       // L = 432 (fusion encoder): exact tile count, no per-tile guards
     else LAUNCH_FWD(64, 1, 28, 8, 0, true);
   }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
 
-#define LAUNCH_BWD(KERN, HD, MODE, NW, WHICH)                                                \
+#define LAUNCH_BWD(KERN, HD, MODE, NW, WHICH, NXB)                                           \
   do {                                                                                       \
     const Smem s_ = smem_layout(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, WHICH);    \
-    int rc_ = set_smem(KERN<HD, MODE, NW>, s_.total);                                        \
+    int rc_ = set_smem(KERN<HD, MODE, NW, NXB>, s_.total);                                   \
     if (rc_) return rc_;                                                                     \
-    hipLaunchKernelGGL((KERN<HD, MODE, NW>), dim3(nb), dim3(NW * 64), s_.total, st, *d);     \
+    hipLaunchKernelGGL((KERN<HD, MODE, NW, NXB>), dim3(nb), dim3(NW * 64), s_.total, st, *d); \
     VMVM_CHECK_LAUNCH();                                                                     \
   } while (0)
-#define LAUNCH_BWD_DQ(HD, MODE, NW)                                                          \
+#define LAUNCH_BWD_DQ(HD, MODE, NW, NXB)                                                     \
   do {                                                                                       \
     const Smem s_ = smem_layout(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 1);        \
-    int rc_ = set_smem(attn_bwd_dq_kernel<HD, MODE, NW>, s_.total);                          \
+    int rc_ = set_smem(attn_bwd_dq_kernel<HD, MODE, NW, NXB>, s_.total);                     \
     if (rc_) return rc_;                                                                     \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, MODE, NW>), dim3(nchunks * d->f.heads), dim3(NW * 64), s_.total, st, *d, nchunks); \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, MODE, NW, NXB>), dim3(nchunks * d->f.heads), dim3(NW * 64), s_.total, st, *d, nchunks); \
     VMVM_CHECK_LAUNCH();                                                                     \
   } while (0)
 
@@ -1667,12 +1674,18 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
         else { if (mask) LAUNCH_DKV2_(13, true, 2, 7); else LAUNCH_DKV2_(13, false, 2, 7); }
         VMVM_CHECK_LAUNCH();
       } else {
-        LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2);
+        LAUNCH_BWD(attn_bwd_dkv_kernel, 32, 0, 4, 2, 0);
       }
     }
   } else {
-    LAUNCH_BWD_DQ(64, 1, 8);
-    LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2);
+    const Smem sb_ = smem_layout(d->f.L, 64, 1, d->f.table_len, 1);
+    if (sb_.nt == 27) {        // L = 432 (fusion encoder): exact tile count, fully unrolled tile loops
+      LAUNCH_BWD_DQ(64, 1, 8, 27);
+      LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2, 27);
+    } else {
+      LAUNCH_BWD_DQ(64, 1, 8, 0);
+      LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2, 0);
+    }
   }
   return VMVM_OK;
 }
