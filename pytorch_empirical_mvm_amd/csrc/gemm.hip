@@ -868,10 +868,31 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     kt0 = slice * per;
     nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
   };
-  auto issue = [&](int m0, int n0, int kt, int buf) {
-    unsigned char* st = smem + buf * 2 * TILE_BYTES;
-    issue_tile<AK>(ra_, p.lda, m0, kt * BK, st, tid);
-    issue_tile<BKM, true>(rb_, p.ldb, n0, kt * BK, st + TILE_BYTES, tid);
+  // DMA requests of a K tile: the per-lane source offsets only depend on the tile origin, so they are computed once per tile
+  // (vo*) and the K position travels in the instruction's SCALAR offset; the LDS destination is a scalar too.  (Per-request
+  // vector address arithmetic was ~30 of the ~100 non-MFMA issue slots of a K step.)
+  const int wave_base_s = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const unsigned kstepA = (unsigned)((AK ? BK : BK * p.lda) * 2), kstepB = (unsigned)((BKM ? BK : BK * p.ldb) * 2);
+  auto tile_offsets = [&](int m0, int n0, unsigned (&vA)[4], unsigned (&vB)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + i * 256;
+      if (AK) { const int row = u >> 3, cs = u & 7; vA[i] = (unsigned)(((size_t)(m0 + row) * p.lda + (cs ^ kswz<false>(row)) * 8) * 2); }
+      else { const int krow = u >> 4, unit = u & 15; const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
+             vA[i] = (unsigned)(((size_t)krow * p.lda + m0 + (slot * 2 + (unit & 1)) * 8) * 2); }
+      if (BKM) { const int row = u >> 3, cs = u & 7; vB[i] = (unsigned)(((size_t)(n0 + row) * p.ldb + (cs ^ kswz<true>(row)) * 8) * 2); }
+      else { const int krow = u >> 4, unit = u & 15; const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
+             vB[i] = (unsigned)(((size_t)krow * p.ldb + n0 + (slot * 2 + (unit & 1)) * 8) * 2); }
+    }
+  };
+  auto issue = [&](const unsigned (&vA)[4], const unsigned (&vB)[4], int kt, int buf) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    unsigned char* st = smem + buf * 2 * TILE_BYTES + wave_base_s * 16;
+    const unsigned sa = (unsigned)kt * kstepA, sb = (unsigned)kt * kstepB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + i * 4096), 16, vA[i], sa, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + TILE_BYTES + i * 4096), 16, vB[i], sb, 0, 0);
   };
 
   int w = li;
@@ -879,7 +900,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
   unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
-  issue(m0, n0, kt0, it & 1);
+  unsigned voA[4], voB[4], nvoA[4], nvoB[4];
+  tile_offsets(m0, n0, voA, voB);
+  issue(voA, voB, kt0, it & 1);
   while (true) {
     f32x4 acc[4][4];
 #pragma unroll
@@ -895,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     const int wn_ = w + per_xcd;
     const bool more = wn_ < x_cnt;
     int nslice = 0, nm0 = 0, nn0 = 0, nkt0 = 0, nnk = 0;
-    if (more) decode(wn_, nslice, nm0, nn0, nkt0, nnk);
+    if (more) { decode(wn_, nslice, nm0, nn0, nkt0, nnk); tile_offsets(nm0, nn0, nvoA, nvoB); }
     for (int kt = kt0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
@@ -944,8 +967,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         }
       };
       load_set(0);
-      if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
-      else if (more) issue(nm0, nn0, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
+      if (kt + 1 < nk) issue(voA, voB, kt + 1, cur ^ 1);
+      else if (more) issue(nvoA, nvoB, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
       finish_set(0);
       load_set(1);
       mfma_set(0);
@@ -1013,6 +1036,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     }
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { voA[i] = nvoA[i]; voB[i] = nvoB[i]; }
   }
 }
 
