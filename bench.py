@@ -24,10 +24,10 @@ TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
 # HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_roofline_gemm.txt):
-# FETCH_SIZE 3.94e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.39e5 KiB.
+# FETCH_SIZE 3.97e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.42e5 KiB.
 # Algorithmic bytes: A 106 MB + W 4.7 MB + C 425 MB + pre-activation 425 MB = 0.96 GB; the excess read traffic is the
 # 4.7 MB weight panel re-streamed through the 4 MiB L2 (served by the Infinity Cache), 1.17 GB before the tile rasterisation.
-ROOFLINE_TRAFFIC_BYTES = int((2 * 3.94e5 + 8.39e5) * 1024)
+ROOFLINE_TRAFFIC_BYTES = int((2 * 3.97e5 + 8.42e5) * 1024)
 
 
 def synth_batch(args, B, device, seed):
