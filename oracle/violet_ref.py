@@ -41,13 +41,14 @@ BERT = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512,
 
 
 def make_cfg(size="base", T=8, img=224, n_txt=32, max_size_frame=None, max_size_patch=14,
-             size_patch=32, temp=0.05, bert_layers=12, mvm_target="pixel", arch=None, vocab=None):
+             size_patch=32, temp=0.05, bert_layers=12, mvm_target="pixel", arch=None, vocab=None,
+             size_vq=8192, dvae_hid=256, dvae_vocab=8192):
     a = dict(ARCH[size]) if arch is None else dict(arch)
     cfg = dict(a)
     cfg.update(size=size, T=T, img=img, n_txt=n_txt, max_size_frame=max_size_frame or max(T, 6),
                max_size_patch=max_size_patch, size_patch=size_patch, temp=temp,
                bert_layers=bert_layers, mvm_target=mvm_target, hidden=BERT["hidden"],
-               vocab=vocab or BERT["vocab"])
+               vocab=vocab or BERT["vocab"], size_vq=size_vq, dvae_hid=dvae_hid, dvae_vocab=dvae_vocab)
     return cfg
 
 
@@ -137,6 +138,39 @@ def param_shapes(cfg):
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    if "vq" in cfg["mvm_target"]:
+        # main_pretrain.py:194-209 (on-the-fly dVAE branch): Conv2d 1x1 H -> 2H, PixelShuffle(32/8), Dropout, Linear, ReLU, Linear
+        up = cfg["size_patch"] // 8
+        c = 2 * H // (up * up)
+        s["decoder_vq.0.weight"] = (2 * H, H, 1, 1)
+        s["decoder_vq.0.bias"] = (2 * H,)
+        s["fc_mvm.1.weight"] = (2 * c, c)
+        s["fc_mvm.1.bias"] = (2 * c,)
+        s["fc_mvm.3.weight"] = (cfg["size_vq"], 2 * c)
+        s["fc_mvm.3.bias"] = (cfg["size_vq"],)
+    return s
+
+
+def dvae_param_shapes(cfg):
+    """Frozen DALL-E dVAE encoder (visbackbone/dalle/encoder.py:41-93): keys as in its state_dict, prefixed `dalle.encoder.`"""
+    nh, V = cfg["dvae_hid"], cfg["dvae_vocab"]
+    s = {}
+    pre = "dalle.encoder.blocks."
+    s[pre + "input.w"] = (nh, 3, 7, 7); s[pre + "input.b"] = (nh,)
+    n_in = nh
+    for gi, mult in enumerate((1, 2, 4, 8)):
+        n_out = mult * nh
+        for bi in range(2):
+            q = pre + f"group_{gi + 1}.block_{bi + 1}."
+            if n_in != n_out:
+                s[q + "id_path.w"] = (n_out, n_in, 1, 1); s[q + "id_path.b"] = (n_out,)
+            hid = n_out // 4
+            s[q + "res_path.conv_1.w"] = (hid, n_in, 3, 3); s[q + "res_path.conv_1.b"] = (hid,)
+            s[q + "res_path.conv_2.w"] = (hid, hid, 3, 3); s[q + "res_path.conv_2.b"] = (hid,)
+            s[q + "res_path.conv_3.w"] = (hid, hid, 3, 3); s[q + "res_path.conv_3.b"] = (hid,)
+            s[q + "res_path.conv_4.w"] = (n_out, hid, 1, 1); s[q + "res_path.conv_4.b"] = (n_out,)
+            n_in = n_out
+    s[pre + "output.conv.w"] = (V, 8 * nh, 1, 1); s[pre + "output.conv.b"] = (V,)
     return s
 
 
@@ -169,7 +203,13 @@ def closed_form(key, shape, dtype=torch.float32):
         v = 0.02 * r3 * u
     elif "relative_position_bias_table" in key:
         v = 0.2 * r3 * u
-    elif "patch_embed.proj.weight" in key or key.startswith("decoder_pixel") or key.startswith("fc."):
+    elif key.startswith("dalle.") and key.endswith(".w"):
+        fan_in = int(np.prod(shape[1:]))
+        v = r3 * u / math.sqrt(fan_in)                         # dalle/utils.py:28 : normal(std = 1/sqrt(n_in*kw^2)), same variance
+    elif key.startswith("dalle.") and key.endswith(".b"):
+        v = 0.05 * u                                           # (zeros in the reference; non-zero here so the bias path is exercised)
+    elif "patch_embed.proj.weight" in key or key.startswith("decoder_pixel") or key.startswith("fc.") or key.startswith("decoder_vq") \
+            or key.startswith("fc_mvm"):
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else n
         v = u / math.sqrt(fan_in)
     else:
@@ -178,7 +218,10 @@ def closed_form(key, shape, dtype=torch.float32):
 
 
 def make_state_dict(cfg, dtype=torch.float32):
-    return {k: closed_form(k, shp, dtype) for k, shp in param_shapes(cfg).items()}
+    sd = {k: closed_form(k, shp, dtype) for k, shp in param_shapes(cfg).items()}
+    if "vq" in cfg["mvm_target"]:
+        sd.update({k: closed_form(k, shp, dtype) for k, shp in dvae_param_shapes(cfg).items()})
+    return sd
 
 
 def make_batch(cfg, B, dtype=torch.float32):
@@ -484,6 +527,79 @@ def pixel_loss(sd, cfg, out_mvm, unmask_img, mvm_mask):
     return (ls.float() * mvm_mask.float()).sum() / (mvm_mask.float().sum() + 1e-5) / Cin
 
 
+# ----------------------------------------------------------------------------
+# MVM 'vq' target: frozen dVAE tokenizer + vq head
+# ----------------------------------------------------------------------------
+IMNET_MEAN = (0.485, 0.456, 0.406)
+IMNET_STD = (0.229, 0.224, 0.225)
+
+
+def dvae_encoder(sd, cfg, x):
+    """Encoder.forward visbackbone/dalle/encoder.py:41-93 (fp32): 7x7 conv, 4 groups x 2 bottleneck blocks
+    (id_path + post_gain * [relu,3x3,relu,3x3,relu,3x3,relu,1x1], :12-39), max-pool 2 after groups 1-3, relu + 1x1 conv."""
+    pre = "dalle.encoder.blocks."
+    conv = lambda t, k: F.conv2d(t, sd[k + ".w"], sd[k + ".b"], padding=(sd[k + ".w"].shape[-1] - 1) // 2)
+    post_gain = 1.0 / (4 * 2) ** 2
+    x = conv(x, pre + "input")
+    for gi in range(4):
+        for bi in range(2):
+            q = pre + f"group_{gi + 1}.block_{bi + 1}."
+            idp = conv(x, q + "id_path") if (q + "id_path.w") in sd else x
+            r = conv(F.relu(x), q + "res_path.conv_1")
+            r = conv(F.relu(r), q + "res_path.conv_2")
+            r = conv(F.relu(r), q + "res_path.conv_3")
+            r = conv(F.relu(r), q + "res_path.conv_4")
+            x = idp + post_gain * r
+        if gi < 3:
+            x = F.max_pool2d(x, 2)
+    return conv(F.relu(x), pre + "output.conv")
+
+
+def vq_tokens(sd, cfg, unmask_img):
+    """DalleModel.extract_vq_token dalle/__init__.py:38-54 : un-normalise (ImageNet), map_pixels 0.8x+0.1 (utils.py:46-52),
+    encoder, argmax over the vocabulary -> (B*T, H/8, W/8) int64"""
+    B, T, C, H, W = unmask_img.shape
+    x = unmask_img.reshape(B * T, C, H, W).float()
+    mean = torch.tensor(IMNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(IMNET_STD).view(1, 3, 1, 1)
+    x = x * std + mean                                         # Normalize(-mean/std, 1/std)
+    x = 0.8 * x + 0.1
+    return torch.argmax(dvae_encoder(sd, cfg, x), dim=1)
+
+
+def vq_answers(tokens, mvm_mask):
+    """main_pretrain.py:485-488 : ans = where(max_pool2d(mask, 8).sum(channels) == 0, -1, token)"""
+    B, T, C, H, W = mvm_mask.shape
+    mk = F.max_pool2d(mvm_mask.reshape(B * T, C, H, W).float(), 8).sum(dim=1)
+    ans = torch.where(mk == 0, torch.full_like(tokens, -1), tokens)
+    return ans.view(B, T * tokens.shape[-1] * tokens.shape[-2])
+
+
+def vq_logits(sd, cfg, out_mvm, T, h, w):
+    """main_pretrain.py:474-477,490-496 : drop per-frame cls, 1x1 conv H -> 2H, PixelShuffle(4), per-position MLP (eval: no dropout)"""
+    B, L, C = out_mvm.shape
+    l = L // T
+    x = torch.cat([out_mvm[:, l * t + 1:l * (t + 1), :] for t in range(T)], dim=1)
+    x = x.permute(0, 2, 1).reshape(B, C, T, h, w).permute(0, 2, 1, 3, 4).reshape(B * T, C, h, w)
+    x = F.conv2d(x, sd["decoder_vq.0.weight"], sd["decoder_vq.0.bias"])
+    up = cfg["size_patch"] // 8
+    x = F.pixel_shuffle(x, up)                                 # (B*T, 2H/up^2, h*up, w*up)
+    vs = h * up
+    x = x.view(B, T, -1, vs, w * up).permute(0, 1, 3, 4, 2).reshape(B, T * vs * w * up, -1)
+    x = F.relu(F.linear(x, sd["fc_mvm.1.weight"], sd["fc_mvm.1.bias"]))
+    return F.linear(x, sd["fc_mvm.3.weight"], sd["fc_mvm.3.bias"])
+
+
+def vq_loss(sd, cfg, out_mvm, unmask_img, mvm_mask, tokens=None):
+    """calc_mvm_loss vq branch main_pretrain.py:469-502 ; `tokens` overrides the teacher (used to pin the head alone)"""
+    B, T, _, H, W = unmask_img.shape
+    h, w = H // cfg["size_patch"], W // cfg["size_patch"]
+    if tokens is None:
+        tokens = vq_tokens(sd, cfg, unmask_img)
+    ans = vq_answers(tokens, mvm_mask)
+    lg = vq_logits(sd, cfg, out_mvm, T, h, w)
+    return cross_entropy_ignore(lg.flatten(0, 1), ans.flatten()), lg, ans
+
+
 def cross_entropy_ignore(logits, target):
     """T.nn.CrossEntropyLoss(ignore_index=-1) agent.py:57 (mean over non-ignored; NaN if none)"""
     return F.cross_entropy(logits, target, ignore_index=-1)
@@ -494,7 +610,12 @@ def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
     out = pretrain_forward(sd, cfg, batch["img"], batch["txt"], batch["mask"], negatives, dp_scales)
     ls_mtm = cross_entropy_ignore(out["out_mtm"].flatten(0, 1), batch["ans_mtm"].flatten())
     ls_vtm = cross_entropy_ignore(out["out_vtm"], out["ans_vtm"])
-    ls_mvm = pixel_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"])
+    ls_mvm = 0.0
+    if "pixel" in cfg["mvm_target"]:
+        ls_mvm = ls_mvm + pixel_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"])
+    if "vq" in cfg["mvm_target"]:                             # the step sums the terms of calc_mvm_loss (main_pretrain.py:563-564)
+        lv, _, _ = vq_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("vq_tokens"))
+        ls_mvm = ls_mvm + lv
     return dict(mtm=ls_mtm, vtm=ls_vtm, mvm=ls_mvm, total=ls_mtm + ls_vtm + ls_mvm, out=out)
 
 

@@ -148,3 +148,36 @@ def test_optimizer_groups_schedule_adamw():
             np.testing.assert_allclose(lr, d["lrs"][step - 1][(2 if nd else 0) + (0 if sw else 1)], rtol=1e-9)
             R.adamw_step(ps[i], gs[i] * coef, ms[i], vs[i], step, lr, 0.0 if nd else 1e-3)
         np.testing.assert_allclose(torch.stack(ps).numpy(), d[f"p{step}"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.timeout(900)
+def test_vq_target_tokenizer_head_and_loss():
+    """SURVEY a13 (config C4 ingredients): frozen dVAE tokenizer + decoder_vq / fc_mvm head + CE, against the reference's own
+    DalleModel / calc_mvm_loss run on a reduced encoder (n_hid 64, 512 codes) with closed-form weights."""
+    d = load("vq.npz")
+    cfg = R.make_cfg("tiny", T=4, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512)
+    sd = R.make_state_dict(cfg)
+    params = {k: (v.requires_grad_(True) if not k.startswith("dalle.") else v) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 2)
+    batch = R.default_masking(cfg, img, txt, mask, seed=5)
+    with torch.no_grad():
+        B, T = 2, 4
+        x = batch["unmask_img"].reshape(B * T, 3, 224, 224)
+        mean = torch.tensor(R.IMNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(R.IMNET_STD).view(1, 3, 1, 1)
+        zl = R.dvae_encoder(sd, cfg, 0.8 * (x * std + mean) + 0.1)
+        tok = R.vq_tokens(sd, cfg, batch["unmask_img"])
+    check_samp(d, "z_logits", zl, rtol=2e-4, atol=2e-4)
+    ref_tok = torch.from_numpy(d["tokens"].astype(np.int64))
+    assert tuple(tok.shape) == tuple(ref_tok.shape) == (8, 28, 28)
+    # near-ties (the generator recorded a minimum top-2 margin of ~4e-6) may flip under a different summation order
+    assert int((tok != ref_tok).sum()) <= 2, int((tok != ref_tok).sum())
+    batch["vq_tokens"] = ref_tok
+    ls = R.pretrain_losses(params, cfg, batch, negatives=d["neg"])
+    np.testing.assert_allclose(float(ls["mtm"]), float(d["ls_mtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["vtm"]), float(d["ls_vtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["mvm"]), float(d["ls_mvm"]), rtol=1e-5)
+    ls["total"].backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for k, p in params.items() if not k.startswith("dalle.") and p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
+    for k in ("decoder_vq.0.weight", "decoder_vq.0.bias", "fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=2e-3, atol=2e-6)

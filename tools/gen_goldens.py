@@ -74,8 +74,15 @@ def install_stubs():
     _stub("yapf"); _stub("yapf.yapflib"); _stub("yapf.yapflib.yapf_api", FormatCode=lambda s, **k: (s, True))
     _stub("easydict", EasyDict=_AttrDict)
     _stub("skimage"); _stub("skimage.feature", hog=None); _stub("skimage.transform")
+    class Normalize:                      # torchvision.transforms.Normalize (absent from this image): (x - mean) / std per channel
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
+
+        def __call__(self, x):
+            return (x - self.mean.view(-1, 1, 1).to(x.dtype)) / self.std.view(-1, 1, 1).to(x.dtype)
+
     tv = _stub("torchvision")
-    tv.transforms = _stub("torchvision.transforms", Normalize=object, Compose=object)
+    tv.transforms = _stub("torchvision.transforms", Normalize=Normalize, Compose=object)
     tv.models = _stub("torchvision.models")
     _stub("torchvision.models.optical_flow", raft_large=None)
     _stub("cv2")
@@ -259,6 +266,81 @@ def gold_c1(size="tiny", T=4, B=2, tag="c1"):
     return mp, agent
 
 
+def gold_vq(size="tiny", T=4, B=2, S=224):
+    """MVM 'vq' target = frozen dVAE tokenizer (visbackbone/dalle) + decoder_vq / fc_mvm head + CE.
+    A reduced reference Encoder (n_hid 64, 512 codes) with closed-form weights is pickled the way DalleModel expects."""
+    import main_pretrain as mp
+    from visbackbone.dalle.encoder import Encoder
+    cfg = R.make_cfg(size, T=T, img=S, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512)
+    sd = R.make_state_dict(cfg)
+    enc = Encoder(n_hid=64, vocab_size=512)
+    esd = enc.state_dict()
+    dsh = R.dvae_param_shapes(cfg)
+    assert set("dalle.encoder." + k for k in esd) == set(dsh), (sorted(esd)[:5], sorted(dsh)[:5])
+    enc.load_state_dict({k: sd["dalle.encoder." + k] for k in esd})
+    path = "/tmp/dvae_tiny_ref.pkl"
+    torch.save(enc, path)
+    args = ref_args(size, T, mvm_target="vq")
+    args.update(dalle_model_path=path, size_img=S)
+    _orig_load = torch.load                 # API drift: torch >= 2.6 defaults to weights_only=True; the file is the module pickled above
+    torch.load = lambda f, *a, **k: _orig_load(f, *a, **dict(k, weights_only=False))
+    try:
+        model = mp.VIOLET_Pretrain(args, None).eval()
+    finally:
+        torch.load = _orig_load
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    enc_t = model.trsfr
+    def go_cross(feat_img, mask_img, feat_txt, mask_txt, **kw):
+        feat = torch.cat([feat_img, feat_txt], dim=1)
+        mask = mask_ext(model.get_attn_mask(mask_img, mask_txt))
+        o = enc_t(feat, attention_mask=mask)
+        return (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), ()
+    model.go_cross = go_cross
+    own = model.state_dict()
+    msd = {k: v for k, v in sd.items() if not k.startswith("dalle.")}
+    miss = [k for k in msd if k not in own]
+    assert not miss, miss
+    model.load_state_dict(msd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    calls = {"i": 0}
+    def fake_perm(lst):
+        i = calls["i"]; calls["i"] += 1
+        rest = [j for j in lst if j not in list(neg[i])]
+        return np.array(list(neg[i]) + rest)
+    mp.np.random.permutation = fake_perm
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    batch = dict(mb)
+    out = model(batch)
+    ls_mtm = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    ls_vtm = agent.loss_func(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = agent.calc_mvm_loss(batch, out["out_mvm"], is_train=True)
+    (ls_mtm + ls_vtm + ls_mvm).backward()
+    with torch.no_grad():
+        tok = model.dalle.extract_vq_token(batch["unmask_img"].view(B * T, 3, S, S))
+        zl = model.dalle.encoder(model.dalle.preprocess(batch["unmask_img"].view(B * T, 3, S, S)))
+    top2 = zl.topk(2, dim=1).values
+    d = dict(ls_mtm=np.array(float(ls_mtm)), ls_vtm=np.array(float(ls_vtm)), ls_mvm=np.array(float(ls_mvm)),
+             tokens=tok.numpy().astype(np.int16), min_margin=np.array(float((top2[:, 0] - top2[:, 1]).min())), neg=neg)
+    put(d, "z_logits", zl, 256)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("decoder_vq") or k.startswith("fc_mvm"):
+            put(d, "g." + k, p_.grad, 16)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, "vq.npz"), **d)
+    print("vq ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5, "tokens", tok.shape, "codes used", tok.unique().numel(),
+          "min margin", float(d["min_margin"]))
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -332,8 +414,11 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
-    gold_helpers(vs)
-    gold_reduced_swin(vs)
-    mp, agent = gold_c1("tiny", 4, 2, "c1")
-    gold_masking(mp, agent)
-    gold_optimizer()
+    if "--vq-only" not in sys.argv:
+        gold_helpers(vs)
+        gold_reduced_swin(vs)
+    if "--vq-only" not in sys.argv:
+        mp, agent = gold_c1("tiny", 4, 2, "c1")
+        gold_masking(mp, agent)
+        gold_optimizer()
+    gold_vq()
