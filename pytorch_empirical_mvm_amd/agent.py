@@ -78,6 +78,8 @@ class Agent_Pretrain:
                 txt[i] = torch.where(sel, torch.full_like(txt[i], self.mask_token_id), txt[i])
         ans_mvm = torch.full((B, T * (1 + h * w)), -1, dtype=torch.long)
         out = {"txt": txt, "mask": mask, "ans_mtm": ans_mtm, "ans_mvm": ans_mvm, "cov": cov, "unmask_img": img}
+        if "vq" in self.args.mvm_target:
+            out.update(self.vq_index(cov))
         if materialize:
             full = cov.to(img.dtype).to(img.device)[:, :, None, :, None, :, None].expand(-1, -1, 3, -1, 32, -1, 32).reshape(B, T, 3, H, W)
             out["mvm_mask"] = full
@@ -85,6 +87,20 @@ class Agent_Pretrain:
         else:
             out["img"] = img
         return out
+
+    def vq_index(self, cov):
+        """Host-side index lists for the vq head (main_pretrain.py:485-488): a vq position is a target iff its 32x32 patch is
+        covered, so the head only runs on covered patches.  patch_rows: rows of the MVM output (B*(T*(1+hw)+X) layout of the
+        fusion output) ; tok_index: for each covered patch its 16 token positions (i-major, j-minor) in the (B*T, 28, 28) map."""
+        B, T, h, w = cov.shape
+        up = self.patch_size // 8
+        vs_h, vs_w = h * up, w * up
+        Lq = T * (1 + h * w) + int(self.args.size_txt)
+        b, t, hh, ww = np.nonzero(cov.cpu().numpy())
+        rows = b * Lq + t * (1 + h * w) + 1 + hh * w + ww
+        ii, jj = np.meshgrid(np.arange(up), np.arange(up), indexing="ij")
+        tok = ((b * T + t)[:, None] * vs_h + (hh[:, None] * up + ii.reshape(1, -1))) * vs_w + ww[:, None] * up + jj.reshape(1, -1)
+        return {"vq_patch_rows": torch.from_numpy(rows.astype(np.int32)), "vq_tok_index": torch.from_numpy(tok.reshape(-1).astype(np.int64))}
 
     def prepare_batch(self, batch):
         """agent.py:156-159 (move_to_cuda)"""
@@ -105,6 +121,9 @@ class Agent_Pretrain:
         b = dict(img=src_img.to(eng.device, torch.float32).contiguous(), cov=batch["cov"].to(eng.device).contiguous(),
                  txt=batch["txt"].to(eng.device).contiguous(), mask=batch["mask"].to(eng.device).contiguous(),
                  ans_mtm=batch["ans_mtm"].to(eng.device).contiguous())
+        for k in ("vq_patch_rows", "vq_tok_index", "vq_tokens"):
+            if k in batch and batch[k] is not None:
+                b[k] = batch[k].to(eng.device).contiguous()
         if is_train:
             hook = self.comm.reduce_other if self.comm is not None else None
             losses, _ = eng.forward_backward(b, negatives=negatives, train=True, dp_all=dp_all, on_other_grads_ready=hook)
@@ -118,7 +137,12 @@ class Agent_Pretrain:
             nm = int((ans_m != -1).sum().item())
             ac_mtm = float(((pred_m == ans_m) & (ans_m != -1)).sum().item()) / nm if nm > 0 else -1
             ac_vtm = float((outs["out_vtm"].argmax(-1) == 0).float().mean().item())
-            return {"mtm": ac_mtm, "vtm": ac_vtm, "mvm_pixel": float(losses["mvm"].item())}
+            r = {"mtm": ac_mtm, "vtm": ac_vtm}
+            if "pixel" in self.args.mvm_target:
+                r["mvm_pixel"] = float(losses["mvm_pixel"].item())
+            if "vq" in self.args.mvm_target:           # accuracy over covered positions (main_pretrain.py:503-506)
+                r["mvm_vq"] = float(outs["vq_acc"].item()) if "vq_acc" in outs else -1
+            return r
         if not sync:
             return losses
         return {"mtm": float(losses["mtm"].item()), "mvm": float(losses["mvm"].item()), "vtm": float(losses["vtm"].item()), "smtm": -1}

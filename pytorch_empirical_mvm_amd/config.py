@@ -26,6 +26,7 @@ DEFAULT_ARGS = dict(  # utils/args.py defaults overlaid by _args/args_pretrain.j
     temporal_fusion="vidswin", size_patch=32, max_size_frame=6, max_size_patch=14, p_mask=0.15, seed=88,
     path_ckpt="", path_output="_snapshot/pretrain", logging_steps=20, max_iter=1000, deepspeed=False, use_checkpoint=False,
     dataset=["synthetic"],
+    size_vq=8192, dvae_hid=256, dvae_vocab=8192, dalle_model_path="",      # MVM 'vq' target (main_pretrain.py:144,194-209)
 )
 
 
@@ -64,7 +65,8 @@ def model_cfg(args):
             cfg.update(args[k])
     cfg.update(size=size, hidden=BERT["hidden"], vocab=BERT["vocab"], bert_layers=args.get("bert_layers", BERT["layers"]),
                max_size_frame=args.max_size_frame, max_size_patch=args.max_size_patch, size_patch=args.size_patch,
-               temp=args.temp, mvm_target=list(args.mvm_target))
+               temp=args.temp, mvm_target=list(args.mvm_target), size_vq=args.get("size_vq", 8192),
+               dvae_hid=args.get("dvae_hid", 256), dvae_vocab=args.get("dvae_vocab", 8192))
     return cfg
 
 
@@ -146,6 +148,15 @@ def param_shapes(cfg):
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    if "vq" in cfg["mvm_target"]:          # main_pretrain.py:194-209 (on-the-fly tokenizer branch)
+        up = cfg["size_patch"] // 8
+        c = 2 * H // (up * up)
+        s["decoder_vq.0.weight"] = (2 * H, H, 1, 1)
+        s["decoder_vq.0.bias"] = (2 * H,)
+        s["fc_mvm.1.weight"] = (2 * c, c)
+        s["fc_mvm.1.bias"] = (2 * c,)
+        s["fc_mvm.3.weight"] = (cfg.get("size_vq", 8192), 2 * c)
+        s["fc_mvm.3.bias"] = (cfg.get("size_vq", 8192),)
     return s
 
 

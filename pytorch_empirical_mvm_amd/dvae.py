@@ -1,0 +1,103 @@
+"""Frozen DALL-E dVAE tokenizer for the MVM 'vq' target.
+
+Reference: `DalleModel` visbackbone/dalle/__init__.py:23-58, `Encoder` encoder.py:41-93, `EncoderBlock` :12-39,
+`Conv2d` utils.py:10-43, `map_pixels` :46-52.  The teacher runs without gradient and only produces integer targets.
+
+FIRST PASS (as SURVEY 8f.1 prescribes): the 3x3 / 1x1 convolutions go through PyTorch's `conv2d` (MIOpen on ROCm) in fp16
+like the reference's GPU path -- plumbing around the hand-written student kernels, not part of libvmvm.  A hand-written
+implicit-GEMM MFMA convolution with a fused arg-max epilogue is the planned replacement (1.67 TFLOP per clip at n_hid 256)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+IMNET_MEAN = (0.485, 0.456, 0.406)
+IMNET_STD = (0.229, 0.224, 0.225)
+
+
+def param_shapes(n_hid=256, vocab=8192):
+    """state_dict keys of the reference Encoder (prefix `dalle.encoder.` inside VIOLET_Pretrain)."""
+    s = {}
+    pre = "blocks."
+    s[pre + "input.w"] = (n_hid, 3, 7, 7); s[pre + "input.b"] = (n_hid,)
+    n_in = n_hid
+    for gi, mult in enumerate((1, 2, 4, 8)):
+        n_out = mult * n_hid
+        for bi in range(2):
+            q = pre + f"group_{gi + 1}.block_{bi + 1}."
+            if n_in != n_out:
+                s[q + "id_path.w"] = (n_out, n_in, 1, 1); s[q + "id_path.b"] = (n_out,)
+            hid = n_out // 4
+            s[q + "res_path.conv_1.w"] = (hid, n_in, 3, 3); s[q + "res_path.conv_1.b"] = (hid,)
+            s[q + "res_path.conv_2.w"] = (hid, hid, 3, 3); s[q + "res_path.conv_2.b"] = (hid,)
+            s[q + "res_path.conv_3.w"] = (hid, hid, 3, 3); s[q + "res_path.conv_3.b"] = (hid,)
+            s[q + "res_path.conv_4.w"] = (n_out, hid, 1, 1); s[q + "res_path.conv_4.b"] = (n_out,)
+            n_in = n_out
+    s[pre + "output.conv.w"] = (vocab, 8 * n_hid, 1, 1); s[pre + "output.conv.b"] = (vocab,)
+    return s
+
+
+class DalleTeacher:
+    """Holds the frozen encoder weights (f32 masters + compute-dtype copies) and extracts token maps."""
+
+    def __init__(self, n_hid=256, vocab=8192, device="cuda", dtype=None, seed=0):
+        self.n_hid, self.vocab, self.device = n_hid, vocab, torch.device(device)
+        self.dtype = dtype or (torch.float16 if self.device.type == "cuda" else torch.float32)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.w = {}
+        for k, shp in param_shapes(n_hid, vocab).items():
+            if k.endswith(".w"):                                         # utils.py:28 : normal(std = 1/sqrt(n_in * kw^2)) ; biases zero
+                t = torch.randn(shp, generator=g) / math.sqrt(shp[1] * shp[2] * shp[3])
+            else:
+                t = torch.zeros(shp)
+            self.w[k] = t.to(self.device)
+        self._refresh()
+
+    def _refresh(self):
+        self.c = {k: (v if k.startswith("blocks.output") else v.to(self.dtype)) for k, v in self.w.items()}    # last conv stays f32 (encoder.py:72)
+
+    def state_dict(self, prefix="dalle.encoder."):
+        return {prefix + k: v.detach().cpu() for k, v in self.w.items()}
+
+    def load_state_dict(self, sd, prefix="dalle.encoder."):
+        for k in self.w:
+            if prefix + k in sd:
+                self.w[k] = sd[prefix + k].to(self.device, torch.float32).reshape(self.w[k].shape)
+        self._refresh()
+
+    def _conv(self, x, k):
+        w = self.c[k + ".w"]
+        return F.conv2d(x.to(w.dtype), w, self.c[k + ".b"], padding=(w.shape[-1] - 1) // 2)
+
+    @torch.no_grad()
+    def logits(self, x):
+        """x: (N,3,H,W) f32 already un-normalised and pixel-mapped -> (N, vocab, H/8, W/8) f32"""
+        post_gain = 1.0 / (4 * 2) ** 2
+        x = self._conv(x, "blocks.input")
+        for gi in range(4):
+            for bi in range(2):
+                q = f"blocks.group_{gi + 1}.block_{bi + 1}."
+                idp = self._conv(x, q + "id_path") if (q + "id_path.w") in self.c else x
+                r = self._conv(F.relu(x), q + "res_path.conv_1")
+                r = self._conv(F.relu(r), q + "res_path.conv_2")
+                r = self._conv(F.relu(r), q + "res_path.conv_3")
+                r = self._conv(F.relu(r), q + "res_path.conv_4")
+                x = idp + post_gain * r
+            if gi < 3:
+                x = F.max_pool2d(x, 2)
+        return self._conv(F.relu(x).float(), "blocks.output.conv")
+
+    @torch.no_grad()
+    def extract_vq_token(self, img, chunk=32):
+        """DalleModel.extract_vq_token (__init__.py:44-54): img (N,3,H,W) ImageNet-normalised f32 -> (N, H/8, W/8) int64"""
+        mean = torch.tensor(IMNET_MEAN, device=img.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMNET_STD, device=img.device).view(1, 3, 1, 1)
+        out = []
+        for a in range(0, img.shape[0], chunk):                          # bounded activation memory (224^2 x 256 ch per frame)
+            x = img[a:a + chunk].float() * std + mean
+            x = 0.8 * x + 0.1                                            # map_pixels, logit_laplace_eps = 0.1
+            out.append(torch.argmax(self.logits(x), dim=1))
+        return torch.cat(out, 0)
+
+    def get_vq_patch_size(self):
+        return 8

@@ -162,6 +162,7 @@ class VioletEngine:
         self.rng_offset = 0
         self._idx_cache = {}
         self.tape = []
+        self.teacher = None                 # frozen dVAE tokenizer (MVM 'vq' target), set by the model
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
@@ -466,7 +467,7 @@ class VioletEngine:
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
         out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
-        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm")}
+        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq")}
         outs = {}
 
         # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560)
@@ -505,33 +506,83 @@ class VioletEngine:
         # ---- MVM pixel head (main_pretrain.py:178-179,420-432)
         ps = cfg["size_patch"]
         h_, w_ = H // ps, W // ps
+        targets = cfg["mvm_target"]
+        use_pix, use_vq = "pixel" in targets, "vq" in targets
         vis_rows = self._cached(("vis_rows", B, T, hw, Lq), lambda: _dev_i32(
             np.concatenate([i * Lq + t * (1 + hw) + 1 + np.arange(hw) for i in range(B) for t in range(T)]), dev))
-        r_p = K.gather_rows(out1.t, vis_rows, B * T * hw)
-        Wpix = S.b("decoder_pixel.0.weight", (3 * ps * ps, Hd))
-        pred = K.gemm(r_p, Wpix, bias=S.p("decoder_pixel.0.bias"))
-        mask_sum = (cov.to(F32).sum() * float(3 * ps * ps)).view(1)
-        dpred = K.pixel_l1(pred, img, cov.reshape(-1), mask_sum, losses["mvm"], B, T, h_, w_, ps)
+        if use_pix:
+            r_p = K.gather_rows(out1.t, vis_rows, B * T * hw)
+            Wpix = S.b("decoder_pixel.0.weight", (3 * ps * ps, Hd))
+            pred = K.gemm(r_p, Wpix, bias=S.p("decoder_pixel.0.bias"))
+            mask_sum = (cov.to(F32).sum() * float(3 * ps * ps)).view(1)
+            dpred = K.pixel_l1(pred, img, cov.reshape(-1), mask_sum, losses["mvm_pixel"], B, T, h_, w_, ps)
+            if want_outputs:
+                outs["pred_pixel"] = pred
+        # ---- MVM vq head (main_pretrain.py:194-209,469-502): frozen dVAE tokens as targets; decoder_vq (1x1 conv H -> 2H) +
+        # PixelShuffle(4) + fc_mvm MLP + CE.  Only covered patches carry targets (ans = -1 elsewhere), so the head runs on the
+        # covered patches' rows only.  PixelShuffle is folded into a row permutation of the decoder weight: output channel
+        # c*16 + (i*4+j) moves to (i*4+j)*96 + c, so one GEMM row is 16 consecutive 96-channel positions.
+        n_mp = 0
+        if use_vq and "vq_patch_rows" in batch:
+            prow, tix = batch["vq_patch_rows"], batch["vq_tok_index"]
+            n_mp = int(prow.numel())
+        if use_vq and n_mp > 0:
+            up = ps // 8
+            cq = 2 * Hd // (up * up)
+            Vq = cfg.get("size_vq", 8192)
+            tokens = batch.get("vq_tokens")
+            if tokens is None:
+                tokens = self.teacher.extract_vq_token(img.view(B * T, 3, H, W))
+            tgt_q = tokens.reshape(-1)[tix].contiguous()
+            perm = self._cached(("vq_perm", Hd, up), lambda: torch.from_numpy(
+                (np.arange(cq)[None, :] * (up * up) + np.arange(up * up)[:, None]).reshape(-1).astype(np.int64)).to(dev))
+            Wq = S.b("decoder_vq.0.weight", (2 * Hd, Hd)).index_select(0, perm)       # (tiny; plumbing)
+            bq = S.p("decoder_vq.0.bias").index_select(0, perm)
+            r_q = K.gather_rows(out1.t, prow, n_mp)
+            y_q = K.gemm(r_q, Wq, bias=bq)                                            # [n_mp, 16*cq]
+            x_q = y_q.view(n_mp * up * up, cq)
+            p_q = 0.1 if train else 0.0
+            off_q = self._next_offset(x_q.numel())
+            x_qd = K.dropout(x_q, p_q, self.seed, off_q) if p_q > 0 else x_q
+            h_q = K.gemm(x_qd, S.b("fc_mvm.1.weight"), bias=S.p("fc_mvm.1.bias"), act=2)
+            lg_q = K.gemm(h_q, S.b("fc_mvm.3.weight"), bias=S.p("fc_mvm.3.bias"), out_dtype=F32)
+            dlg_q = K.cross_entropy(lg_q, Vq, tgt_q, losses["mvm_vq"], want_grad=backward, ld_d=Vq)
+            if want_outputs:
+                outs["vq_logits"], outs["vq_targets"] = lg_q, tgt_q
+                outs["vq_acc"] = (lg_q.argmax(-1) == tgt_q).float().mean()
+        losses["mvm"] = losses["mvm_pixel"] + losses["mvm_vq"]
         if want_outputs:
             outs["out_mvm"] = out1.t.view(B, Lq, Hd)[:, :Lv]
-            outs["pred_pixel"] = pred
         if not backward:
             self.tape = []
             return losses, outs
 
         # =============================== backward ===============================
         # heads -> gradients of the two encoder outputs
-        dcat = torch.empty((B * T * hw + B * X, Hd), device=dev, dtype=BF16)       # [pixel rows ; mlm rows]
-        self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
-                         dx_kw=dict(out=dcat[:B * T * hw]), wT=S.bt("decoder_pixel.0.weight"))
+        npx = B * T * hw if use_pix else 0
+        dcat = torch.empty((npx + B * X, Hd), device=dev, dtype=BF16)              # [pixel rows ; mlm rows]
+        if use_pix:
+            self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
+                             dx_kw=dict(out=dcat[:npx]), wT=S.bt("decoder_pixel.0.weight"))
         K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
         K.gemm(dlog, tn, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
         dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
         dt_m, _ = K.layernorm_bwd(dtn, t_m, gm, mean_m, rstd_m, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
         du_m = K.gelu_bwd(dt_m, u_m)
-        self._linear_bwd(du_m, r_m, pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dcat[B * T * hw:]))
-        inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows]))
+        self._linear_bwd(du_m, r_m, pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dcat[npx:]))
+        inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X, use_pix), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows] if use_pix else [txt_rows]))
         out1.g = K.gather_rows(dcat, inv1, B * Lq)
+        if use_vq and n_mp > 0:
+            dh_q = self._linear_bwd(dlg_q, h_q, "fc_mvm.3.weight", "fc_mvm.3.bias", dx_kw=dict(act=4, aux=h_q))     # ReLU' folded into the dgrad
+            dx_q = self._linear_bwd(dh_q, x_qd, "fc_mvm.1.weight", "fc_mvm.1.bias")
+            if p_q > 0:
+                dx_q = K.dropout(dx_q, p_q, self.seed, off_q)
+            gWq = torch.zeros((2 * Hd, Hd), device=dev, dtype=F32)
+            gbq = torch.zeros(2 * Hd, device=dev, dtype=F32)
+            dr_q = self._linear_bwd(dx_q.view(n_mp, 2 * Hd), r_q, None, None, w=Wq, gw=gWq, gb=gbq)
+            S.g("decoder_vq.0.weight", (2 * Hd, Hd)).index_add_(0, perm, gWq)          # undo the PixelShuffle row permutation
+            S.g("decoder_vq.0.bias").index_add_(0, perm, gbq)
+            out1.g.index_add_(0, prow.long(), dr_q)                                     # covered-patch rows (unique) of the fusion output
         # VTM
         dlg = dlg_v.float().reshape(-1).contiguous()
         dh_v = K.rowdot_bwd(h_v, S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)

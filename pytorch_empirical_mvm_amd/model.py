@@ -58,6 +58,14 @@ class VIOLET_Pretrain(torch.nn.Module):
             for b in range(d):
                 getattr(self.enc_img.swin.layers, str(i)).blocks.__getattr__(str(b)).attn.register_buffer("relative_position_index", rpi)
         self.init_weights(args.get("seed", 88))
+        # MVM 'vq' target: frozen dVAE tokenizer (main_pretrain.py:194-198).  Offline there is no pickled `dall_e` encoder, so
+        # the teacher is randomly initialised like the reference's Conv2d unless `dalle.encoder.*` tensors are loaded.
+        self.dalle = None
+        if "vq" in self.cfg["mvm_target"]:
+            from .dvae import DalleTeacher
+            self.dalle = DalleTeacher(self.cfg["dvae_hid"], self.cfg["dvae_vocab"], device=self.engine.device, dtype=args.get("dvae_dtype"),
+                                      seed=args.get("seed", 88))
+            self.engine.teacher = self.dalle
 
     # ------------------------------------------------------------------ init / state
     @torch.no_grad()
@@ -73,8 +81,10 @@ class VIOLET_Pretrain(torch.nn.Module):
             if is_ln:
                 t.fill_(1.0 if last == "weight" else 0.0)
             elif last == "bias":
-                if name in ("fc.1.bias", "fc.3.bias", "decoder_pixel.0.bias", "enc_img.fc.bias", "enc_img.swin.patch_embed.proj.bias"):
+                if name in ("fc.1.bias", "fc.3.bias", "decoder_pixel.0.bias", "enc_img.fc.bias", "enc_img.swin.patch_embed.proj.bias",
+                            "decoder_vq.0.bias", "fc_mvm.1.bias", "fc_mvm.3.bias"):
                     fan_in = {"fc.1.bias": self.hidden_size, "fc.3.bias": 2 * self.hidden_size, "decoder_pixel.0.bias": self.hidden_size,
+                              "decoder_vq.0.bias": self.hidden_size, "fc_mvm.1.bias": self.hidden_size // 8, "fc_mvm.3.bias": self.hidden_size // 4,
                               "enc_img.fc.bias": self.cfg["embed_dim"] * 8, "enc_img.swin.patch_embed.proj.bias": 96}[name]
                     b = 1.0 / math.sqrt(fan_in)
                     t.uniform_(-b, b, generator=gen)
@@ -108,6 +118,8 @@ class VIOLET_Pretrain(torch.nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
         self.engine.store.load_state({k: v for k, v in sd.items() if k in self.engine.store.index})
+        if self.dalle is not None:
+            self.dalle.load_state_dict(sd)
         return missing, unexpected
 
     def load_ckpt(self, ckpt):
@@ -146,4 +158,4 @@ class VIOLET_Pretrain(torch.nn.Module):
         O = min(B, 4)
         return {"out_vtm": outs["out_vtm"], "out_mvm": outs["out_mvm"], "out_mtm": outs["out_mtm"], "out_smtm": None,
                 "ans_vtm": torch.zeros(B, dtype=torch.long, device=dev), "ans_mtm": b["ans_mtm"], "ans_mvm": batch.get("ans_mvm"),
-                "ans_smtm": None, "losses": losses, "pred_pixel": outs["pred_pixel"]}
+                "ans_smtm": None, "losses": losses, "pred_pixel": outs.get("pred_pixel")}

@@ -79,3 +79,31 @@ def test_arena_layout_groups_and_fused_qkv():
     S.p(qn[1]).fill_(2.0)
     assert float(w[H:2 * H].sum()) == 2.0 * H * H and float(w[:H].sum()) == 0.0
     assert S.n_trainable == S.segments[3][1]
+
+
+def test_vq_index_matches_reference_answer_map():
+    """SURVEY a13 host side: covered vq positions (max_pool2d(mvm_mask, 8) != 0, main_pretrain.py:485-488) <-> index lists"""
+    import numpy as np
+    import torch
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+
+    class _M:                                   # masking()/vq_index() only need these attributes
+        patch_size = 32
+        class engine: device = "cpu"
+    args = CFG.get_args(mvm_target=["vq"], size_frame=4, size_txt=32)
+    ag = Agent_Pretrain.__new__(Agent_Pretrain)
+    ag.args, ag.patch_size = args, 32
+    cfg = R.make_cfg("tiny", T=4, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512)
+    img, txt, mask = R.make_batch(cfg, 3)
+    mb = R.default_masking(cfg, img, txt, mask, seed=11)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    vqi = ag.vq_index(cov)
+    tok = torch.arange(3 * 4 * 28 * 28).view(12, 28, 28)
+    ans = R.vq_answers(tok, mb["mvm_mask"]).flatten()
+    assert sorted(vqi["vq_tok_index"].tolist()) == torch.nonzero(ans != -1).flatten().tolist()
+    assert vqi["vq_patch_rows"].numel() * 16 == vqi["vq_tok_index"].numel() == int(cov.sum()) * 16
+    Lq = 4 * 50 + 32
+    b, t, hh, ww = np.nonzero(cov.numpy())
+    np.testing.assert_array_equal(vqi["vq_patch_rows"].numpy(), b * Lq + t * 50 + 1 + hh * 7 + ww)

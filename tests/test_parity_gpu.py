@@ -186,3 +186,47 @@ def test_train_step_matches_oracle_adamw_trajectory():
     ug = torch.cat([(got[k].cpu() - R.closed_form(k, tuple(v.shape))).double().flatten() for k, v in sd.items()])
     assert float(ur.norm()) > 0 and _cos(ur, ug) > 0.85, _cos(ur, ug)
     assert abs(float(ug.norm()) / float(ur.norm()) - 1.0) < 0.1
+
+
+def test_vq_target_head_loss_and_grads_vs_reference_golden():
+    """MVM 'vq' target.  Fixture `vq.npz` comes from the REFERENCE (DalleModel + calc_mvm_loss on a reduced dVAE
+    encoder).  The teacher's tokens are checked separately in fp32; the head / loss / gradients are checked with the golden
+    tokens as input (an arg-max near-tie must not decide the comparison)."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, "vq.npz"))
+    cfg = R.make_cfg("tiny", T=4, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512)
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512,
+                               dvae_dtype=torch.float32))
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    agent = Agent_Pretrain(args, model)
+    img, txt, mask = R.make_batch(cfg, 2)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    dev = "cuda"
+    ref_tok = torch.from_numpy(d["tokens"].astype(np.int64))
+    # teacher (PyTorch conv first pass, fp32 here): token agreement with the reference's tokenizer
+    tok = model.dalle.extract_vq_token(img.view(8, 3, 224, 224).to(dev)).cpu()
+    assert float((tok == ref_tok).float().mean()) >= 0.99, float((tok == ref_tok).float().mean())
+    vqi = agent.vq_index(cov)
+    batch = dict(img=img.to(dev), cov=cov.to(dev).contiguous(), txt=mb["txt"].to(dev), mask=mask.to(dev), ans_mtm=mb["ans_mtm"].to(dev),
+                 vq_patch_rows=vqi["vq_patch_rows"].to(dev), vq_tok_index=vqi["vq_tok_index"].to(dev), vq_tokens=ref_tok.to(dev))
+    # the index lists reproduce the reference's answer map: covered positions <-> ans != -1
+    ans = R.vq_answers(ref_tok, mb["mvm_mask"]).flatten()
+    assert sorted(vqi["vq_tok_index"].tolist()) == torch.nonzero(ans != -1).flatten().tolist()
+    eng = model.engine
+    eng.store.grad.zero_()
+    losses, outs = eng.forward_backward(batch, negatives=d["neg"], train=False, want_outputs=True, backward=True)
+    torch.cuda.synchronize()
+    got = float(losses["mvm"].item())
+    assert abs(got - float(d["ls_mvm"])) <= 2e-2 * float(d["ls_mvm"]), (got, float(d["ls_mvm"]))
+    assert abs(float(losses["mtm"].item()) - float(d["ls_mtm"])) <= 2e-2 * float(d["ls_mtm"])
+    gn = float(eng.store.grad[:eng.store.n_trainable].double().pow(2).sum().sqrt().item())
+    assert abs(gn - float(d["grad_norm"])) <= 5e-2 * float(d["grad_norm"]), (gn, float(d["grad_norm"]))
+    for k in ("decoder_vq.0.weight", "decoder_vq.0.bias", "fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
+        _check_samples(d, "g." + k, eng.store.g(k).reshape(tuple(d[f"g.{k}.shape"])), tol=5e-2)
+    # one optimizer step through the agent surface with the teacher in the loop (train mode, dropout on)
+    masked = dict(mb); masked.update(cov=cov, unmask_img=img); masked.update(vqi)
+    r = agent.step(agent.prepare_batch(masked), is_train=True)
+    assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
