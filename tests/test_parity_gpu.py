@@ -230,3 +230,65 @@ def test_vq_target_head_loss_and_grads_vs_reference_golden():
     masked = dict(mb); masked.update(cov=cov, unmask_img=img); masked.update(vqi)
     r = agent.step(agent.prepare_batch(masked), is_train=True)
     assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
+
+
+@pytest.mark.timeout(900)
+def test_full_size_c2_forward_losses_vs_oracle():
+    """BASELINE config C2 shapes end to end (Swin-B, 8 x 224^2 frames, 32 text tokens, 392-token windows, 432-token fusion
+    sequences: the exact-tile kernels only run at these sizes): the three losses and sampled outputs against the CPU oracle's
+    forward (B = 2 keeps the oracle to seconds)."""
+    from oracle import violet_ref as R
+    cfg = R.make_cfg("base", T=8)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8))
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    B = 2
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=3)
+    assert int((mb["ans_mtm"] != -1).sum()) > 0 and float(mb["mvm_mask"].sum()) > 0
+    neg = R.vtm_negatives_default(B)
+    with torch.no_grad():
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        ref = R.pretrain_losses(sd, cfg, mb, negatives=neg)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+    batch = dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+    losses, outs = model.engine.forward_backward(batch, negatives=neg, train=False, want_outputs=True, backward=False)
+    torch.cuda.synchronize()
+    for k in ("mtm", "mvm"):
+        got, want = float(losses[k].item()), float(ref[k])
+        assert abs(got - want) <= 2e-2 * abs(want) + 1e-3, (k, got, want)
+    assert abs(float(losses["vtm"].item()) - float(ref["vtm"])) <= 8e-2, (float(losses["vtm"].item()), float(ref["vtm"]))    # logits / temp 0.05
+    assert _cos(outs["out_mvm"].float().cpu(), ref["out"]["out_mvm"]) >= 0.999
+    assert _cos(outs["out_mtm"].float().cpu(), ref["out"]["out_mtm"]) >= 0.999
+
+
+def test_full_size_batch_permutation_invariance():
+    """Size-independent property at the C2 shapes (B = 4): permuting the clips of a batch (and the VTM negatives with them)
+    leaves every loss and the whole gradient arena unchanged up to summation order."""
+    from oracle import violet_ref as R
+    cfg = R.make_cfg("base", T=8)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8))
+    B = 4
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=3)
+    assert int((mb["ans_mtm"] != -1).sum()) > 0
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    neg = R.vtm_negatives_default(B)
+    eng = model.engine
+
+    def run(perm):
+        inv = np.argsort(perm)
+        b = dict(img=img[perm].cuda(), cov=cov[perm].cuda().contiguous(), txt=mb["txt"][perm].cuda(), mask=mask[perm].cuda(),
+                 ans_mtm=mb["ans_mtm"][perm].cuda())
+        ng = np.array([[inv[j] for j in neg[perm[i]]] for i in range(B)])
+        eng.store.grad.zero_()
+        ls, _ = eng.forward_backward(b, negatives=ng, train=False, backward=True)
+        torch.cuda.synchronize()
+        return {k: float(v.item()) for k, v in ls.items()}, eng.store.grad[:eng.store.n_trainable].clone()
+
+    l0, g0 = run(np.arange(B))
+    l1, g1 = run(np.array([2, 0, 3, 1]))
+    for k in ("mtm", "vtm", "mvm"):
+        assert abs(l0[k] - l1[k]) <= 2e-3 * abs(l0[k]) + 1e-4, (k, l0[k], l1[k])
+    assert _cos(g0, g1) >= 0.9995, _cos(g0, g1)
+    assert abs(float(g0.norm()) - float(g1.norm())) <= 1e-2 * float(g0.norm())
