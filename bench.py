@@ -181,7 +181,7 @@ def main():
         "metric": "pretrain clips/sec (Swin-B, 8x224^2, 32 txt tok)", "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{'C2' if a.mvm_target == 'pixel' else 'C4 (1 GPU; dVAE tokenizer = PyTorch conv first pass, random weights)'}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window(8,7,7), {a.frames}x224^2 frames, 32 text tokens, "
+        "config": {"workload": f"{'C2' if a.mvm_target == 'pixel' else 'C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)'}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window(8,7,7), {a.frames}x224^2 frames, 32 text tokens, "
                                f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if a.mvm_target == "pixel" else None,

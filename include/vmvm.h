@@ -67,6 +67,11 @@ typedef struct {
   int32_t splitk;         /* 0 = auto (split the reduction when C is a plain f32 accumulator), 1 = off, >1 = K slices */
   void* workspace; int64_t workspace_bytes;   /* optional caller-owned scratch for split-K slabs (splitk*M*N f32); without it
                                                  the slices combine with f32 atomics */
+  /* fp16 element type + implicit-GEMM convolution (frozen dVAE tokenizer of the MVM 'vq' target, visbackbone/dalle/encoder.py):
+   * in_fp16 = 1: A, B, C (bf16 slots), aux and resid are IEEE fp16.  conv_taps = 9 (3x3, padding 1): A is an NHWC activation
+   * [n_img*conv_h*conv_w][lda] with C_in = K / 9 channels (multiple of 64), B is [C_out][9*C_in] with k = tap*C_in + c and
+   * tap = (dy+1)*3 + (dx+1); rows whose tap falls outside the image read zeros.  Both need k-major operands. */
+  int32_t in_fp16, conv_taps, conv_h, conv_w;
   float* colsum;          /* optional, a_kmajor=0 only: colsum[m] += sum_k A(m,k)  (f32 [M]).  The bias gradient of a Linear is the
                              column sum of dY, and dY is the A operand of its weight-gradient GEMM dW = dY^T X: fused, the extra
                              pass over dY (vmvm_colsum_bf16) disappears into one more MFMA per fragment on the first N tile. */

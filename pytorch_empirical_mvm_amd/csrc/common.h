@@ -42,6 +42,27 @@ __device__ __forceinline__ uint4 pack_bf8(const float* f) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
+// fp16 twins of pack_bf8 / unpack_bf8 (the frozen dVAE tokenizer runs in fp16 like the reference's GPU path)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, f16x2));
+}
+__device__ __forceinline__ uint4 pack_h8(const float* f) {
+  return make_uint4(pack_h2(f[0], f[1]), pack_h2(f[2], f[3]), pack_h2(f[4], f[5]), pack_h2(f[6], f[7]));
+}
+__device__ __forceinline__ void unpack_h8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = __builtin_bit_cast(f16x2, w[i]);
+    f[2 * i] = (float)h[0]; f[2 * i + 1] = (float)h[1];
+  }
+}
+template <bool F16> __device__ __forceinline__ uint4 pack8(const float* f) { return F16 ? pack_h8(f) : pack_bf8(f); }
+template <bool F16> __device__ __forceinline__ void unpack8(const uint4& v, float* f) { if (F16) unpack_h8(v, f); else unpack_bf8(v, f); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -213,7 +213,7 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
 enum : int { EF_BIAS = 1, EF_COLSCALE = 2, EF_ACT1 = 4, EF_ACT24 = 8, EF_ACT3 = 16, EF_RS = 32, EF_DROP = 64, EF_RESID = 128,
              EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095,
              EF_COLSUM = 4096 /* fused column sum of the m-major A operand (not part of EF_ALL: only the wgrad build carries it) */ };
-template <int F>
+template <int F, bool F16 = false>
 __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid,
                                            const float (&bz)[8], const uint4& auxv, const uint4& resv) {
   // bz / auxv / resv: bias, saved activation and residual of this fragment, requested by the caller BEFORE the tile's first
@@ -233,7 +233,7 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
     for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
   }
   if ((F & EF_ACT1) && p.act == 1) {
-    if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack_bf8(v);
+    if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack8<F16>(v);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
   } else if ((F & EF_ACT24) && p.act == 2) {
@@ -241,12 +241,12 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   } else if ((F & EF_ACT3) && p.act == 3) {
     float u[8];
-    unpack_bf8(auxv, u);
+    unpack8<F16>(auxv, u);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
   } else if ((F & EF_ACT24) && p.act == 4) {
     float u[8];
-    unpack_bf8(auxv, u);
+    unpack8<F16>(auxv, u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= (u[e] > 0.f ? 1.f : 0.f);
   }
@@ -268,7 +268,7 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
   }
   if ((F & EF_RESID) && p.resid) {
     float rr[8];
-    unpack_bf8(resv, rr);
+    unpack8<F16>(resv, rr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += rr[e];
   }
@@ -291,7 +291,7 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
     *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
   } else {
-    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) = pack_bf8(v);
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)dst * p.ldc + n) = pack8<F16>(v);
   }
 }
 
@@ -831,7 +831,9 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // stage 1/2: K = 128..512, i.e. 2..8 K tiles) are otherwise dominated by the load latency of the prologue and by store
 // phases during which nothing is in flight (measured 1.8-2.2 TB/s on HBM-bound shapes = half of what the copy rate allows).
 // =====================================================================================================================
-template <bool AK, bool BKM, int F>
+// F16: fp16 operands / outputs (v_mfma_f32_16x16x32_f16).  CONV: A is an NHWC activation read as an implicit 3x3 convolution
+// (K = 9 * C_in, one tap per C_in/64 consecutive K tiles; rows whose tap leaves the image get an out-of-range DMA offset = zeros).
+template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -851,7 +853,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   const u16* A = reinterpret_cast<const u16*>(p.A);
   const u16* B = reinterpret_cast<const u16*>(p.B);
   const size_t bytesA = (size_t)(AK ? M : K) * p.lda * 2, bytesB = (size_t)(BKM ? N : K) * p.ldb * 2;
-  const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A), 0, (int)bytesA, 0x00020000);
+  // conv mode: the descriptor base sits (W+1) pixels BEFORE the activation so every tap offset is non-negative; the rows that
+  // would read in front of / behind the tensor are exactly the ones masked out below
+  const int cC = CONV ? K / p.conv_taps : 0;                               // input channels
+  const unsigned conv_shift = CONV ? (unsigned)((p.conv_w + 1) * cC * 2) : 0u;
+  const unsigned a_records = (unsigned)bytesA + 2u * conv_shift;
+  const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(A) - (conv_shift >> 1), 0, (int)a_records, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(B), 0, (int)bytesB, 0x00020000);
   const int r = lane & 15, g = lane >> 4;
   EpiCtx ec;
@@ -873,10 +880,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   // vector address arithmetic was ~30 of the ~100 non-MFMA issue slots of a K step.)
   const int wave_base_s = __builtin_amdgcn_readfirstlane(tid & ~63);
   const unsigned kstepA = (unsigned)((AK ? BK : BK * p.lda) * 2), kstepB = (unsigned)((BKM ? BK : BK * p.ldb) * 2);
-  auto tile_offsets = [&](int m0, int n0, unsigned (&vA)[4], unsigned (&vB)[4]) {
+  auto tile_offsets = [&](int m0, int n0, unsigned (&vA)[4], unsigned (&vB)[4], int (&py)[4], int (&px)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = tid + i * 256;
+      py[i] = 0; px[i] = 0;
+      if (CONV) {                                           // pixel (y, x) of this request's row; rows >= M are parked outside the image
+        const int pix = m0 + (u >> 3);
+        const int q = pix / p.conv_w;
+        px[i] = pix - q * p.conv_w; py[i] = (pix < M) ? q % p.conv_h : -4;
+      }
       if (AK) { const int row = u >> 3, cs = u & 7; vA[i] = (unsigned)(((size_t)(m0 + row) * p.lda + (cs ^ kswz<false>(row)) * 8) * 2); }
       else { const int krow = u >> 4, unit = u & 15; const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
              vA[i] = (unsigned)(((size_t)krow * p.lda + m0 + (slot * 2 + (unit & 1)) * 8) * 2); }
@@ -885,12 +898,23 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
              vB[i] = (unsigned)(((size_t)krow * p.ldb + n0 + (slot * 2 + (unit & 1)) * 8) * 2); }
     }
   };
-  auto issue = [&](const unsigned (&vA)[4], const unsigned (&vB)[4], int kt, int buf) {
+  auto issue = [&](const unsigned* vA, const unsigned* vB, const int* py, const int* px, int kt, int buf) {
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned char* st = smem + buf * 2 * TILE_BYTES + wave_base_s * 16;
-    const unsigned sa = (unsigned)kt * kstepA, sb = (unsigned)kt * kstepB;
+    unsigned sa = (unsigned)kt * kstepA;
+    const unsigned sb = (unsigned)kt * kstepB;
+    int dy = 0, dx = 0;
+    if (CONV) {                                             // K tile kt = tap * (C/64) + channel block
+      const int cpt = cC >> 6, tap = kt / cpt, cb = kt - tap * cpt;
+      dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+      sa = (unsigned)(((dy + 1) * p.conv_w + (dx + 1)) * cC + cb * 64) * 2u;
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + i * 4096), 16, vA[i], sa, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      unsigned vo = vA[i];
+      if (CONV) vo = ((unsigned)(py[i] + dy) < (unsigned)p.conv_h && (unsigned)(px[i] + dx) < (unsigned)p.conv_w) ? vo : a_records;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + i * 4096), 16, vo, sa, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + TILE_BYTES + i * 4096), 16, vB[i], sb, 0, 0);
   };
@@ -901,8 +925,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   decode(w, slice, m0, n0, kt0, nk);
   unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
   unsigned voA[4], voB[4], nvoA[4], nvoB[4];
-  tile_offsets(m0, n0, voA, voB);
-  issue(voA, voB, kt0, it & 1);
+  int pyA[4], pxA[4], npyA[4], npxA[4];
+  tile_offsets(m0, n0, voA, voB, pyA, pxA);
+  issue(voA, voB, pyA, pxA, kt0, it & 1);
   while (true) {
     f32x4 acc[4][4];
 #pragma unroll
@@ -918,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     const int wn_ = w + per_xcd;
     const bool more = wn_ < x_cnt;
     int nslice = 0, nm0 = 0, nn0 = 0, nkt0 = 0, nnk = 0;
-    if (more) { decode(wn_, nslice, nm0, nn0, nkt0, nnk); tile_offsets(nm0, nn0, nvoA, nvoB); }
+    if (more) { decode(wn_, nslice, nm0, nn0, nkt0, nnk); tile_offsets(nm0, nn0, nvoA, nvoB, npyA, npxA); }
     for (int kt = kt0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
@@ -958,7 +983,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[s][j]), __builtin_bit_cast(f16x8, fa[s][i]), acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
         if ((F & EF_COLSUM) && do_cs) {
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 o8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};      // bf16 1.0
@@ -967,8 +993,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         }
       };
       load_set(0);
-      if (kt + 1 < nk) issue(voA, voB, kt + 1, cur ^ 1);
-      else if (more) issue(nvoA, nvoB, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
+      if (kt + 1 < nk) issue(voA, voB, pyA, pxA, kt + 1, cur ^ 1);
+      else if (more) issue(nvoA, nvoB, npyA, npxA, nkt0, cur ^ 1);     // cross-tile prefetch: overlaps this tile's last MFMAs + epilogue
       finish_set(0);
       load_set(1);
       mfma_set(0);
@@ -1031,13 +1057,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         const int n = n0 + wn * 64 + jb * 32 + g * 8;
         float v[8] = {acc[i][2 * jb][0], acc[i][2 * jb][1], acc[i][2 * jb][2], acc[i][2 * jb][3],
                       acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
-        if (rvalid[i] && n < N) epi_store8<F>(p, ec, v, m, rdst[i], n, rrs[i], N - n, bz[jb], auxv[i][jb], resv[i][jb]);
+        if (rvalid[i] && n < N) epi_store8<F, F16>(p, ec, v, m, rdst[i], n, rrs[i], N - n, bz[jb], auxv[i][jb], resv[i][jb]);
       }
     }
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { voA[i] = nvoA[i]; voB[i] = nvoB[i]; }
+    for (int i = 0; i < 4; ++i) { voA[i] = nvoA[i]; voB[i] = nvoB[i]; pyA[i] = npyA[i]; pxA[i] = npxA[i]; }
   }
 }
 
@@ -1083,6 +1109,23 @@ static int epi_need(const vmvm_gemm_desc& d) {
 // The instantiations cover the epilogue classes of the training step (plain; qkv = bias + q scale; fc1 = bias + GELU + saved
 // pre-activation; fc2 dgrad = GELU' x saved; proj / fc2 = bias + dropout + residual (+ window un-gather); wgrad = f32 split-K)
 // and fall back to the all-features build for anything else.
+// fp16 / implicit-convolution builds (frozen dVAE tokenizer): one epilogue mask covers its four GEMM forms
+constexpr int EF_TEACHER = EF_BIAS | EF_COLSCALE | EF_ACT24 | EF_RESID | EF_F32;
+template <bool CONV>
+int launch_pers_teacher(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, EF_TEACHER, true, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_done = true;
+  }
+  int grid = 512;
+  if (items < grid) grid = ((items + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_pers_kernel<true, true, EF_TEACHER, true, CONV>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
 template <bool AK, bool BKM>
 int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
   const int need = epi_need(d);
@@ -1107,6 +1150,23 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
   if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
+  if (d->in_fp16 || d->conv_taps) {
+    // fp16 / implicit 3x3 convolution builds of the persistent kernel (frozen dVAE tokenizer): k-major operands, whole K tiles,
+    // epilogue features within EF_TEACHER
+    const int taps = d->conv_taps;
+    if (!d->in_fp16 || !d->a_kmajor || !d->b_kmajor || (taps != 0 && taps != 9)) return VMVM_ENOSUPPORT;
+    if ((d->K % BK) || (d->N & 7) || d->row_scale || d->dropout_p > 0.f || d->row_map || d->C2 || d->accumulate || d->colsum ||
+        (d->act != 0 && d->act != 2) || d->splitk > 1) return VMVM_ENOSUPPORT;
+    const int Cin = taps ? d->K / taps : d->K;
+    if (taps && ((d->K % taps) || (Cin % BK) || d->conv_h <= 0 || d->conv_w <= 0 || (d->M % (d->conv_h * d->conv_w)))) return VMVM_EINVAL;
+    if (d->lda < Cin || d->ldb < d->K) return VMVM_EINVAL;
+    const size_t bA = (size_t)d->M * d->lda * 2 + (taps ? (size_t)4 * (d->conv_w + 1) * Cin : 0), bB = (size_t)d->N * d->ldb * 2;
+    if (bA >= 0x7fffffffull || bB >= 0x7fffffffull) return VMVM_ENOSUPPORT;       // 32-bit buffer offsets: the caller chunks the frames
+    vmvm_gemm_desc dt = *d;
+    dt.splitk = 1;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    return taps ? launch_pers_teacher<true>(dt, st_) : launch_pers_teacher<false>(dt, st_);
+  }
   // 16-byte chunks may straddle the logical extent as long as the row stride covers the round-up
   const int K8 = (d->K + 7) & ~7, M8 = (d->M + 7) & ~7, N8 = (d->N + 7) & ~7;
   if (d->a_kmajor ? (d->lda < K8) : (d->lda < M8)) return VMVM_EINVAL;

@@ -3,9 +3,13 @@
 Reference: `DalleModel` visbackbone/dalle/__init__.py:23-58, `Encoder` encoder.py:41-93, `EncoderBlock` :12-39,
 `Conv2d` utils.py:10-43, `map_pixels` :46-52.  The teacher runs without gradient and only produces integer targets.
 
-FIRST PASS (as SURVEY 8f.1 prescribes): the 3x3 / 1x1 convolutions go through PyTorch's `conv2d` (MIOpen on ROCm) in fp16
-like the reference's GPU path -- plumbing around the hand-written student kernels, not part of libvmvm.  A hand-written
-implicit-GEMM MFMA convolution with a fused arg-max epilogue is the planned replacement (1.67 TFLOP per clip at n_hid 256)."""
+Two execution paths:
+* native (default on the GPU when every channel count is a multiple of 64, i.e. the real n_hid = 256 encoder): all 3x3
+  convolutions run as IMPLICIT GEMMs on the persistent MFMA kernel of libvmvm (`vmvm_gemm_desc.conv_taps = 9`, fp16 operands,
+  NHWC activations, zero padding through out-of-range DMA offsets) and all 1x1 convolutions as plain fp16 GEMMs with the
+  bias / ReLU / post_gain-scaled residual epilogues; only the 7x7 stem (3 input channels, 2% of the flops), the ReLU of block
+  inputs and the 2x2 max-pools stay in PyTorch.
+* torch (`F.conv2d`, CPU or reduced test encoders): the first pass SURVEY 8f.1 prescribes, kept as the reference path."""
 import math
 
 import torch
@@ -51,10 +55,50 @@ class DalleTeacher:
             else:
                 t = torch.zeros(shp)
             self.w[k] = t.to(self.device)
+        self.native = self.device.type == "cuda" and n_hid % 256 == 0 and self.dtype == torch.float16
+        self._nw = None
         self.channels_last = self.device.type == "cuda"      # NHWC convolutions: 252 -> 194 ms for 256 frames on MI355X (tools/bench_teacher.py)
         self._refresh()
 
+    def _native_weights(self):
+        """fp16 GEMM operands: 3x3 kernels as [C_out][9*C_in] with k = tap*C_in + c (tap = ky*3 + kx), 1x1 as [C_out][C_in]"""
+        if self._nw is None:
+            nw = {}
+            for k, v in self.w.items():
+                if k.endswith(".w") and not k.startswith("blocks.input"):
+                    nw[k] = v.permute(0, 2, 3, 1).reshape(v.shape[0], -1).to(torch.float16).contiguous()
+            self._nw = nw
+        return self._nw
+
+    @torch.no_grad()
+    def logits_native(self, x):
+        """x (N,3,H,W) f32 un-normalised + pixel-mapped -> logits f32 [N*(H/8)*(W/8), vocab] (NHWC row order)"""
+        from . import kernels as K
+        nw = self._native_weights()
+        post_gain = 1.0 / (4 * 2) ** 2
+        x = self._conv(x.contiguous(memory_format=torch.channels_last), "blocks.input")           # stem: PyTorch (3 input channels)
+        N, C, H, W = x.shape
+        x = x.permute(0, 2, 3, 1).contiguous().view(N * H * W, C)                                   # NHWC rows
+        for gi in range(4):
+            for bi in range(2):
+                q = f"blocks.group_{gi + 1}.block_{bi + 1}."
+                xr = torch.relu(x)
+                idp = K.gemm(x, nw[q + "id_path.w"], bias=self.w[q + "id_path.b"], fp16=True) if (q + "id_path.w") in nw else x
+                r = K.gemm(xr, nw[q + "res_path.conv_1.w"], bias=self.w[q + "res_path.conv_1.b"], act=2, fp16=True, conv=(9, H, W))
+                r = K.gemm(r, nw[q + "res_path.conv_2.w"], bias=self.w[q + "res_path.conv_2.b"], act=2, fp16=True, conv=(9, H, W))
+                r = K.gemm(r, nw[q + "res_path.conv_3.w"], bias=self.w[q + "res_path.conv_3.b"], act=2, fp16=True, conv=(9, H, W))
+                Co = nw[q + "res_path.conv_4.w"].shape[0]
+                x = K.gemm(r, nw[q + "res_path.conv_4.w"], bias=self.w[q + "res_path.conv_4.b"], col_scale=post_gain, col_scale_n=Co,
+                           resid=idp, fp16=True)                                               # id + post_gain * (conv_4 + b)
+                C = Co
+            if gi < 3:
+                x = F.max_pool2d(x.view(N, H, W, C).permute(0, 3, 1, 2), 2)                        # channels-last in and out
+                H, W = H // 2, W // 2
+                x = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+        return K.gemm(torch.relu(x), nw["blocks.output.conv.w"], bias=self.w["blocks.output.conv.b"], out_dtype=torch.float32, fp16=True)
+
     def _refresh(self):
+        self._nw = None
         self.c = {k: (v if k.startswith("blocks.output") else v.to(self.dtype)) for k, v in self.w.items()}    # last conv stays f32 (encoder.py:72)
 
     def state_dict(self, prefix="dalle.encoder."):
@@ -96,10 +140,16 @@ class DalleTeacher:
         mean = torch.tensor(IMNET_MEAN, device=img.device).view(1, 3, 1, 1)
         std = torch.tensor(IMNET_STD, device=img.device).view(1, 3, 1, 1)
         out = []
+        if self.native:
+            chunk = min(chunk * 2, 64)                                   # 32-bit DMA offsets: <= 2 GiB per activation tensor
         for a in range(0, img.shape[0], chunk):                          # bounded activation memory (224^2 x 256 ch per frame)
             x = img[a:a + chunk].float() * std + mean
             x = 0.8 * x + 0.1                                            # map_pixels, logit_laplace_eps = 0.1
-            out.append(torch.argmax(self.logits(x), dim=1))
+            if self.native:
+                n, hv, wv = x.shape[0], x.shape[2] // 8, x.shape[3] // 8
+                out.append(torch.argmax(self.logits_native(x), dim=1).view(n, hv, wv))
+            else:
+                out.append(torch.argmax(self.logits(x), dim=1))
         return torch.cat(out, 0)
 
     def get_vq_patch_size(self):

@@ -26,17 +26,17 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None):
+         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
     if K is None:
-        K = A.shape[1] if a_kmajor else A.shape[0]
+        K = B.shape[1] if conv is not None else (A.shape[1] if a_kmajor else A.shape[0])
     if N is None:
         N = B.shape[0] if b_kmajor else B.shape[1]
     if out is None:
         rows = out_rows if out_rows is not None else M
-        out = torch.empty((rows, N), device=A.device, dtype=out_dtype)
+        out = torch.empty((rows, N), device=A.device, dtype=(torch.float16 if (fp16 and out_dtype == BF16) else out_dtype))
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -60,6 +60,8 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
         workspace = _WORKSPACE.get(A.device)
     d.workspace, d.workspace_bytes = L.ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
     d.colsum = L.ptr(colsum)
+    d.in_fp16 = int(fp16)
+    d.conv_taps, d.conv_h, d.conv_w = conv if conv is not None else (0, 0, 0)
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
 

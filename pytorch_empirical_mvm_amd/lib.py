@@ -26,7 +26,8 @@ class GemmDesc(C.Structure):
                 ("out_fp32", c_int), ("accumulate", c_int),
                 ("col_scale", c_float), ("col_scale_n", c_int),
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
-                ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64), ("colsum", c_void_p)]
+                ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
+                ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p)]
 
 
 class LnFwdDesc(C.Structure):

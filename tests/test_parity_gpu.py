@@ -292,3 +292,23 @@ def test_full_size_batch_permutation_invariance():
         assert abs(l0[k] - l1[k]) <= 2e-3 * abs(l0[k]) + 1e-4, (k, l0[k], l1[k])
     assert _cos(g0, g1) >= 0.9995, _cos(g0, g1)
     assert abs(float(g0.norm()) - float(g1.norm())) <= 1e-2 * float(g0.norm())
+
+
+def test_dvae_teacher_native_convs_vs_pytorch_fp32():
+    """the full-width (n_hid 256, 8192 codes) tokenizer on the hand-written implicit-GEMM convolutions
+    (fp16, libvmvm) against the same weights through PyTorch conv2d in fp32: logits close, tokens agree."""
+    from pytorch_empirical_mvm_amd.dvae import DalleTeacher
+    dev = "cuda"
+    torch.manual_seed(0)
+    img = torch.randn(4, 3, 224, 224, device=dev)
+    t = DalleTeacher(256, 8192, device=dev)
+    assert t.native
+    ref = DalleTeacher(256, 8192, device=dev, dtype=torch.float32)
+    ref.w = t.w; ref._refresh(); ref.native = False
+    x = 0.8 * (img * torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1) + torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)) + 0.1
+    zl = t.logits_native(x).view(4, 28, 28, 8192)
+    zr = ref.logits(x).permute(0, 2, 3, 1)
+    assert _cos(zl.float(), zr.float()) >= 0.9995
+    assert float((zl - zr).abs().max()) <= 3e-2 * float(zr.abs().max())
+    tok, tokr = t.extract_vq_token(img), ref.extract_vq_token(img)
+    assert float((tok == tokr).float().mean()) >= 0.99

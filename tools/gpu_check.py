@@ -89,6 +89,30 @@ def check_gemm_colsum():
     K._WORKSPACE.clear()
 
 
+def check_gemm_fp16_conv():
+    """fp16 builds of the persistent GEMM + implicit 3x3 convolution (frozen dVAE tokenizer) against torch in fp32"""
+    H16 = torch.float16
+    def r16(*sh): return (torch.randn(*sh, device=dev) * 0.5).to(H16)
+    for (M, N, K_) in [(4096, 256, 512), (1000, 136, 192), (6272, 8192, 2048)]:
+        A, Bw, bias = r16(M, K_), r16(N, K_), torch.randn(N, device=dev)
+        ref = A.float() @ Bw.float().t() + bias
+        rep(f"gemm fp16 {M}x{N}x{K_} bias", K.gemm(A, Bw, bias=bias, fp16=True).float(), ref)
+        rep(f"gemm fp16 {M}x{N}x{K_} bias+relu", K.gemm(A, Bw, bias=bias, act=2, fp16=True).float(), torch.relu(ref))
+        res = r16(M, N)
+        rep(f"gemm fp16 {M}x{N}x{K_} (xW+b)*g+res", K.gemm(A, Bw, bias=bias, col_scale=0.25, col_scale_n=N, resid=res, fp16=True).float(), ref * 0.25 + res.float())
+        rep(f"gemm fp16 {M}x{N}x{K_} f32 out", K.gemm(A, Bw, bias=bias, out_dtype=torch.float32, fp16=True), ref, tol=2e-3)
+    for (n, Hh, Ww, Ci, Co) in [(3, 14, 10, 64, 128), (2, 28, 28, 128, 256), (5, 56, 56, 64, 64), (1, 7, 9, 256, 72)]:
+        x = r16(n, Hh, Ww, Ci)                                                        # NHWC
+        w = (torch.randn(Co, Ci, 3, 3, device=dev) / (3 * Ci ** 0.5)).to(H16)
+        bias = torch.randn(Co, device=dev) * 0.1
+        w2 = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()                   # k = tap * C_in + c
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+        y = K.gemm(x.view(-1, Ci), w2, bias=bias, fp16=True, conv=(9, Hh, Ww))
+        rep(f"conv3x3 fp16 n={n} {Hh}x{Ww} {Ci}->{Co}", y.float(), ref)
+        y = K.gemm(x.view(-1, Ci), w2, bias=bias, act=2, fp16=True, conv=(9, Hh, Ww))
+        rep(f"conv3x3 fp16 n={n} {Hh}x{Ww} {Ci}->{Co} relu", y.float(), torch.relu(ref))
+
+
 def check_gemm_big(variant=4, tag="big"):
     """256^2-tile kernel (variant 4) / 3-stage 256x128 kernel (variant 5) on every layout + epilogue paths + split-K."""
     for (M, N, K_) in [(392 * 3, 768, 128), (1000, 1024, 768), (4096, 512, 2048), (777 * 8, 256, 64)]:
@@ -611,8 +635,8 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
-    table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
+    table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
                  attnw=check_attn_window, attnb=check_attn_bert, misc=check_misc)
     for w in which:
         if w == "bench":
