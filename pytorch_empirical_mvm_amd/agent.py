@@ -126,6 +126,7 @@ class Agent_Pretrain:
                 b[k] = batch[k].to(eng.device).contiguous()
         if is_train:
             hook = self.comm.reduce_other if self.comm is not None else None
+            eng.on_swin_tail_ready = self.comm.reduce_swin_tail if self.comm is not None else None
             losses, _ = eng.forward_backward(b, negatives=negatives, train=True, dp_all=dp_all, on_other_grads_ready=hook)
             self.backward_step()
             self.global_step += 1

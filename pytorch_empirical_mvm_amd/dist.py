@@ -77,6 +77,7 @@ class GradReducer:
         self.cuda = torch.device(device).type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
         self.pending = False
+        self.tail_done = False
 
     def _run(self, segs):
         g = self.store.grad
@@ -97,10 +98,34 @@ class GradReducer:
         else:
             self._run((1, 3))
 
+    def reduce_swin_tail(self):
+        """called by the engine when the backward leaves Swin stage n-2: stages >= n-2 (+ final norm) are final; their sum
+        runs on the side stream under the two early, memory-bound stages"""
+        if not is_initialized() or not self.store.swin_tail:
+            return
+        g = self.store.grad
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for a, e in self.store.swin_tail:
+                    all_reduce_chunks_(g, a, e)
+            self.pending = True
+        else:
+            for a, e in self.store.swin_tail:
+                all_reduce_chunks_(g, a, e)
+        self.tail_done = True
+
     def reduce_swin_and_wait(self):
         if not is_initialized():
             return
-        self._run((0, 2))
+        g = self.store.grad
+        tails = {a: e for a, e in self.store.swin_tail} if getattr(self, "tail_done", False) else {}
+        for gi in (0, 2):
+            a, e = self.store.segments[gi]
+            split = next((s for s, ee in tails.items() if ee == e and a <= s), e)      # tail of this segment already reduced?
+            if split > a:
+                all_reduce_chunks_(g, a, split)
+        self.tail_done = False
         if self.cuda and self.pending:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.pending = False

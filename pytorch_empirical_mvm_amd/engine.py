@@ -59,6 +59,32 @@ class ParamStore:
         self.shadow = torch.zeros(off + self.TAIL, device=device, dtype=BF16)
         self.shadowT = torch.zeros(off + self.TAIL, device=device, dtype=BF16) if torch.device(device).type == "cuda" else None
         self.tmap, self.ttable = {}, None
+        self.swin_tail = self._swin_tail_ranges()
+
+    def _swin_tail_ranges(self):
+        """[(a, e)] inside the two Swin segments covering the parameters of the LAST TWO stages + the final norm: their
+        gradients are final once the backward has left stage n-2 (93% of Swin-B's parameters, with the two memory-bound early
+        stages and the patch embedding still to run), so their all-reduce can start there.  Empty when the arena order does
+        not keep them contiguous at the end of a segment."""
+        stages = sorted({int(n.split(".")[3]) for n in self.index if n.startswith("enc_img.swin.layers.")})
+        if len(stages) < 3:
+            return []
+        lo = stages[-2]
+        def is_tail(n):
+            if n.startswith("enc_img.swin.norm."):
+                return True
+            return n.startswith("enc_img.swin.layers.") and int(n.split(".")[3]) >= lo
+        out = []
+        for gi in (0, 2):
+            a, e = self.segments[gi]
+            names = [n for n, (o, c, _) in self.index.items() if a <= o < e]
+            tail = [n for n in names if is_tail(n)]
+            if not tail:
+                continue
+            split = min(self.index[n][0] for n in tail)
+            if all(is_tail(n) for n in names if self.index[n][0] >= split):
+                out.append((split, e))
+        return out
 
     def _view(self, buf, n, shape=None):
         o, c, s = self.index[n]
@@ -163,6 +189,7 @@ class VioletEngine:
         self._idx_cache = {}
         self.tape = []
         self.teacher = None                 # frozen dVAE tokenizer (MVM 'vq' target), set by the model
+        self.on_swin_tail_ready = None      # data-parallel hook (dist.GradReducer.reduce_swin_tail)
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
@@ -303,7 +330,11 @@ class VioletEngine:
         dims = (T, H // 4, W // 4)
         C = cfg["embed_dim"]
         blk = 0
+        n_st = len(cfg["depths"])
         for i, (d, nh) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+            if i == n_st - 2 and n_st >= 3:
+                # runs in the backward right after stage n-2's last block: the gradients of stages >= n-2 are final
+                self.tape.append(lambda: self.on_swin_tail_ready() if self.on_swin_tail_ready is not None else None)
             for b in range(d):
                 dp = None if dp_all is None else dp_all[blk]
                 xv = self._swin_block(xv, B, dims, C, nh, f"enc_img.swin.layers.{i}.blocks.{b}.", b % 2 == 1, dp)

@@ -35,7 +35,21 @@ def _worker(rank, world, port, q):
     red = D.GradReducer(S, "cpu")
     red.reduce_other()
     mid = S.grad[:S.total].clone()
+    # phase 2a: the Swin tail (stages >= n-2 + final norm) as soon as its gradients are final, 2b: the rest
+    assert S.swin_tail and all(S.segments[gi][0] < a < e == S.segments[gi][1] for gi, (a, e) in zip((0, 2), S.swin_tail)), S.swin_tail
+    red.reduce_swin_tail()
+    mid2 = S.grad[:S.total].clone()
     red.reduce_swin_and_wait()
+    for (a, e), gi in zip(S.swin_tail, (0, 2)):
+        tot_ = sum(torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world))
+        assert torch.allclose(mid2[a:e], tot_[a:e], atol=1e-5) and torch.equal(mid2[S.segments[gi][0]:a], mine[S.segments[gi][0]:a])
+    # a second round WITHOUT the tail hook must still reduce everything exactly once
+    S.grad[:S.total].copy_(mine)
+    red.reduce_other(); red.reduce_swin_and_wait()
+    again = S.grad[:S.total].clone()
+    S.grad[:S.total].copy_(mine)
+    red.reduce_other(); red.reduce_swin_tail(); red.reduce_swin_and_wait()
+    assert torch.allclose(again[:S.n_trainable], S.grad[:S.n_trainable], atol=1e-5)
     # expected: sum over ranks in trainable segments
     others = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
     tot = sum(others)
