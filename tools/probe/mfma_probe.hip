@@ -47,7 +47,41 @@ void run(const char* name, int wgs_per_cu) {
   printf("%-28s waves/SIMD=%d  %.3f ms  %.1f TFLOP/s  counter cycles per (MFMA + %d VALU) = %.1f\n", name, wgs_per_cu, ms, mfma * 16384.0 / ms / 1e9, NV, cyc);
   hipFree(d);
 }
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int NACC>
+__global__ __launch_bounds__(256) void probe32(float* out, int iters) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  bf16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(threadIdx.x * 0.001f + e); b[e] = (__bf16)(0.5f + e); }
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(t1 - t0) / (float)(iters * NACC);
+}
+void run32(int wgs_per_cu) {
+  float* d; hipMalloc(&d, 256 * 1024 * sizeof(float));
+  const int iters = 2000; constexpr int NACC = 8;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((probe32<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((probe32<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  float cyc; hipMemcpy(&cyc, d, 4, hipMemcpyDeviceToHost);
+  const double mfma = (double)256 * wgs_per_cu * 4 * iters * NACC;
+  printf("%-28s waves/SIMD=%d  %.3f ms  %.1f TFLOP/s  counter cycles per MFMA = %.1f\n", "mfma 32x32x16 only", wgs_per_cu, ms, mfma * 32768.0 / ms / 1e9, cyc);
+  hipFree(d);
+}
 int main() {
+  run32(1); run32(2);
   for (int w = 1; w <= 2; ++w) {
     run<0, 16>("mfma only", w);
     run<1, 16>("mfma + 1 valu", w);
