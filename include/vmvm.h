@@ -124,7 +124,7 @@ typedef struct {
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused attention over short sequences (whole K/V of one (sequence, head) resident in LDS).
+ * Fused attention (whole K/V of one (sequence, head) resident in LDS up to 448 tokens, streamed in chunks above).
  *   mode 0: Video-Swin window attention  (WindowAttention3D.forward video_swin.py:147-172):
  *           S = q k^T (q pre-scaled by the qkv GEMM epilogue) + table[rc[i]-rc[j]+rc0][h]
  *               + (region[w][i] != region[w][j] ? -100 : 0) ; softmax ; P v.   head_dim 32.
@@ -148,6 +148,10 @@ typedef struct {
   float dropout_p; uint64_t seed, offset;
   /* DropPath 'producer' form: out rows of sequence s are multiplied by seq_scale[s / seqs_per_scale] (or NULL) */
   const float* seq_scale; int32_t seqs_per_scale;
+  /* Sequences longer than 448 tokens (Swin-L-384 windows: 1152; 16-frame 384^2 fusion sequences: 2352) run the streaming
+   * kernels: K/V pass through LDS in 128-token chunks with an online softmax, same masks / bias / dropout stream as the
+   * resident kernels.  stream_min_len > 0 lowers that threshold (L >= stream_min_len streams; parity tests); 0 = default. */
+  int32_t stream_min_len;
 } vmvm_attn_fwd_desc;
 int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
 

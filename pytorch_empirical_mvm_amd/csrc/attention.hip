@@ -1493,6 +1493,480 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
   }
 }
 
+// ================================================================================================
+// streaming variants (any L; used above 448 tokens: Swin-L-384 windows of 8x12x12 = 1152 tokens and the 2352-token fusion
+// sequences of 16 x 384^2 clips).  Same lane layout and math as the kernels above, but K / V (forward, dQ) or Q / dO (dK/dV) pass
+// through LDS in chunks of KC tokens and the softmax is the online (running max / running sum) form.  A workgroup owns NW query
+// tiles (forward, dQ) or NW*KT key tiles (dK/dV) of one (sequence, head); blocks of the same (sequence, head) are adjacent in the
+// XCD remap so the chunks they re-read stay in that XCD's L2.
+// ================================================================================================
+struct SmemS { int lpk, off_b, off_rc, off_reg, off_tab, off_dtab, off_lse, off_delta, total; };
+// which: 0 fwd, 1 dq (+dtab), 2 dkv (+lse/delta chunk)
+__host__ __device__ inline SmemS smem_stream(int L, int hd, int mode, int table_len, int which, int KC) {
+  SmemS s;
+  s.lpk = (L + KC - 1) / KC * KC;
+  int o = KC * hd * 2;
+  s.off_b = o; o += KC * hd * 2;
+  s.off_rc = o; if (mode == 0) o += s.lpk * 4;
+  s.off_reg = o; o += s.lpk;
+  s.off_tab = o; if (mode == 0) o += ((table_len + 3) & ~3) * 4;
+  s.off_dtab = o; if (mode == 0 && which == 1) o += ((table_len + 3) & ~3) * 4;
+  s.off_lse = o; if (which == 2) o += KC * 4;
+  s.off_delta = o; if (which == 2) o += KC * 4;
+  s.total = (o + 15) & ~15;
+  return s;
+}
+
+template <int HD, int MODE, int NW, int KC>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_attn_fwd_desc p, const int nqb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTC = KC / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads;
+  const SmemS sm = smem_stream(L, HD, MODE, p.table_len, 0, KC);
+  const int logical = xcd_remap(blockIdx.x, p.nseq * heads * nqb);
+  const int sh = logical / nqb, qb = logical - sh * nqb;
+  const int seq = sh / heads, h = sh - seq * heads;
+  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+  unsigned char* Ksm = smem;
+  unsigned char* Vsm = smem + sm.off_b;
+  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
+  unsigned char* reg = smem + sm.off_reg;
+  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  if (MODE == 0) {
+    for (int i = tid; i < sm.lpk; i += NW * 64) {
+      rc[i] = i < L ? p.rc[i] : 0;
+      reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
+    }
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+  } else {
+    for (int i = tid; i < sm.lpk; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
+  }
+  const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
+  const uint32_t thr8 = drop_thr8(p.dropout_p);
+  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+
+  const int qt = qb * NW + wave;
+  const int q = qt * 16 + r;
+  const bool qv = q < L;
+  const u16* qp = qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8;
+  bf16x8 qf[HD / 32];
+#pragma unroll
+  for (int s = 0; s < HD / 32; ++s) qf[s] = load_frag_global(qp + s * 32, qv);
+  f32x4 o[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, lsum = 0.f;                // running max (finite start: exp(-inf - m) = 0, never inf - inf) and this lane's share of the sum
+
+  for (int k0 = 0; k0 < L; k0 += KC) {
+    __syncthreads();                             // every wave is done with the previous chunk (and, first time, the tables are staged)
+    fill_rowmajor<HD>(Ksm, qkv + (size_t)k0 * p.ld_qkv + p.k_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+    fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+    fill_wait();
+    __syncthreads();
+    const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
+    const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
+    f32x4 acc[NTC];
+    float cmx = NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = t * 16 + r;
+#pragma unroll
+      for (int s = 0; s < HD / 32; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc[t], 0, 0, 0);
+      }
+      const int key0 = k0 + t * 16 + g * 4;
+      if (MODE == 0) {
+        const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
+        const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0);
+        const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
+        const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s = acc[t][j] + tab[rcq - rks[j] + p.rc0] + (regq != gks[j] ? -100.f : 0.f);
+          s = (key0 + j < L) ? s : NEG_INF;
+          acc[t][j] = s; cmx = fmaxf(cmx, s);
+        }
+      } else {
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
+        const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float s = mks[j] ? acc[t][j] * p.scale : NEG_INF;
+          acc[t][j] = s; cmx = fmaxf(cmx, s);
+        }
+      }
+    }
+    cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
+    cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+    const float mnew = fmaxf(m, cmx);
+    const float alpha = __expf(m - mnew);
+    m = mnew;
+    float csum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float e = __expf(acc[t][j] - mnew); acc[t][j] = e; csum += e; }
+    }
+    lsum = lsum * alpha + csum;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) o[dt] *= alpha;
+    if (has_drop) {
+      uint4 own = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        if ((t & 3) == 0)                           // quad lane i: block of (absolute) tile t+i; chunks are whole groups of four tiles
+          own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g));
+        const uint4 blk = quad_bcast_i(own, t & 3);
+        const uint32_t w = u4_get(blk, q & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NTC / 2; ++c) {
+      float a[4] = {acc[2 * c][0], acc[2 * c][1], acc[2 * c][2], acc[2 * c][3]};
+      float b[4] = {acc[2 * c + 1][0], acc[2 * c + 1][1], acc[2 * c + 1][2], acc[2 * c + 1][3]};
+      const bf16x8 pf = frag_from_f32(a, b);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const bf16x8 vf = frag_tokens<HD>(Vsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  float sum = lsum;
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = m + __logf(sum);
+  if (qv) {
+    const float inv = seq_scale / sum;
+    u16* op = reinterpret_cast<u16*>(p.out) + ((size_t)seq * L + q) * p.ld_out + h * HD + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt)
+      *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+  }
+}
+
+// dQ (+ delta, + bias-table gradient): workgroup (sequence chunk, head, query block) walks its sequences so the LDS copy of the
+// table gradient is flushed once per workgroup; K / V stream through LDS in KC-token chunks.
+template <int HD, int MODE, int NW, int KC>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads;
+  const SmemS sm = smem_stream(L, HD, MODE, p.table_len, 1, KC);
+  const int logical = xcd_remap(blockIdx.x, nchunks * heads * nqb);
+  const int ch = logical / nqb, qb = logical - ch * nqb;
+  const int chunk = ch / heads, h = ch - chunk * heads;
+  unsigned char* Ksm = smem;
+  unsigned char* Vsm = smem + sm.off_b;
+  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
+  unsigned char* reg = smem + sm.off_reg;
+  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  float* dtab = reinterpret_cast<float*>(smem + sm.off_dtab);
+  const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
+  const bool want_dtab = pb.dbias_table != nullptr;
+  const uint32_t thr8 = drop_thr8(p.dropout_p);
+  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  if (MODE == 0) {
+    for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
+    for (int i = tid; i < p.table_len; i += NW * 64) { tab[i] = p.bias_table[(size_t)i * heads + h]; dtab[i] = 0.f; }
+  }
+  const int qt = qb * NW + wave;
+  const int q = qt * 16 + r;
+  const bool qv = q < L;
+
+  for (int seq = chunk; seq < p.nseq; seq += nchunks) {
+    const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+    const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
+    const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * L * p.ld_out + h * HD;
+    __syncthreads();                                // previous sequence's last chunk is consumed before its mask image changes
+    if (MODE == 0) {
+      for (int i = tid; i < sm.lpk; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
+    } else {
+      for (int i = tid; i < sm.lpk; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
+    }
+    const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+    bf16x8 qf[HD / 32], dof[HD / 32];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < HD / 32; ++s) {
+      qf[s] = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8 + s * 32, qv);
+      dof[s] = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8 + s * 32, qv);
+      const bf16x8 of = load_frag_global(O + (size_t)q * p.ld_out + g * 8 + s * 32, qv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[s][e] * (float)of[e];
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0 && qv) pb.delta[((size_t)seq * heads + h) * L + q] = dl;
+    const float lse = qv ? p.lse[((size_t)seq * heads + h) * L + q] : 0.f;
+    f32x4 dq[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < L; k0 += KC) {
+      __syncthreads();
+      fill_rowmajor<HD>(Ksm, qkv + (size_t)k0 * p.ld_qkv + p.k_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+      fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+      fill_wait();
+      __syncthreads();
+      const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
+      const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
+      uint4 own = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < KC / 32; ++c) {
+        float ds[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * c + u;
+          const int row = t * 16 + r;
+          f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < HD / 32; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], s4, 0, 0, 0);
+            const bf16x8 vf = frag_hd<HD>(Vsm, row, s * 4 + g);
+            dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dp4, 0, 0, 0);
+          }
+          const int key0 = k0 + t * 16 + g * 4;
+          uint32_t w = 0;
+          if (has_drop) {
+            if ((t & 3) == 0) own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g));
+            const uint4 blk = (c & 1) ? (u ? quad_bcast<3>(own) : quad_bcast<2>(own)) : (u ? quad_bcast<1>(own) : quad_bcast<0>(own));
+            w = u4_get(blk, q & 3);
+          }
+          if (MODE == 0) {
+            const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
+            const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0);
+            const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
+            const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int bi = rcq - rks[j] + p.rc0;
+              const float s = s4[j] + tab[bi] + (regq != gks[j] ? -100.f : 0.f);
+              const float pr = (key0 + j < L && qv) ? __expf(s - lse) : 0.f;
+              const float d = pr * (dp4[j] * seq_scale - dl);
+              ds[u][j] = d;
+              if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], d);
+            }
+          } else {
+            const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
+            const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float pr = (mks[j] && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
+              float dpj = dp4[j] * seq_scale;
+              if (has_drop) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
+              ds[u][j] = pr * (dpj - dl);
+            }
+          }
+        }
+        const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          const bf16x8 kf = frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qv) {
+      u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + q) * pb.ld_dqkv + p.q_off + h * HD + g * 4;
+      const float sc = p.scale;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt)
+        *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
+    }
+  }
+  if (MODE == 0 && want_dtab) {
+    __syncthreads();
+    for (int i = tid; i < p.table_len; i += NW * 64) {
+      const float v = dtab[i];
+      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+    }
+  }
+}
+
+// dK / dV: workgroup = (sequence, head, block of NW*KT key tiles); Q / dO (+ lse, delta) stream through LDS in KC-query chunks.
+template <int HD, int MODE, int NW, int KC>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm_attn_bwd_desc pb, const int nkb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads;
+  const SmemS sm = smem_stream(L, HD, MODE, p.table_len, 2, KC);
+  const int logical = xcd_remap(blockIdx.x, p.nseq * heads * nkb);
+  const int sh = logical / nkb, kb = logical - sh * nkb;
+  const int seq = sh / heads, h = sh - seq * heads;
+  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+  const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
+  unsigned char* Qsm = smem;
+  unsigned char* dOsm = smem + sm.off_b;
+  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
+  unsigned char* reg = smem + sm.off_reg;
+  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  float* lse_s = reinterpret_cast<float*>(smem + sm.off_lse);
+  float* delta_s = reinterpret_cast<float*>(smem + sm.off_delta);
+  const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
+  const float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
+  for (int i = tid; i < sm.lpk; i += NW * 64) {
+    if (MODE == 0) {
+      rc[i] = i < L ? p.rc[i] : 0;
+      reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
+    } else {
+      reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
+    }
+  }
+  if (MODE == 0)
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+  __syncthreads();
+
+  const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
+  const uint32_t thr8 = drop_thr8(p.dropout_p);
+  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const int nt = (L + 15) / 16;
+
+  constexpr int KT = (HD == 32) ? 2 : 1;
+  int key[KT]; bool kv[KT];
+  bf16x8 kf[KT][HD / 32], vf[KT][HD / 32];
+  int rck[KT], regk[KT];
+  f32x4 dk[KT][HD / 16], dv[KT][HD / 16];
+  uint4 own[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    key[t] = ((kb * NW + wave) * KT + t) * 16 + r;
+    kv[t] = key[t] < L;
+#pragma unroll
+    for (int s = 0; s < HD / 32; ++s) {
+      kf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.k_off + h * HD + g * 8 + s * 32, kv[t]);
+      vf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.v_off + h * HD + g * 8 + s * 32, kv[t]);
+    }
+    rck[t] = (MODE == 0) ? rc[kv[t] ? key[t] : 0] : 0;
+    regk[t] = reg[kv[t] ? key[t] : 0];
+    own[t] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  for (int q0c = 0; q0c < L; q0c += KC) {
+    __syncthreads();
+    fill_rowmajor<HD>(Qsm, qkv + (size_t)q0c * p.ld_qkv + p.q_off + h * HD, p.ld_qkv, L - q0c, KC, tid, NW * 64);
+    fill_rowmajor<HD>(dOsm, dO + (size_t)q0c * pb.ld_dout, pb.ld_dout, L - q0c, KC, tid, NW * 64);
+    for (int i = tid; i < KC; i += NW * 64) {
+      lse_s[i] = (q0c + i < L) ? lse_g[q0c + i] : __builtin_huge_valf();     // +inf -> p = 0 for padded queries
+      delta_s[i] = (q0c + i < L) ? delta_g[q0c + i] : 0.f;
+    }
+    fill_wait();
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC / 32; ++c) {
+      float pt[KT][2][4], ds[KT][2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ql = 2 * c + u;                    // query tile inside the chunk
+        const int qt = q0c / 16 + ql;                // absolute query tile
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pt[t][u][j] = 0.f; ds[t][u][j] = 0.f; }
+        if (qt < nt) {
+          const int qrow = ql * 16 + r;
+          f32x4 s4[KT], dp4[KT];
+#pragma unroll
+          for (int t = 0; t < KT; ++t) { s4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int s = 0; s < HD / 32; ++s) {
+            const bf16x8 qf = frag_hd<HD>(Qsm, qrow, s * 4 + g);
+            const bf16x8 dof = frag_hd<HD>(dOsm, qrow, s * 4 + g);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              s4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[t][s], s4[t], 0, 0, 0);
+              dp4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[t][s], dp4[t], 0, 0, 0);
+            }
+          }
+          const int ql0 = ql * 16 + g * 4, q0 = q0c + ql0;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql0);
+          const float4 d4 = *reinterpret_cast<const float4*>(delta_s + ql0);
+          const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+          const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+          if (MODE == 0) {
+            const int4 rq = *reinterpret_cast<const int4*>(rc + q0);
+            const uchar4 gq = *reinterpret_cast<const uchar4*>(reg + q0);
+            const int rqs[4] = {rq.x, rq.y, rq.z, rq.w};
+            const int gqs[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float sv = s4[t][j] + tab[rqs[j] - rck[t] + p.rc0] + (gqs[j] != regk[t] ? -100.f : 0.f);
+                const float pr = kv[t] ? __expf(sv - ls[j]) : 0.f;
+                pt[t][u][j] = pr;
+                ds[t][u][j] = pr * (dp4[t][j] * seq_scale - dls[j]);
+              }
+          } else {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              uint4 blk = make_uint4(0, 0, 0, 0);
+              if (has_drop) {                               // quad lane i evaluates the block of query tile (qt & ~3) + i
+                if ((qt & 3) == 0) own[t] = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)((qt + (lane & 3)) * 4 + g), (uint32_t)(key[t] >> 2));
+                blk = (c & 1) ? (u ? quad_bcast<3>(own[t]) : quad_bcast<2>(own[t])) : (u ? quad_bcast<1>(own[t]) : quad_bcast<0>(own[t]));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float pr = (kv[t] && regk[t]) ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
+                float dpj = dp4[t][j] * seq_scale, pj = pr;
+                if (has_drop) {
+                  const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                  dpj = dropped ? 0.f : dpj * keep;
+                  pj = dropped ? 0.f : pr * keep;
+                }
+                pt[t][u][j] = pj;
+                ds[t][u][j] = pr * (dpj - dls[j]);
+              }
+            }
+          }
+        }
+      }
+      bf16x8 pf[KT], dsf[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) { pf[t] = frag_from_f32(pt[t][0], pt[t][1]); dsf[t] = frag_from_f32(ds[t][0], ds[t][1]); }
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const bf16x8 dof = frag_tokens<HD>(dOsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
+        const bf16x8 qf = frag_tokens<HD>(Qsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[t], dv[t][dt], 0, 0, 0);
+          dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[t], dk[t][dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (kv[t]) {
+      u16* base = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + key[t]) * pb.ld_dqkv + h * HD + g * 4;
+      const float ksc = (MODE == 1) ? p.scale : 1.0f;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
+            make_uint2(pack_bf2(dk[t][dt][0] * ksc, dk[t][dt][1] * ksc), pack_bf2(dk[t][dt][2] * ksc, dk[t][dt][3] * ksc));
+        *reinterpret_cast<uint2*>(base + p.v_off + dt * 16) =
+            make_uint2(pack_bf2(dv[t][dt][0] * seq_scale, dv[t][dt][1] * seq_scale), pack_bf2(dv[t][dt][2] * seq_scale, dv[t][dt][3] * seq_scale));
+      }
+    }
+  }
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes > 160 * 1024) return VMVM_ENOSUPPORT;
@@ -1510,11 +1984,13 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
   if (d->mode == 1 && d->head_dim != 64) return VMVM_EINVAL;
   if (d->mode != 0 && d->mode != 1) return VMVM_EINVAL;
   if ((d->ld_qkv & 7) || (d->ld_out & 7) || (d->q_off & 7) || (d->k_off & 7) || (d->v_off & 7)) return VMVM_EINVAL;
-  if (d->L > 448) return VMVM_ENOSUPPORT;          // full-row-in-registers design (C5 needs the streaming variant)
+  if (d->L > 16384) return VMVM_ENOSUPPORT;        // dropout block ids carry key/4 in 12 bits; above 448 tokens the streaming kernels run
   if (d->region && d->n_win <= 0) return VMVM_EINVAL;
   if (d->seq_scale && d->seqs_per_scale <= 0) return VMVM_EINVAL;
   return VMVM_OK;
 }
+
+inline bool use_stream(const vmvm_attn_fwd_desc* d) { return d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len); }
 
 }  // namespace
 
@@ -1529,6 +2005,21 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (use_stream(d)) {                               // streaming kernels: K / V chunks of 128 tokens, 8 query tiles per workgroup
+    constexpr int NWS = 8, KCS = 128;
+    const SmemS ss = smem_stream(d->L, d->head_dim, d->mode, d->table_len, 0, KCS);
+    const int nqb = ((d->L + 15) / 16 + NWS - 1) / NWS;
+    const int grid = d->nseq * d->heads * nqb;
+#define LAUNCH_FWD_S(HD, MODE)                                                                                       \
+    do {                                                                                                             \
+      int rc_ = set_smem(attn_fwd_stream_kernel<HD, MODE, NWS, KCS>, ss.total);                                       \
+      if (rc_) return rc_;                                                                                           \
+      hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, MODE, NWS, KCS>), dim3(grid), dim3(NWS * 64), ss.total, st, *d, nqb); \
+    } while (0)
+    if (d->mode == 0) LAUNCH_FWD_S(32, 0); else LAUNCH_FWD_S(64, 1);
+    VMVM_CHECK_LAUNCH();
+    return VMVM_OK;
+  }
   const Smem sm = smem_layout(d->L, d->head_dim, d->mode, d->table_len, 0);
   const int nb = d->nseq * d->heads;
   const bool mask = d->region != nullptr;
@@ -1593,6 +2084,31 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   if (rc) return rc;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (use_stream(&d->f)) {                           // streaming kernels (see vmvm_attention_fwd)
+    constexpr int NWS = 8, KCS = 128;
+    const int nt_ = (d->f.L + 15) / 16;
+    const SmemS sa = smem_stream(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 1, KCS);
+    const SmemS sb = smem_stream(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 2, KCS);
+    const int nqb = (nt_ + NWS - 1) / NWS;
+    int nchs = 1024 / (d->f.heads * nqb);             // ~4 workgroups per CU; more sequences per workgroup = fewer table-gradient flushes
+    if (nchs < 1) nchs = 1;
+    if (nchs > d->f.nseq || d->f.mode == 1) nchs = d->f.nseq;
+    const int kt_ = d->f.mode == 0 ? 2 : 1;
+    const int nkb = (nt_ + NWS * kt_ - 1) / (NWS * kt_);
+#define LAUNCH_BWD_S(HD, MODE)                                                                                       \
+    do {                                                                                                             \
+      int rc_ = set_smem(attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS>, sa.total);                                    \
+      if (rc_) return rc_;                                                                                           \
+      hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS>), dim3(nchs * d->f.heads * nqb), dim3(NWS * 64), sa.total, st, *d, nchs, nqb); \
+      VMVM_CHECK_LAUNCH();                                                                                           \
+      rc_ = set_smem(attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS>, sb.total);                                       \
+      if (rc_) return rc_;                                                                                           \
+      hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS>), dim3(d->f.nseq * d->f.heads * nkb), dim3(NWS * 64), sb.total, st, *d, nkb); \
+      VMVM_CHECK_LAUNCH();                                                                                           \
+    } while (0)
+    if (d->f.mode == 0) LAUNCH_BWD_S(32, 0); else LAUNCH_BWD_S(64, 1);
+    return VMVM_OK;
+  }
   const int nb = d->f.nseq * d->f.heads;
   // dq: persistent workgroups, ~3 per CU (mode 0) so the per-workgroup bias-table flush is amortised over many windows
   int nchunks = d->f.nseq;

@@ -400,6 +400,115 @@ def check_attn_bert():
     rep("bert attn dropout bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
 
 
+def check_attn_stream():
+    """Streaming attention kernels (L > 448, SURVEY C5 shapes): Swin-L-384 windows (8,12,12) = 1152 tokens with the 15x23x23 bias
+    table and shift mask; fusion sequences of 16 x 384^2 clips (2352 tokens) and a ragged 600; and -- the dropout stream being a
+    function of the absolute (query, key) position only -- the streaming kernels forced at the step's own shapes (432 / 392
+    tokens) against the resident kernels with the same seed."""
+    win = (8, 12, 12)
+    for (dims, B, heads) in [((16, 24, 12), 1, 2), ((16, 12, 12), 2, 1)]:
+        D, H, W = dims
+        for shifted in (False, True):
+            ws, ss = SI.get_window_size(dims, win, (4, 6, 6) if shifted else (0, 0, 0))
+            m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+            N = ws[0] * ws[1] * ws[2]
+            nW = m.size // N
+            reg = SI.region_ids(Dp, Hp, Wp, ws, ss)
+            rc, rc0 = SI.rc_codes(N, win)
+            C_ = heads * 32
+            nseq = B * nW
+            qkv = rnd(nseq * N, 3 * C_, scale=1.0)
+            table = (torch.randn(15 * 23 * 23, heads, device=dev) * 0.5)
+            rc_t = torch.from_numpy(rc).to(dev)
+            reg_t = torch.from_numpy(reg).to(dev) if reg is not None else None
+            sscale = (torch.rand(B, device=dev) + 0.5)
+            kw = dict(q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW)
+            out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, **kw)
+            qf = qkv.float().requires_grad_(True)
+            tf = table.clone().requires_grad_(True)
+            x = qf.view(nseq, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+            idx = (rc_t[:, None] - rc_t[None, :] + rc0).long()
+            bias = tf[idx.reshape(-1)].view(N, N, heads).permute(2, 0, 1)[None]
+            if reg is not None:
+                mk = torch.where(reg_t[:, :, None] != reg_t[:, None, :], -100.0, 0.0)
+                bias = bias + mk.repeat(B, 1, 1)[:, None]
+            o = attn_ref(x[0], x[1], x[2], bias)
+            sc = sscale.repeat_interleave(nW)[:, None, None, None]
+            ref = (o * sc).transpose(1, 2).reshape(nseq * N, C_)
+            tag = f"stream win attn {dims} N={N} shifted={shifted}"
+            rep(tag + " fwd", out, ref)
+            dout = rnd(nseq * N, C_)
+            ref.backward(dout.float())
+            dtab = torch.zeros_like(table)
+            dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=dtab, **kw)
+            gq = qf.grad.clone()
+            gq[:, :C_] *= 32 ** -0.5
+            rep(tag + " bwd dq", dqkv[:, :C_], gq[:, :C_])
+            rep(tag + " bwd dk", dqkv[:, C_:2 * C_], gq[:, C_:2 * C_])
+            rep(tag + " bwd dv", dqkv[:, 2 * C_:], gq[:, 2 * C_:])
+            rep(tag + " bwd dtable", dtab, tf.grad)
+    for (nseq, Lq, heads) in [(2, 2352, 2), (3, 600, 3)]:
+        Hd = heads * 64
+        qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+        km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+        for s in range(nseq):
+            km[s, Lq - 5 * (s + 1):] = 0
+        out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km)
+        qf = qkv.float().requires_grad_(True)
+        x = qf.view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        bias = torch.where(km.bool(), 0.0, float("-inf"))[:, None, None, :]
+        o = attn_ref(x[0] * 0.125, x[1], x[2], bias)
+        ref = o.transpose(1, 2).reshape(nseq * Lq, Hd)
+        tag = f"stream bert attn nseq={nseq} L={Lq} h={heads}"
+        rep(tag + " fwd", out, ref)
+        lse_ref = torch.logsumexp((x[0] * 0.125) @ x[1].transpose(-1, -2) + bias, -1)
+        rep(tag + " lse", lse, lse_ref.detach(), tol=2e-3)
+        dout = rnd(nseq * Lq, Hd)
+        ref.backward(dout.float())
+        dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km)
+        rep(tag + " bwd dq", dqkv[:, :Hd], qf.grad[:, :Hd])
+        rep(tag + " bwd dk", dqkv[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
+        rep(tag + " bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+    # forced streaming at the resident kernels' shapes: same dropout stream, same masks -> same results up to bf16 rounding
+    nseq, Lq, heads = 3, 432, 4
+    Hd = heads * 64
+    qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+    km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+    km[1, 410:] = 0
+    dout = rnd(nseq * Lq, Hd)
+    kw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=77, offset=12345)
+    o0, l0 = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, **kw)
+    o1, l1 = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, stream_min_len=1, **kw)
+    rep("stream vs resident bert+dropout fwd", o1, o0, tol=1e-2)
+    rep("stream vs resident bert+dropout lse", l1, l0, tol=1e-4)
+    g0 = K.attention_bwd(dout, qkv, o0, l0, nseq, Lq, heads, 64, 1, 0.125, **kw)
+    g1 = K.attention_bwd(dout, qkv, o0, l0, nseq, Lq, heads, 64, 1, 0.125, stream_min_len=1, **kw)
+    rep("stream vs resident bert+dropout bwd", g1, g0, tol=1e-2)
+    dims, win7, B, heads = (8, 14, 14), (8, 7, 7), 2, 4
+    ws, ss = SI.get_window_size(dims, win7, (4, 3, 3))
+    m, (Dp, Hp, Wp) = SI.window_map(*dims, ws, ss)
+    N = ws[0] * ws[1] * ws[2]
+    nW = m.size // N
+    reg_t = torch.from_numpy(SI.region_ids(Dp, Hp, Wp, ws, ss)).to(dev)
+    rc, rc0 = SI.rc_codes(N, win7)
+    rc_t = torch.from_numpy(rc).to(dev)
+    C_ = heads * 32
+    nseq = B * nW
+    qkv = rnd(nseq * N, 3 * C_, scale=1.0)
+    table = (torch.randn(15 * 13 * 13, heads, device=dev) * 0.5)
+    dout = rnd(nseq * N, C_)
+    kw = dict(q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg_t, n_win=nW)
+    o0, l0 = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, **kw)
+    o1, l1 = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, stream_min_len=1, **kw)
+    rep("stream vs resident window fwd", o1, o0, tol=1e-2)
+    rep("stream vs resident window lse", l1, l0, tol=1e-3)      # the resident window kernels carry bias+mask as packed bf16
+    t0, t1 = torch.zeros_like(table), torch.zeros_like(table)
+    g0 = K.attention_bwd(dout, qkv, o0, l0, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=t0, **kw)
+    g1 = K.attention_bwd(dout, qkv, o0, l0, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=t1, stream_min_len=1, **kw)
+    rep("stream vs resident window bwd", g1, g0, tol=1e-2)
+    rep("stream vs resident window dtable", t1, t0, tol=1e-2)
+
+
 # ------------------------------------------------------------------ misc
 def check_misc():
     B, T, H, W = 2, 4, 64, 96
@@ -635,9 +744,9 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "misc", "bench"]
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, misc=check_misc)
+                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, misc=check_misc)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
