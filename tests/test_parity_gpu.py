@@ -262,6 +262,52 @@ def test_full_size_c2_forward_losses_vs_oracle():
     assert _cos(outs["out_mtm"].float().cpu(), ref["out"]["out_mtm"]) >= 0.999
 
 
+@pytest.mark.timeout(900)
+def test_c5_window_and_sequence_lengths_vs_oracle():
+    """BASELINE config 5 geometry (window (8,12,12), 16 frames: 1152-token windows with temporal shift 4, fusion sequences
+    above 448 tokens -> the STREAMING attention kernels) at reduced widths and 288^2 frames so the CPU oracle's autograd runs
+    in seconds: stage grids 72/36/18/9 exercise whole windows, H/W padding (18 -> 24) and a clamped (8,9,9) = 648-token window;
+    the fusion sequence is 16*(1+81)+32 = 1344 tokens.  Losses, outputs and every parameter gradient against the oracle."""
+    from oracle import violet_ref as R
+    arch = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 12, 12))
+    model, args = _engine(dict(vis_backbone_size="large", size_frame=16, max_size_frame=16, arch_override=arch, bert_layers=2, size_img=288, temp=1.0))
+    cfg = R.make_cfg("large", T=16, img=288, arch=arch, bert_layers=2, temp=1.0, max_size_frame=16)
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    B = 2
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    assert int((mb["ans_mtm"] != -1).sum()) > 0 and float(mb["mvm_mask"].sum()) > 0
+    neg = R.vtm_negatives_default(B)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ls = R.pretrain_losses(params, cfg, mb, negatives=neg)
+    ls["total"].backward()
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+    eng = model.engine
+    eng.store.grad.zero_()
+    losses, outs = eng.forward_backward(dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda()),
+                                        negatives=neg, train=False, want_outputs=True, backward=True)
+    torch.cuda.synchronize()
+    for k in ("mtm", "vtm", "mvm"):
+        assert abs(float(losses[k].item()) - float(ls[k])) <= 2e-2 * abs(float(ls[k])) + 2e-3, (k, float(losses[k].item()), float(ls[k]))
+    assert _cos(outs["out_mvm"].float().cpu(), ls["out"]["out_mvm"].detach()) >= 0.999
+    assert _cos(outs["out_mtm"].float().cpu(), ls["out"]["out_mtm"].detach()) >= 0.999
+    gmax = max(float(p.grad.norm()) for p in params.values() if p.grad is not None)
+    bad, checked = [], 0
+    for name, p in params.items():
+        if p.grad is None or float(p.grad.norm()) < 1e-3 * gmax or name.startswith(("fc.1.", "fc.3.")):
+            continue
+        got = eng.store.g(name).detach().cpu().double().flatten()
+        ref = p.grad.double().flatten()
+        cos = _cos(got, ref)
+        ratio = float(got.norm() / ref.norm())
+        checked += 1
+        if cos < 0.98 or abs(ratio - 1.0) > 0.1:
+            bad.append((name, round(cos, 4), round(ratio, 3)))
+    assert checked > 80 and not bad, (checked, bad[:12])
+
+
 def test_full_size_batch_permutation_invariance():
     """Size-independent property at the C2 shapes (B = 4): permuting the clips of a batch (and the VTM negatives with them)
     leaves every loss and the whole gradient arena unchanged up to summation order."""
