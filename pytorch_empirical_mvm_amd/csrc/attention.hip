@@ -1500,8 +1500,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
 // tiles (forward, dQ) or NW*KT key tiles (dK/dV) of one (sequence, head); blocks of the same (sequence, head) are adjacent in the
 // XCD remap so the chunks they re-read stay in that XCD's L2.
 // ================================================================================================
-struct SmemS { int lpk, off_b, off_rc, off_reg, off_tab, off_dtab, off_lse, off_delta, total; };
-// which: 0 fwd, 1 dq (+dtab), 2 dkv (+lse/delta chunk)
+struct SmemS { int lpk, off_b, off_rc, off_reg, off_tab, off_lse, off_delta, total; };
+// which: 0 fwd / dq / dbias, 2 dkv (+lse/delta chunk)
 __host__ __device__ inline SmemS smem_stream(int L, int hd, int mode, int table_len, int which, int KC) {
   SmemS s;
   s.lpk = (L + KC - 1) / KC * KC;
@@ -1510,7 +1510,6 @@ __host__ __device__ inline SmemS smem_stream(int L, int hd, int mode, int table_
   s.off_rc = o; if (mode == 0) o += s.lpk * 4;
   s.off_reg = o; o += s.lpk;
   s.off_tab = o; if (mode == 0) o += ((table_len + 3) & ~3) * 4;
-  s.off_dtab = o; if (mode == 0 && which == 1) o += ((table_len + 3) & ~3) * 4;
   s.off_lse = o; if (which == 2) o += KC * 4;
   s.off_delta = o; if (which == 2) o += KC * 4;
   s.total = (o + 15) & ~15;
@@ -1652,8 +1651,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
   }
 }
 
-// dQ (+ delta, + bias-table gradient): workgroup (sequence chunk, head, query block) walks its sequences so the LDS copy of the
-// table gradient is flushed once per workgroup; K / V stream through LDS in KC-token chunks.
+// dQ (+ delta): workgroup (sequence chunk, head, query block) walks its sequences (the per-head table is staged once); K / V
+// stream through LDS in KC-token chunks.  The bias-table gradient has its own kernel (attn_bwd_dbias_stream_kernel).
 template <int HD, int MODE, int NW, int KC>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1661,7 +1660,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int L = p.L, heads = p.heads;
-  const SmemS sm = smem_stream(L, HD, MODE, p.table_len, 1, KC);
+  const SmemS sm = smem_stream(L, HD, MODE, p.table_len, 0, KC);
   const int logical = xcd_remap(blockIdx.x, nchunks * heads * nqb);
   const int ch = logical / nqb, qb = logical - ch * nqb;
   const int chunk = ch / heads, h = ch - chunk * heads;
@@ -1670,14 +1669,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
   int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
   unsigned char* reg = smem + sm.off_reg;
   float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
-  float* dtab = reinterpret_cast<float*>(smem + sm.off_dtab);
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const bool want_dtab = pb.dbias_table != nullptr;
   const uint32_t thr8 = drop_thr8(p.dropout_p);
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   if (MODE == 0) {
     for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
-    for (int i = tid; i < p.table_len; i += NW * 64) { tab[i] = p.bias_table[(size_t)i * heads + h]; dtab[i] = 0.f; }
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
   }
   const int qt = qb * NW + wave;
   const int q = qt * 16 + r;
@@ -1755,7 +1752,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
               const float pr = (key0 + j < L && qv) ? __expf(s - lse) : 0.f;
               const float d = pr * (dp4[j] * seq_scale - dl);
               ds[u][j] = d;
-              if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], d);
             }
           } else {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
@@ -1785,12 +1781,111 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
         *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
     }
   }
-  if (MODE == 0 && want_dtab) {
-    __syncthreads();
-    for (int i = tid; i < p.table_len; i += NW * 64) {
-      const float v = dtab[i];
-      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+}
+
+// Relative-position-bias table gradient of the streaming window path.  Scattering every dS element into an LDS table copy from
+// the dQ kernel costs one conflicting LDS atomic per score element (47% of the config-5 step); instead a workgroup of THIS kernel
+// owns a fixed (head, query block, key chunk), recomputes S / dP for its block over the sequences and sums dS in registers (the
+// accumulator layout of the score tiles), so the scatter through rc[i]-rc[j]+rc0 happens once per workgroup.  Sequences are
+// walked window-major: the bias + shift-mask block of a window position is built once (it is the score MFMA's C operand) and
+// serves that position's sequence of every clip -- per score element only exp2 and three fmas remain.  Runs after the dQ kernel
+// (reads delta).
+template <int NW, int KC>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dbias_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb, const int nwin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HD = 32, NTC = KC / 16;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int L = p.L, heads = p.heads;
+  const SmemS sm = smem_stream(L, HD, 0, p.table_len, 0, KC);
+  const int nkc = (L + KC - 1) / KC;
+  const int logical = xcd_remap(blockIdx.x, nchunks * heads * nqb * nkc);
+  const int kc = logical % nkc, rest = logical / nkc;
+  const int qb = rest % nqb, ch = rest / nqb;
+  const int chunk = ch / heads, h = ch - chunk * heads;
+  const int k0 = kc * KC;
+  unsigned char* Ksm = smem;
+  unsigned char* Vsm = smem + sm.off_b;
+  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
+  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  float* dtab = tab;                                 // the gradient copy reuses the table's LDS once the sequence loop is done
+  for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
+  for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+  __syncthreads();
+  const int qt = qb * NW + wave;
+  const int q = qt * 16 + r;
+  const bool qv = q < L;
+  const int rcq = rc[qv ? q : 0];
+  const int nclip = p.nseq / nwin;                   // host guarantees nwin divides nseq (nwin = nseq otherwise)
+  f32x4 racc[NTC];
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) racc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int w = chunk; w < nwin; w += nchunks) {
+    // bias + mask block of this window position against the key chunk (-inf: padded key / padded query -> p = 0)
+    f32x4 bm[NTC];
+    {
+      const unsigned char* regw = p.region ? p.region + (size_t)(w % p.n_win) * L : nullptr;
+      const int regq = (regw && qv) ? regw[q] : 0;
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        const int key0 = k0 + t * 16 + g * 4;
+        const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
+        const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = qv && key0 + j < L;
+          float v = tab[rcq - rks[j] + p.rc0];
+          if (regw && ok && regq != regw[key0 + j]) v -= 100.f;
+          bm[t][j] = ok ? v : NEG_INF;
+        }
+      }
     }
+    for (int b = 0; b < nclip; ++b) {
+      const int seq = b * nwin + w;
+      const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
+      const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
+      __syncthreads();
+      fill_rowmajor<HD>(Ksm, qkv + (size_t)k0 * p.ld_qkv + p.k_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+      fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+      const float ss = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+      const bf16x8 qf = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8, qv);
+      const bf16x8 dof = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8, qv);
+      const float nl = qv ? -p.lse[((size_t)seq * heads + h) * L + q] * LOG2E : 0.f;
+      const float ndl = qv ? -pb.delta[((size_t)seq * heads + h) * L + q] : 0.f;
+      fill_wait();
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        const int row = t * 16 + r;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, g));
+        const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, bm[t], 0, 0, 0);
+        const bf16x8 vf = frag_hd<HD>(Vsm, row, g);
+        const f32x4 dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[j], LOG2E, nl));
+          racc[t][j] = __builtin_fmaf(pr, __builtin_fmaf(dp4[j], ss, ndl), racc[t][j]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < p.table_len; i += NW * 64) dtab[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) {
+    const int key0 = k0 + t * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (qv && key0 + j < L && racc[t][j] != 0.f) atomicAdd(&dtab[rcq - rc[key0 + j] + p.rc0], racc[t][j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < p.table_len; i += NW * 64) {
+    const float v = dtab[i];
+    if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
   }
 }
 
@@ -2087,10 +2182,10 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   if (use_stream(&d->f)) {                           // streaming kernels (see vmvm_attention_fwd)
     constexpr int NWS = 8, KCS = 128;
     const int nt_ = (d->f.L + 15) / 16;
-    const SmemS sa = smem_stream(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 1, KCS);
+    const SmemS sa = smem_stream(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 0, KCS);
     const SmemS sb = smem_stream(d->f.L, d->f.head_dim, d->f.mode, d->f.table_len, 2, KCS);
     const int nqb = (nt_ + NWS - 1) / NWS;
-    int nchs = 1024 / (d->f.heads * nqb);             // ~4 workgroups per CU; more sequences per workgroup = fewer table-gradient flushes
+    int nchs = 2048 / (d->f.heads * nqb);             // ~8 workgroups per CU; a workgroup stages the per-head table once for its sequences
     if (nchs < 1) nchs = 1;
     if (nchs > d->f.nseq || d->f.mode == 1) nchs = d->f.nseq;
     const int kt_ = d->f.mode == 0 ? 2 : 1;
@@ -2107,6 +2202,22 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       VMVM_CHECK_LAUNCH();                                                                                           \
     } while (0)
     if (d->f.mode == 0) LAUNCH_BWD_S(32, 0); else LAUNCH_BWD_S(64, 1);
+    if (d->f.mode == 0 && d->dbias_table) {
+      const int nkc = (d->f.L + KCS - 1) / KCS;
+      // window positions (the bias + mask block is per position); without a region map every sequence shares one block
+      int nwin = d->f.region ? ((d->f.n_win > 0 && d->f.nseq % d->f.n_win == 0) ? d->f.n_win : d->f.nseq) : 1;
+      int ncb = 2048 / (d->f.heads * nqb * nkc);
+      if (ncb < 1) ncb = 1;
+      if (!d->f.region && ncb > 1) {                  // no mask: split the sequences themselves to fill the chip
+        nwin = ncb < d->f.nseq ? ncb : d->f.nseq;
+        while (d->f.nseq % nwin) --nwin;
+      }
+      if (ncb > nwin) ncb = nwin;
+      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWS, KCS>, sa.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWS, KCS>), dim3(ncb * d->f.heads * nqb * nkc), dim3(NWS * 64), sa.total, st, *d, ncb, nqb, nwin);
+      VMVM_CHECK_LAUNCH();
+    }
     return VMVM_OK;
   }
   const int nb = d->f.nseq * d->f.heads;
