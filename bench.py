@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("VMVM_BENCH_BATCH", "32")), help="clips per GPU")
     ap.add_argument("--size", default="base")
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--img", type=int, default=224, help="frame size; --size large --img 384 --frames 16 is BASELINE config 5's geometry (run at bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mvm-target", default="pixel", help="pixel (C2/C3, the headline config) or vq (C4: frozen dVAE tokenizer, random weights)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -133,7 +134,7 @@ def main():
     rank, world, local = D.init_from_env("nccl")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    args = CFG.get_args(vis_backbone_size=a.size, size_frame=a.frames, max_size_frame=max(a.frames, 6), size_img=224, size_txt=32,
+    args = CFG.get_args(vis_backbone_size=a.size, size_frame=a.frames, max_size_frame=max(a.frames, 6), size_img=a.img, size_txt=32,
                         mvm_target=[a.mvm_target], max_iter=10000, seed=88 + rank)
     model = VIOLET_Pretrain(args, None, device=device)
     agent = Agent_Pretrain(args, model)
@@ -177,20 +178,28 @@ def main():
     clips = B * world * a.steps
     value = clips / dt
     kt, kflop = time_kernel_gemm(device)
+    headline = a.size == "base" and a.frames == 8 and a.img == 224
+    window = "(8,12,12)" if (a.size == "large" and a.img == 384) else "(8,7,7)"
+    if headline:
+        label = "C2" if a.mvm_target == "pixel" else "C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)"
+    elif a.size == "large" and a.img == 384 and a.frames == 16:
+        label = "C5 geometry at bf16 (the fp8 GEMM path of config 5 is not built; streaming attention kernels)"
+    else:
+        label = "non-headline shape"
     out = {
-        "metric": "pretrain clips/sec (Swin-B, 8x224^2, 32 txt tok)", "value": round(value, 3), "unit": "clips/s",
+        "metric": "pretrain clips/sec (Swin-B, 8x224^2, 32 txt tok)" if headline else f"pretrain clips/sec (Swin-{a.size}, {a.frames}x{a.img}^2, 32 txt tok)", "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{'C2' if a.mvm_target == 'pixel' else 'C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)'}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window(8,7,7), {a.frames}x224^2 frames, 32 text tokens, "
+        "config": {"workload": f"{label}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window{window}, {a.frames}x{a.img}^2 frames, 32 text tokens, "
                                f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-        "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if a.mvm_target == "pixel" else None,
+        "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4), "traffic": ROOFLINE_TRAFFIC_BYTES,
                      "kernel": "gemm_pers_kernel<k-major,k-major,F=bias|GELU|rowscale> fusion FFN fc1+bias+GELU (M=69120,N=3072,K=768), 2*M*N*K flop per launch"},
         "losses_last_step": last,
     }
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.img == 224:
         out["cpu_baseline"] = cpu_baseline(a.size, a.frames)
     print(json.dumps(out), flush=True)
     if world > 1:

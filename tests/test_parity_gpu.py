@@ -283,6 +283,7 @@ def test_c5_window_and_sequence_lengths_vs_oracle():
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ls = R.pretrain_losses(params, cfg, mb, negatives=neg)
     ls["total"].backward()
+    ls = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ls.items()}
     cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
     eng = model.engine
     eng.store.grad.zero_()
