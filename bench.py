@@ -4,6 +4,7 @@
     python bench.py [--gpus N --steps K --warmup W --batch B]         (N>1: launched by torch.distributed.run)
 
 A "step" = one full optimizer step of the hot path over one synthetic WebVid-shape batch already resident in HBM:
+rm/bm + MLM masking on the device (vmvm_masking, fresh draws each step; --host-masking moves it out of the timed region) ->
 forward (Swin-B 8x224^2 + BERT embeddings + 12-layer fusion x (1+O) sequences) -> MLM/VTM/MVM-pixel losses -> backward ->
 gradient all-reduce (N>1) -> clip -> AdamW; train mode (dropout + DropPath + attention dropout ON), bf16 compute.
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside this run) and `cpu_baseline`
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--img", type=int, default=224, help="frame size; --size large --img 384 --frames 16 is BASELINE config 5's geometry (run at bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-masking", action="store_true", help="mask the batches on the host before the timed region (the round-1 default until device-side masking existed)")
     ap.add_argument("--mvm-target", default="pixel", help="pixel (C2/C3, the headline config) or vq (C4: frozen dVAE tokenizer, random weights)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
@@ -143,14 +145,21 @@ def main():
     B = a.batch
     import random
     random.seed(88 + rank); np.random.seed(88 + rank); torch.manual_seed(88 + rank)
-    batches = []
+    batches, raw = [], []
     for i in range(2):
         img, txt, mask = synth_batch(args, B, device, 88 + rank + 1000 * i)
+        raw.append((img.to(device), txt.to(device), mask.to(device)))
         mb = agent.masking(img, txt, mask, None)
         batches.append(agent.prepare_batch(mb))
     torch.cuda.synchronize()
+    # masking INSIDE the timed step (device-side, vmvm_masking; fresh rm/bm draws every step) for the pixel target; the vq
+    # target needs host-built index lists of the covered patches, so its batches are masked before the timed region
+    mask_in_step = (a.mvm_target == "pixel") and not a.host_masking
+    gen = torch.Generator(device=device).manual_seed(88 + rank)
 
     def one_step(i):
+        if mask_in_step:
+            return agent.step(agent.masking_device(*raw[i % len(raw)], generator=gen), is_train=True, sync=False)
         return agent.step(batches[i % len(batches)], is_train=True, sync=False)
 
     for i in range(a.warmup):
@@ -191,7 +200,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{label}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window{window}, {a.frames}x{a.img}^2 frames, 32 text tokens, "
-                               f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip",
+                               f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip, "
+                               f"{'device-side rm/bm masking inside the timed step' if mask_in_step else 'masking before the timed region'}",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -174,6 +174,20 @@ int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
  * Agent_Pretrain.masking (main_pretrain.py:362-364) without writing a masked copy of the clip. */
 int vmvm_patch_im2col(const float* img, const uint8_t* cov, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream);
 
+/* Device-side masking (Agent_Pretrain.masking main_pretrain.py:276-372, mask types 'rm' and 'bm'; 'am' is not built) from
+ * EXPLICIT uniform draws in [0,1) (f32, e.g. torch.rand on the device), so the same draws give the same batch on the CPU oracle:
+ *   u_type [B]            mask type of clip b = types[floor(u * n_types)]   (types[i]: 0 = 'rm', 1 = 'bm'; random.choice :303)
+ *   u_txt  [B][X]         MLM: a non-special token (cls/sep/pad/mask ids) with u < p gets label = id and id <- mask_id (:305,:346,:354)
+ *   u_rm   [B][T][1+h*w]  'rm': patch (t, i) covered iff u[t][1+i] < p   (slot 0 is the frame's cls position, never a target :348-352)
+ *   u_bm   [B][T][6]      'bm': cuboid k of T: t = 1+floor(u0*(T-1)) (T>1 else 1), hh = 1+floor(u1*(2h/3-1)), ww likewise,
+ *                          t1 = floor(u3*(T-t+1)), h1 = floor(u4*(h-hh+1)), w1 = floor(u5*(w-ww+1))   (numpy randint bounds :308-313)
+ * txt i64 [B][X] is updated in place; ans_mtm i64 [B][X] (-1 = not a target); cov u8 [B][T][h][w] is the patch cover that
+ * vmvm_patch_im2col / vmvm_pixel_l1 consume (the reference's x32 expansion :362 and `img *= 1-cov` are applied there).
+ * has_bm: 'bm' is among `types` (validates h, w >= 3 as numpy's randint does in the reference). */
+int vmvm_masking(int64_t* txt, int64_t* ans_mtm, uint8_t* cov, const float* u_type, const float* u_txt, const float* u_rm,
+                 const float* u_bm, const int32_t* types, int32_t n_types, int32_t has_bm, int32_t B, int32_t X, int32_t T, int32_t h,
+                 int32_t w, float p, int32_t cls, int32_t sep, int32_t pad, int32_t mask_id, void* stream);
+
 /* EncVideo token assembly (model.py:58-71): pre[b,t,0,:]=cls, pre[b,t,1+p,:]=fc_out[b,t,p,:]; + pos[p] + len[t].
  * out bf16 [B*T*(1+hw)][Hd] (the following LayerNorm is vmvm_layernorm_fwd). */
 int vmvm_encvideo_assemble(const void* fc_out, const float* cls, const float* pos, const float* len,

@@ -654,6 +654,42 @@ def bm_cover(T, h, w, draws):
     return cov
 
 
+def masking_from_uniform(cfg, img, txt, mask, u_type, u_txt, u_rm, u_bm, types=("rm", "bm"), p_mask=0.15):
+    """masking() driven by explicit uniform draws (float32 in [0,1)) -- the CPU statement of the device-side masking kernel's
+    contract (include/vmvm.h vmvm_masking): mask type = types[floor(u*len)] (random.choice :303), MLM selection u < p (:305),
+    'rm' field u[t][1+i] < p with the cls slot dropped (:348-352), 'bm' cuboids with numpy's randint bounds (:308-313) mapped as
+    lo + floor(u*(hi-lo)) in float32.  The geometry itself goes through bm_cover / apply_masking (pinned by masking.npz)."""
+    B, T, _, H, W = img.shape
+    h, w = H // cfg["size_patch"], W // cfg["size_patch"]
+    f32 = np.float32
+
+    def ri(u, n):
+        return min(int(f32(u) * f32(n)), n - 1)
+    u_type, u_txt, u_rm, u_bm = (np.asarray(a, dtype=np.float32) for a in (u_type, u_txt, u_rm, u_bm))
+    sel = torch.from_numpy(u_txt.reshape(B, -1) < f32(p_mask))
+    cov = torch.zeros(B, T, h, w)
+    u_rm = u_rm.reshape(B, T, 1 + h * w)
+    u_bm = u_bm.reshape(B, T, 6)
+    kinds = []
+    for b in range(B):
+        kind = types[ri(u_type[b], len(types))]
+        kinds.append(kind)
+        if kind == "rm":
+            cov[b] = torch.from_numpy((u_rm[b, :, 1:] < f32(p_mask)).astype(np.float32).reshape(T, h, w))
+        else:
+            draws = []
+            for k in range(T):
+                u = u_bm[b, k]
+                t = 1 + ri(u[0], T - 1) if T > 1 else 1
+                hh, ww = 1 + ri(u[1], h * 2 // 3 - 1), 1 + ri(u[2], w * 2 // 3 - 1)
+                draws.append((t, hh, ww, ri(u[3], T - t + 1), ri(u[4], h - hh + 1), ri(u[5], w - ww + 1)))
+            cov[b] = bm_cover(T, h, w, draws)
+    out = apply_masking(img, txt, mask, sel, cov, cfg["size_patch"])
+    out["cov"] = cov
+    out["kinds"] = kinds
+    return out
+
+
 def default_masking(cfg, img, txt, mask, seed=0, p_mask=0.15):
     """Seeded masking with the reference's distributions ('rm' for even samples, 'bm' for odd)."""
     g = np.random.RandomState(seed)

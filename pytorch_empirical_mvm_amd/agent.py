@@ -88,6 +88,39 @@ class Agent_Pretrain:
             out["img"] = img
         return out
 
+    @torch.no_grad()
+    def masking_device(self, img, txt, mask, vq=None, p_mask=0.15, generator=None, draws=None):
+        """masking() on the GPU (libvmvm `vmvm_masking`) -- no host loops, no host sync for the pixel target.
+        `img`, `txt`, `mask` are device tensors; the uniform draws come from torch.rand on the device (`generator` = the
+        rank's CUDA generator) or are passed explicitly as `draws` = (u_type, u_txt, u_rm, u_bm) (parity tests: the CPU
+        oracle's `masking_from_uniform` consumes the same arrays).  Same distributions as the reference ('rm' Bernoulli
+        field / 'bm' cuboids / 15 % [MASK]); the random STREAM necessarily differs from the host RNGs of masking()."""
+        dev = self.engine.device
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        h, w = H // self.patch_size, W // self.patch_size
+        kinds = {"rm": 0, "bm": 1}
+        for m in self.args.pretrain_masks:
+            if m not in kinds:
+                raise NotImplementedError(f"mask type '{m}' is outside the accelerated path (SURVEY 8f.2)")
+        types = torch.tensor([kinds[m] for m in self.args.pretrain_masks], dtype=torch.int32)
+        if draws is None:
+            n = [B, B * X, B * T * (1 + h * w), B * T * 6]
+            u = torch.rand(sum(n), device=dev, generator=generator)
+            draws = torch.split(u, n)
+        u_type, u_txt, u_rm, u_bm = (d.to(dev, torch.float32).contiguous() for d in draws)
+        txt = txt.to(dev).clone()
+        if p_mask > 0:
+            ans_mtm, cov = K.masking(txt, u_type, u_txt, u_rm, u_bm, types, T, h, w, p_mask, CFG.TOKENS)
+        else:
+            ans_mtm = torch.full_like(txt, -1)
+            cov = torch.zeros((B, T, h, w), device=dev, dtype=torch.uint8)
+        out = {"img": img, "unmask_img": img, "txt": txt, "mask": mask, "ans_mtm": ans_mtm, "cov": cov,
+               "ans_mvm": torch.full((B, T * (1 + h * w)), -1, dtype=torch.long, device=dev)}
+        if "vq" in self.args.mvm_target:
+            out.update(self.vq_index(cov))              # index lists are built on the host (one sync)
+        return out
+
     def vq_index(self, cov):
         """Host-side index lists for the vq head (main_pretrain.py:485-488): a vq position is a target iff its 32x32 patch is
         covered, so the head only runs on covered patches.  patch_rows: rows of the MVM output (B*(T*(1+hw)+X) layout of the

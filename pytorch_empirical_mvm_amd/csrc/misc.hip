@@ -450,7 +450,70 @@ inline int nblk(long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-side masking (Agent_Pretrain.masking main_pretrain.py:276-372, 'rm' / 'bm'): one workgroup per clip turns
+// explicit uniform draws into the patch cover, the [MASK]-ed token ids and the MLM labels.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int randint_u(float u, int n) {          // numpy randint(0, n) from u in [0,1): floor(u*n), clamped
+  int v = (int)(u * (float)n);
+  return v > n - 1 ? n - 1 : v;
+}
+__global__ __launch_bounds__(256) void masking_kernel(int64_t* __restrict__ txt, int64_t* __restrict__ ans_mtm, uint8_t* __restrict__ cov,
+                                                      const float* __restrict__ u_type, const float* __restrict__ u_txt,
+                                                      const float* __restrict__ u_rm, const float* __restrict__ u_bm,
+                                                      const int32_t* __restrict__ types, int n_types, int X, int T, int h, int w, float p,
+                                                      int cls, int sep, int pad, int msk) {
+  __shared__ int cub[64][6];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int type = types[randint_u(u_type[b], n_types)];             // random.choice(pretrain_masks) (:303)
+  for (int x = tid; x < X; x += 256) {                               // MLM: non-special token with rand < p -> label = id, id <- [MASK] (:305,:346,:354)
+    const int64_t id = txt[(size_t)b * X + x];
+    const bool spc = id == cls || id == sep || id == pad || id == msk;
+    const bool sel = !spc && u_txt[(size_t)b * X + x] < p;
+    ans_mtm[(size_t)b * X + x] = sel ? id : (int64_t)-1;
+    if (sel) txt[(size_t)b * X + x] = msk;
+  }
+  const int hw = h * w;
+  if (type == 0) {                                                   // 'rm': rand((1+hw)*T) < p, the per-frame cls slot is never a target (:348-352)
+    for (int i = tid; i < T * hw; i += 256) {
+      const int t = i / hw, pp = i - t * hw;
+      cov[((size_t)b * T + t) * hw + pp] = u_rm[((size_t)b * T + t) * (1 + hw) + 1 + pp] < p ? 1 : 0;
+    }
+  } else {                                                           // 'bm': T cuboids, numpy randint bounds of :308-313
+    for (int k = tid; k < T; k += 256) {
+      const float* u = u_bm + ((size_t)b * T + k) * 6;
+      const int t = T > 1 ? 1 + randint_u(u[0], T - 1) : 1;
+      const int hh = 1 + randint_u(u[1], h * 2 / 3 - 1), ww = 1 + randint_u(u[2], w * 2 / 3 - 1);
+      cub[k][0] = randint_u(u[3], T - t + 1); cub[k][1] = cub[k][0] + t;
+      cub[k][2] = randint_u(u[4], h - hh + 1); cub[k][3] = cub[k][2] + hh;
+      cub[k][4] = randint_u(u[5], w - ww + 1); cub[k][5] = cub[k][4] + ww;
+    }
+    __syncthreads();
+    for (int i = tid; i < T * hw; i += 256) {
+      const int t = i / hw, pp = i - t * hw, ph = pp / w, pw = pp - ph * w;
+      int c = 0;
+      for (int k = 0; k < T; ++k)
+        c |= (t >= cub[k][0] && t < cub[k][1] && ph >= cub[k][2] && ph < cub[k][3] && pw >= cub[k][4] && pw < cub[k][5]) ? 1 : 0;
+      cov[((size_t)b * T + t) * hw + pp] = (uint8_t)c;
+    }
+  }
+}
+
 #define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int vmvm_masking(int64_t* txt, int64_t* ans_mtm, uint8_t* cov, const float* u_type, const float* u_txt, const float* u_rm,
+                            const float* u_bm, const int32_t* types, int32_t n_types, int32_t has_bm, int32_t B, int32_t X, int32_t T, int32_t h,
+                            int32_t w, float p, int32_t cls, int32_t sep, int32_t pad, int32_t mask_id, void* stream) {
+  if (!txt || !ans_mtm || !cov || !u_type || !u_txt || !u_rm || !u_bm || !types || n_types <= 0 || B <= 0 || X <= 0 || T <= 0 || h <= 0 || w <= 0)
+    return VMVM_EINVAL;
+  if (T > 64) return VMVM_ENOSUPPORT;
+  if (has_bm && (h * 2 / 3 < 2 || w * 2 / 3 < 2)) return VMVM_EINVAL;        // numpy's randint(1, 1) raises in the reference as well
+  hipLaunchKernelGGL(masking_kernel, dim3(B), dim3(256), 0, ST, txt, ans_mtm, cov, u_type, u_txt, u_rm, u_bm, types, n_types, X, T, h, w, p,
+                     cls, sep, pad, mask_id);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
 
 extern "C" int vmvm_patch_im2col(const float* img, const uint8_t* cov, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream) {
   if (!img || !cols || B <= 0 || T <= 0 || (H & 3) || (W & 3)) return VMVM_EINVAL;

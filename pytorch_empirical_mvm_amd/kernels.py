@@ -153,6 +153,19 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     return dqkv
 
 
+def masking(txt, u_type, u_txt, u_rm, u_bm, types, T, h, w, p, tokens):
+    """vmvm_masking: txt (B,X) i64 on the device is updated in place; returns (ans_mtm i64 (B,X), cov u8 (B,T,h,w))."""
+    B, X = txt.shape
+    ans = torch.empty_like(txt)
+    cov = torch.empty((B, T, h, w), device=txt.device, dtype=torch.uint8)
+    has_bm = int(bool((types == 1).any().item())) if types.device.type == "cpu" else 1
+    tdev = types.to(txt.device)
+    L.check(L.load().vmvm_masking(txt.data_ptr(), ans.data_ptr(), cov.data_ptr(), u_type.data_ptr(), u_txt.data_ptr(), u_rm.data_ptr(),
+                                  u_bm.data_ptr(), tdev.data_ptr(), tdev.numel(), has_bm, B, X, T, h, w, float(p),
+                                  tokens["cls"], tokens["sep"], tokens["pad"], tokens["mask"], L.stream()), "masking")
+    return ans, cov
+
+
 def patch_im2col(img, cov=None):
     B, T, _, H, W = img.shape
     cols = torch.empty((B * T * (H // 4) * (W // 4), 192), device=img.device, dtype=BF16)

@@ -107,3 +107,42 @@ def test_vq_index_matches_reference_answer_map():
     Lq = 4 * 50 + 32
     b, t, hh, ww = np.nonzero(cov.numpy())
     np.testing.assert_array_equal(vqi["vq_patch_rows"].numpy(), b * Lq + t * 50 + 1 + hh * 7 + ww)
+
+
+def test_masking_from_uniform_matches_reference_distributions():
+    """SURVEY 8f.2 contract of the device-side masking kernel, stated by the oracle: the explicit-draw mapping reproduces the
+    reference's ranges (numpy randint bounds of main_pretrain.py:308-313, cls slot never covered, special tokens never masked)
+    including u at the top of [0,1), and its statistics (15 % Bernoulli fields, uniform cuboid sizes)."""
+    import numpy as np
+    import torch
+    from oracle import violet_ref as R
+    cfg = R.make_cfg("tiny", T=8)
+    B, T, h, w, X = 64, 8, 7, 7, 32
+    img, txt, mask = R.make_batch(cfg, 2)
+    img = img[:1].expand(B, -1, -1, -1, -1)
+    txt = txt[:1].repeat(B, 1); mask = mask[:1].repeat(B, 1)
+    g = np.random.RandomState(5)
+    top = np.float32(1.0) - np.float32(2.0 ** -24)
+    u_type = g.rand(B).astype(np.float32)
+    u_txt = g.rand(B, X).astype(np.float32)
+    u_rm = g.rand(B, T, 1 + h * w).astype(np.float32)
+    u_bm = g.rand(B, T, 6).astype(np.float32)
+    u_type[0], u_bm[0] = top, top                        # extreme draws: clamped to the last value, never out of range
+    u_type[1], u_bm[1] = top, 0.0
+    o = R.masking_from_uniform(cfg, img, txt, mask, u_type, u_txt, u_rm, u_bm)
+    assert o["kinds"][0] == "bm" and o["kinds"][1] == "bm" and set(o["kinds"]) == {"rm", "bm"}
+    # extreme cuboids: every draw at the top -> t = T-1, hh = ww = 3 at the last admissible corner; all zero -> 1x1x1 at the origin
+    c0 = o["cov"][0]
+    assert float(c0.sum()) == (T - 1) * 3 * 3 and float(c0[1:, 4:, 4:].sum()) == (T - 1) * 9
+    assert float(o["cov"][1].sum()) == 1 and float(o["cov"][1][0, 0, 0]) == 1
+    spc = (txt == 101) | (txt == 102) | (txt == 0) | (txt == 103)
+    assert bool(((o["ans_mtm"] != -1) & spc).any()) is False
+    assert torch.equal(o["txt"][o["ans_mtm"] != -1], torch.full((int((o["ans_mtm"] != -1).sum()),), 103))
+    rm = [b for b in range(B) if o["kinds"][b] == "rm"]
+    frac = float(o["cov"][rm].mean())
+    assert abs(frac - 0.15) < 0.02, frac
+    for b in rm:                                         # the field is exactly the draw, cls slot dropped
+        np.testing.assert_array_equal(o["cov"][b].numpy().reshape(T, -1), (u_rm[b, :, 1:] < np.float32(0.15)).astype(np.float32))
+    # mvm_mask is the x32 expansion of cov and img is zeroed under it (main_pretrain.py:362-364)
+    assert torch.equal(o["mvm_mask"][:, :, 0, ::32, ::32], o["cov"])
+    assert float((o["img"] * o["mvm_mask"]).abs().max()) == 0.0

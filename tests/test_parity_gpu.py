@@ -359,3 +359,34 @@ def test_dvae_teacher_native_convs_vs_pytorch_fp32():
     assert float((zl - zr).abs().max()) <= 3e-2 * float(zr.abs().max())
     tok, tokr = t.extract_vq_token(img), ref.extract_vq_token(img)
     assert float((tok == tokr).float().mean()) >= 0.99
+
+
+def test_device_masking_matches_oracle_on_the_same_draws():
+    """`vmvm_masking` (through Agent_Pretrain.masking_device) against the oracle's masking_from_uniform on the SAME
+    uniform draws -- cover, [MASK]-ed ids and MLM labels bit-exact -- at the C1 / C2 / C5 grids and a 3x3 grid; then a train step
+    on a device-masked batch."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6))
+    agent = Agent_Pretrain(args, model)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    for (T, S, B) in [(4, 224, 6), (8, 224, 32), (16, 384, 5), (1, 96, 4), (3, 96, 7)]:
+        h = w = S // 32
+        cfg = R.make_cfg("tiny", T=T, img=S)
+        img = torch.zeros(B, T, 3, S, S)
+        _, txt, mask = R.make_batch(R.make_cfg("tiny", T=4), B)
+        n = [B, B * 32, B * T * (1 + h * w), B * T * 6]
+        u = torch.rand(sum(n), device="cuda", generator=g)
+        if T == 8:
+            u[:2] = 1.0 - 2.0 ** -24                      # top-of-range draws (clamp path)
+            u[n[0] + n[1] + n[2]:n[0] + n[1] + n[2] + 12] = 1.0 - 2.0 ** -24
+        draws = torch.split(u, n)
+        out = agent.masking_device(img.cuda(), txt.cuda(), mask.cuda(), draws=draws)
+        ref = R.masking_from_uniform(cfg, img, txt, mask, *(d.cpu().numpy() for d in draws))
+        assert torch.equal(out["cov"].cpu(), ref["cov"].to(torch.uint8)), (T, S)
+        assert torch.equal(out["txt"].cpu(), ref["txt"]) and torch.equal(out["ans_mtm"].cpu(), ref["ans_mtm"]), (T, S)
+        assert out["cov"].sum() > 0
+    img, txt, mask = R.make_batch(R.make_cfg("tiny", T=4), 4)
+    mb = agent.masking_device(img.cuda(), txt.cuda(), mask.cuda(), generator=g)
+    r = agent.step(mb, is_train=True)
+    assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
