@@ -216,6 +216,14 @@ int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, int32_t V, co
 int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum,
                   float* loss_sum, void* dpred, int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, void* stream);
 
+/* MVM feature targets (calc_mvm_loss '3d_feature' main_pretrain.py:508-526 / '2d_feature' :527-545): masked L1 between the
+ * fc_mvm prediction and the frozen Swin teacher's features, bf16 [M][C] each, row = (b, t, patch); cov u8 [M] is the patch cover
+ * (= max_pool2d(mvm_mask, 32).sum(1)/3 of the reference); mask_sum = device f32 = sum(cov) (covered PATCHES, as the reference's
+ * mask.sum()); loss_sum (ACCUMULATED) += sum |pred-target| cov * inv_div / (mask_sum + 1e-5) with inv_div = 1/3;
+ * dpred bf16 [M][C] = cov * sign(pred - target) * inv_div / (mask_sum + 1e-5). */
+int vmvm_feature_l1(const void* pred, const void* target, const uint8_t* cov, const float* mask_sum, float inv_div, float* loss_sum,
+                    void* dpred, int32_t M, int32_t C, void* stream);
+
 /* VTM head tail (main_pretrain.py:147,260): logit[m] = (dot(hid[m,:], w) + b) / temp ; hid bf16 [M][K] */
 int vmvm_rowdot(const void* hid, int32_t M, int32_t K, const float* w, const float* b, float inv_temp,
                 float* out, void* stream);

@@ -42,9 +42,10 @@ BERT = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512,
 
 def make_cfg(size="base", T=8, img=224, n_txt=32, max_size_frame=None, max_size_patch=14,
              size_patch=32, temp=0.05, bert_layers=12, mvm_target="pixel", arch=None, vocab=None,
-             size_vq=8192, dvae_hid=256, dvae_vocab=8192):
+             size_vq=8192, dvae_hid=256, dvae_vocab=8192, teacher_arch=None):
     a = dict(ARCH[size]) if arch is None else dict(arch)
     cfg = dict(a)
+    cfg["teacher_arch"] = dict(ARCH["base"]) if teacher_arch is None else dict(teacher_arch)   # main_pretrain.py:157,168: always "base"
     cfg.update(size=size, T=T, img=img, n_txt=n_txt, max_size_frame=max_size_frame or max(T, 6),
                max_size_patch=max_size_patch, size_patch=size_patch, temp=temp,
                bert_layers=bert_layers, mvm_target=mvm_target, hidden=BERT["hidden"],
@@ -148,7 +149,81 @@ def param_shapes(cfg):
         s["fc_mvm.1.bias"] = (2 * c,)
         s["fc_mvm.3.weight"] = (cfg["size_vq"], 2 * c)
         s["fc_mvm.3.bias"] = (cfg["size_vq"],)
+    for kind in ("3d_feature", "2d_feature"):
+        if kind in cfg["mvm_target"]:      # main_pretrain.py:153-174: Dropout, Linear(H, 2H), ReLU, Linear(2H, feat_size)
+            feat = cfg["teacher_arch"]["embed_dim"] * 8
+            s["fc_mvm.1.weight"] = (2 * H, H)
+            s["fc_mvm.1.bias"] = (2 * H,)
+            s["fc_mvm.3.weight"] = (feat, 2 * H)
+            s["fc_mvm.3.bias"] = (feat,)
     return s
+
+
+def swin_param_shapes(arch, win, prefix):
+    """{key: shape} of a SwinTransformer3D (video_swin.py:410-468) under `prefix`."""
+    E, depths, heads = arch["embed_dim"], arch["depths"], arch["num_heads"]
+    s = {}
+    s[prefix + "patch_embed.proj.weight"] = (E, 3) + PATCH
+    s[prefix + "patch_embed.proj.bias"] = (E,)
+    s[prefix + "patch_embed.norm.weight"] = (E,)
+    s[prefix + "patch_embed.norm.bias"] = (E,)
+    ntab = (2 * win[0] - 1) * (2 * win[1] - 1) * (2 * win[2] - 1)
+    for i, (d, nh) in enumerate(zip(depths, heads)):
+        C = E * 2 ** i
+        for b in range(d):
+            p = prefix + f"layers.{i}.blocks.{b}."
+            s[p + "norm1.weight"] = (C,); s[p + "norm1.bias"] = (C,)
+            s[p + "attn.relative_position_bias_table"] = (ntab, nh)
+            s[p + "attn.qkv.weight"] = (3 * C, C); s[p + "attn.qkv.bias"] = (3 * C,)
+            s[p + "attn.proj.weight"] = (C, C); s[p + "attn.proj.bias"] = (C,)
+            s[p + "norm2.weight"] = (C,); s[p + "norm2.bias"] = (C,)
+            s[p + "mlp.fc1.weight"] = (4 * C, C); s[p + "mlp.fc1.bias"] = (4 * C,)
+            s[p + "mlp.fc2.weight"] = (C, 4 * C); s[p + "mlp.fc2.bias"] = (C,)
+        if i < len(depths) - 1:
+            p = prefix + f"layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,); s[p + "norm.bias"] = (4 * C,)
+    s[prefix + "norm.weight"] = (E * 8,)
+    s[prefix + "norm.bias"] = (E * 8,)
+    return s
+
+
+def hf_swin2d_param_shapes(arch, prefix, ws=7):
+    """{key: shape} of HF `transformers.SwinModel` (third-party; built at visbackbone/swin.py:16-35) under `prefix`."""
+    E, depths, heads = arch["embed_dim"], arch["depths"], arch["num_heads"]
+    s = {}
+    s[prefix + "embeddings.patch_embeddings.projection.weight"] = (E, 3, 4, 4)
+    s[prefix + "embeddings.patch_embeddings.projection.bias"] = (E,)
+    s[prefix + "embeddings.norm.weight"] = (E,)
+    s[prefix + "embeddings.norm.bias"] = (E,)
+    for i, (d, nh) in enumerate(zip(depths, heads)):
+        C = E * 2 ** i
+        for b in range(d):
+            p = prefix + f"encoder.layers.{i}.blocks.{b}."
+            s[p + "layernorm_before.weight"] = (C,); s[p + "layernorm_before.bias"] = (C,)
+            s[p + "attention.self.relative_position_bias_table"] = ((2 * ws - 1) ** 2, nh)
+            for n in ("query", "key", "value"):
+                s[p + f"attention.self.{n}.weight"] = (C, C); s[p + f"attention.self.{n}.bias"] = (C,)
+            s[p + "attention.output.dense.weight"] = (C, C); s[p + "attention.output.dense.bias"] = (C,)
+            s[p + "layernorm_after.weight"] = (C,); s[p + "layernorm_after.bias"] = (C,)
+            s[p + "intermediate.dense.weight"] = (4 * C, C); s[p + "intermediate.dense.bias"] = (4 * C,)
+            s[p + "output.dense.weight"] = (C, 4 * C); s[p + "output.dense.bias"] = (C,)
+        if i < len(depths) - 1:
+            p = prefix + f"encoder.layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,); s[p + "norm.bias"] = (4 * C,)
+    s[prefix + "layernorm.weight"] = (E * 8,)
+    s[prefix + "layernorm.bias"] = (E * 8,)
+    return s
+
+
+def teacher_param_shapes(cfg):
+    """frozen feature teacher `feature_model.*` (main_pretrain.py:153-174): VideoSwin-B for '3d_feature', HF Swin-B for '2d_feature'"""
+    if "3d_feature" in cfg["mvm_target"]:
+        return swin_param_shapes(cfg["teacher_arch"], tuple(cfg["teacher_arch"]["window"]), "feature_model.")
+    if "2d_feature" in cfg["mvm_target"]:
+        return hf_swin2d_param_shapes(cfg["teacher_arch"], "feature_model.", cfg["teacher_arch"]["window"][-1])
+    return {}
 
 
 def dvae_param_shapes(cfg):
@@ -221,6 +296,7 @@ def make_state_dict(cfg, dtype=torch.float32):
     sd = {k: closed_form(k, shp, dtype) for k, shp in param_shapes(cfg).items()}
     if "vq" in cfg["mvm_target"]:
         sd.update({k: closed_form(k, shp, dtype) for k, shp in dvae_param_shapes(cfg).items()})
+    sd.update({k: closed_form(k, shp, dtype) for k, shp in teacher_param_shapes(cfg).items()})
     return sd
 
 
@@ -384,7 +460,7 @@ def patch_embed(sd, p, x):
     return layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
 
 
-def swin_forward(sd, cfg, x, dp_scales=None, prefix="enc_img.swin."):
+def swin_forward(sd, cfg, x, dp_scales=None, prefix="enc_img.swin.", final_norm=True):
     """SwinTransformer3D.forward video_swin.py:470-482 + BasicLayer.forward :352-370.
     x (B,3,T,H,W) -> channels-last (B,T,H/32,W/32,8E).  dp_scales: list per block of (B,) or None."""
     win = tuple(cfg["window"])
@@ -405,6 +481,8 @@ def swin_forward(sd, cfg, x, dp_scales=None, prefix="enc_img.swin."):
             blk += 1
         if i < len(cfg["depths"]) - 1:
             x = patch_merging(sd, prefix + f"layers.{i}.downsample.", x)
+    if not final_norm:
+        return x
     return layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)
 
 
@@ -600,6 +678,77 @@ def vq_loss(sd, cfg, out_mvm, unmask_img, mvm_mask, tokens=None):
     return cross_entropy_ignore(lg.flatten(0, 1), ans.flatten()), lg, ans
 
 
+# ----------------------------------------------------------------------------
+# MVM feature targets: frozen Swin teachers + fc_mvm head + masked L1
+# ----------------------------------------------------------------------------
+def hf_swin2d_to_3d_keys(sd, arch, prefix="feature_model."):
+    """HF `transformers.SwinModel` tensors (third-party dependency, README 'Transformers 4.26'; SwinModel.forward with
+    output_hidden_states) renamed onto the SwinTransformer3D layout so swin_forward() can run them with window (1, ws, ws) on
+    single-frame clips: a 2-D Swin block IS the 3-D block with D = 1 (same partition / shift / -100 mask / bias index order
+    (dh + ws-1)(2ws-1) + (dw + ws-1); q k^T / sqrt(hd) == (q * hd^-0.5) k^T; PatchMerging concat order identical).  The 4x4
+    patch conv becomes the (2,4,4) conv whose second temporal slice is zero (the 3-D embed pads one zero frame, :398).
+    Pinned by tests/golden/feature2d.npz, produced by SwinModel itself."""
+    o = {}
+    w = sd[prefix + "embeddings.patch_embeddings.projection.weight"]
+    o["t.patch_embed.proj.weight"] = torch.stack([w, torch.zeros_like(w)], dim=2)
+    o["t.patch_embed.proj.bias"] = sd[prefix + "embeddings.patch_embeddings.projection.bias"]
+    o["t.patch_embed.norm.weight"] = sd[prefix + "embeddings.norm.weight"]
+    o["t.patch_embed.norm.bias"] = sd[prefix + "embeddings.norm.bias"]
+    for i, d in enumerate(arch["depths"]):
+        for b in range(d):
+            p, q = prefix + f"encoder.layers.{i}.blocks.{b}.", f"t.layers.{i}.blocks.{b}."
+            for wb in ("weight", "bias"):
+                o[q + "norm1." + wb] = sd[p + "layernorm_before." + wb]
+                o[q + "norm2." + wb] = sd[p + "layernorm_after." + wb]
+                o[q + "attn.qkv." + wb] = torch.cat([sd[p + f"attention.self.{n}." + wb] for n in ("query", "key", "value")], 0)
+                o[q + "attn.proj." + wb] = sd[p + "attention.output.dense." + wb]
+                o[q + "mlp.fc1." + wb] = sd[p + "intermediate.dense." + wb]
+                o[q + "mlp.fc2." + wb] = sd[p + "output.dense." + wb]
+            o[q + "attn.relative_position_bias_table"] = sd[p + "attention.self.relative_position_bias_table"]
+        if i < len(arch["depths"]) - 1:
+            p, q = prefix + f"encoder.layers.{i}.downsample.", f"t.layers.{i}.downsample."
+            o[q + "reduction.weight"] = sd[p + "reduction.weight"]
+            o[q + "norm.weight"], o[q + "norm.bias"] = sd[p + "norm.weight"], sd[p + "norm.bias"]
+    o["t.norm.weight"], o["t.norm.bias"] = sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"]
+    return o
+
+
+def teacher_features(sd, cfg, unmask_img):
+    """no-grad targets (B, T, h*w, F).  '3d_feature' main_pretrain.py:516-518: feature_model(img.transpose(1,2)) (final norm
+    applied, video_swin.py:480) ; '2d_feature' :535-537: SwinModel(img.flatten(0,1)).hidden_states[-1] = last stage output
+    BEFORE SwinModel.layernorm, tokens (B*T, h*w, F)."""
+    B, T, _, H, W = unmask_img.shape
+    ta = cfg["teacher_arch"]
+    with torch.no_grad():
+        if "3d_feature" in cfg["mvm_target"]:
+            tc = dict(ta)
+            f = swin_forward(sd, tc, unmask_img.transpose(1, 2), None, prefix="feature_model.")       # (B, T, h, w, F)
+            return f.reshape(B, T, -1, f.shape[-1])
+        ws = ta["window"][-1]
+        tsd = hf_swin2d_to_3d_keys(sd, ta)
+        tc = dict(ta); tc["window"] = (1, ws, ws)
+        f = swin_forward(tsd, tc, unmask_img.flatten(0, 1).unsqueeze(2), None, prefix="t.", final_norm=False)   # (B*T, 1, h, w, F)
+        return f.reshape(B, T, -1, f.shape[-1])
+
+
+def feature_loss(sd, cfg, out_mvm, unmask_img, mvm_mask, target=None):
+    """calc_mvm_loss '3d_feature' / '2d_feature' branches main_pretrain.py:508-545 (eval mode: fc_mvm's Dropout is identity)"""
+    B, T, Cin, H, W = unmask_img.shape
+    ps = cfg["size_patch"]
+    h, w = H // ps, W // ps
+    _, L, C = out_mvm.shape
+    l = L // T
+    x = torch.cat([out_mvm[:, l * t + 1:l * (t + 1), :] for t in range(T)], dim=1)
+    x = F.relu(F.linear(x, sd["fc_mvm.1.weight"], sd["fc_mvm.1.bias"]))
+    pred = F.linear(x, sd["fc_mvm.3.weight"], sd["fc_mvm.3.bias"]).reshape(B, T, h * w, -1)
+    if target is None:
+        target = teacher_features(sd, cfg, unmask_img)
+    m = F.max_pool2d(mvm_mask.reshape(B * T, Cin, H, W).float(), ps).sum(dim=1) / 3.0
+    m = m.view(B, T, h * w, 1)
+    ls = (pred - target).abs()
+    return (ls.float() * m).sum() / (m.sum() + 1e-5) / Cin, pred, target
+
+
 def cross_entropy_ignore(logits, target):
     """T.nn.CrossEntropyLoss(ignore_index=-1) agent.py:57 (mean over non-ignored; NaN if none)"""
     return F.cross_entropy(logits, target, ignore_index=-1)
@@ -616,6 +765,10 @@ def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
     if "vq" in cfg["mvm_target"]:                             # the step sums the terms of calc_mvm_loss (main_pretrain.py:563-564)
         lv, _, _ = vq_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("vq_tokens"))
         ls_mvm = ls_mvm + lv
+    if "3d_feature" in cfg["mvm_target"] or "2d_feature" in cfg["mvm_target"]:
+        lf, pred_f, tgt_f = feature_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("feature_target"))
+        ls_mvm = ls_mvm + lf
+        out["pred_feature"], out["feature_target"] = pred_f, tgt_f
     return dict(mtm=ls_mtm, vtm=ls_vtm, mvm=ls_mvm, total=ls_mtm + ls_vtm + ls_mvm, out=out)
 
 

@@ -214,6 +214,39 @@ __global__ __launch_bounds__(256) void pixel_l1_kernel(const u16* __restrict__ p
   if (threadIdx.x == 0) atomicAdd(loss_sum, acc * coef);
 }
 
+// ---------------------------------------------------------------- MVM feature-target masked L1 (2d_feature / 3d_feature)
+// loss += sum_rows cov[row] * sum_c |pred - target| * coef,  dpred = cov[row] * sign(pred - target) * coef,
+// coef = inv_div / (mask_sum + 1e-5)   (main_pretrain.py:523-525 / :542-544: the mask sum counts covered PATCHES, inv_div = 1/3)
+__global__ __launch_bounds__(256) void feature_l1_kernel(const u16* __restrict__ pred, const u16* __restrict__ tgt, const uint8_t* __restrict__ cov,
+                                                         const float* __restrict__ mask_sum, float inv_div, float* __restrict__ loss_sum,
+                                                         u16* __restrict__ dpred, int C) {
+  __shared__ float sh[4];
+  const long row = blockIdx.x;
+  u16* drow = dpred + row * C;
+  if (!cov[row]) {
+    for (int k = threadIdx.x * 8; k < C; k += 256 * 8) *reinterpret_cast<uint4*>(drow + k) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const float coef = inv_div / (*mask_sum + 1e-5f);
+  float acc = 0.f;
+  for (int k = threadIdx.x * 8; k < C; k += 256 * 8) {
+    const uint4 p4 = *reinterpret_cast<const uint4*>(pred + row * C + k);
+    const uint4 t4 = *reinterpret_cast<const uint4*>(tgt + row * C + k);
+    const uint32_t pw[4] = {p4.x, p4.y, p4.z, p4.w}, tw[4] = {t4.x, t4.y, t4.z, t4.w};
+    uint32_t gw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = __uint_as_float(pw[e] << 16) - __uint_as_float(tw[e] << 16);
+      const float d1 = __uint_as_float(pw[e] & 0xffff0000u) - __uint_as_float(tw[e] & 0xffff0000u);
+      acc += fabsf(d0) + fabsf(d1);
+      gw[e] = pack_bf2(d0 > 0.f ? coef : (d0 < 0.f ? -coef : 0.f), d1 > 0.f ? coef : (d1 < 0.f ? -coef : 0.f));
+    }
+    *reinterpret_cast<uint4*>(drow + k) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, acc * coef);
+}
+
 // ---------------------------------------------------------------- VTM head tail
 __global__ void rowdot_kernel(const u16* __restrict__ hid, int M, int K, const float* __restrict__ w, const float* __restrict__ b,
                               float inv_temp, float* __restrict__ out) {
@@ -575,6 +608,14 @@ extern "C" int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* 
   if (!pred || !img || !cov || !mask_sum || !loss_sum || !dpred || (ps & 3)) return VMVM_EINVAL;
   hipLaunchKernelGGL(pixel_l1_kernel, dim3(B * T * h * w), dim3(256), 0, ST, reinterpret_cast<const u16*>(pred), img, cov, mask_sum, loss_sum,
                      reinterpret_cast<u16*>(dpred), B, T, h, w, ps);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_feature_l1(const void* pred, const void* target, const uint8_t* cov, const float* mask_sum, float inv_div, float* loss_sum,
+                               void* dpred, int32_t M, int32_t C, void* stream) {
+  if (!pred || !target || !cov || !mask_sum || !loss_sum || !dpred || M <= 0 || C <= 0 || (C & 7)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(feature_l1_kernel, dim3(M), dim3(256), 0, ST, reinterpret_cast<const u16*>(pred), reinterpret_cast<const u16*>(target), cov,
+                     mask_sum, inv_div, loss_sum, reinterpret_cast<u16*>(dpred), C);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

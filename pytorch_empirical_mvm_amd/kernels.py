@@ -221,6 +221,14 @@ def pixel_l1(pred, img, cov, mask_sum, loss_sum, B, T, h, w, ps):
     return dpred
 
 
+def feature_l1(pred, target, cov, mask_sum, loss_sum, inv_div=1.0 / 3.0):
+    dpred = torch.empty_like(pred)
+    M, C_ = pred.shape
+    L.check(L.load().vmvm_feature_l1(pred.data_ptr(), target.data_ptr(), cov.data_ptr(), mask_sum.data_ptr(), inv_div, loss_sum.data_ptr(),
+                                     dpred.data_ptr(), M, C_, L.stream()), "feature_l1")
+    return dpred
+
+
 def rowdot(hid, w, b, inv_temp):
     M, K = hid.shape
     out = torch.empty(M, device=hid.device, dtype=F32)

@@ -181,3 +181,28 @@ def test_vq_target_tokenizer_head_and_loss():
     np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
     for k in ("decoder_vq.0.weight", "decoder_vq.0.bias", "fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["3d_feature", "2d_feature"])
+def test_feature_targets_teacher_head_and_loss(kind):
+    """MVM feature targets -- frozen Swin-B teachers (VideoSwin-B; HF SwinModel restated on the 3-D code with D = 1)
+    + fc_mvm head + masked L1, against the reference's own VIOLET_Pretrain / calc_mvm_loss (fixtures: tools/gen_goldens.py
+    gold_feature; teacher = the real classes with closed-form weights)."""
+    d = load(f"feature{kind[:2]}.npz")
+    cfg = R.make_cfg("tiny", T=4, mvm_target=[kind])
+    sd = R.make_state_dict(cfg)
+    params = {k: (v.requires_grad_(True) if not k.startswith("feature_model.") else v) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 2)
+    batch = R.default_masking(cfg, img, txt, mask, seed=5)
+    tgt = R.teacher_features(sd, cfg, batch["unmask_img"])
+    check_samp(d, "target", tgt, rtol=2e-3, atol=2e-4)
+    ls = R.pretrain_losses(params, cfg, batch, negatives=d["neg"])
+    np.testing.assert_allclose(float(ls["mtm"]), float(d["ls_mtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["vtm"]), float(d["ls_vtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["mvm"]), float(d["ls_mvm"]), rtol=1e-4)
+    ls["total"].backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for k, p in params.items() if not k.startswith("feature_model.") and p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
+    for k in ("fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-5)

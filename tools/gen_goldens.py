@@ -341,6 +341,95 @@ def gold_vq(size="tiny", T=4, B=2, S=224):
           "min margin", float(d["min_margin"]))
 
 
+def gold_feature(kind, size="tiny", T=4, B=2, S=224):
+    """MVM '3d_feature' / '2d_feature' targets -- frozen Swin-B teachers (VideoSwin via get_vidswin_model, HF
+    SwinModel via get_swin_model; no checkpoints offline, so both get the oracle's closed-form weights) + fc_mvm head + masked L1
+    through the REFERENCE's VIOLET_Pretrain / calc_mvm_loss."""
+    import main_pretrain as mp
+    import transformers as tr
+    from visbackbone import video_swin as vs
+    cfg = R.make_cfg(size, T=T, img=S, mvm_target=[kind])
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target=kind)
+    args.update(size_img=S, imagenet=22)
+    vs.load_checkpoint_3d = lambda path: {}            # no Kinetics checkpoint here: the teacher keeps init weights until loaded below
+    _orig = getattr(tr.SwinModel, "from_pretrained")
+    tr.SwinModel.from_pretrained = classmethod(lambda cls, name, *a, **k: tr.SwinModel(tr.SwinConfig(
+        image_size=224, patch_size=4, num_channels=3, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7)))
+    try:
+        model = mp.VIOLET_Pretrain(args, None).eval()
+    finally:
+        tr.SwinModel.from_pretrained = _orig
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    enc_t = model.trsfr
+    def go_cross(feat_img, mask_img, feat_txt, mask_txt, **kw):
+        feat = torch.cat([feat_img, feat_txt], dim=1)
+        mask = mask_ext(model.get_attn_mask(mask_img, mask_txt))
+        o = enc_t(feat, attention_mask=mask)
+        return (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), ()
+    model.go_cross = go_cross
+    own = model.state_dict()
+    if kind == "2d_feature":
+        # API drift (installed transformers 5.15 vs the README's 4.26): SwinModel's attention / MLP sub-modules were renamed; the
+        # oracle and the build keep the 4.26 names the reference's checkpoints carry, this shim renames for the installed class
+        def to_515(k):
+            if not k.startswith("feature_model."):
+                return k
+            for a, b in ((".attention.self.query.", ".attention.q_proj."), (".attention.self.key.", ".attention.k_proj."),
+                         (".attention.self.value.", ".attention.v_proj."), (".attention.output.dense.", ".attention.o_proj."),
+                         (".attention.self.relative_position_bias_table", ".attention.relative_position_bias.relative_position_bias_table"),
+                         (".intermediate.dense.", ".mlp.fc1."), (".output.dense.", ".mlp.fc2.")):
+                k = k.replace(a, b)
+            return k
+        sd = {to_515(k): v for k, v in sd.items()}
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    extra = [k for k in own if k.startswith("feature_model.") and k not in sd and "relative_position_index" not in k]
+    assert not extra, extra[:8]
+    for k in sd:
+        assert tuple(own[k].shape) == tuple(sd[k].shape), (k, own[k].shape, sd[k].shape)
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    calls = {"i": 0}
+    def fake_perm(lst):
+        i = calls["i"]; calls["i"] += 1
+        rest = [j for j in lst if j not in list(neg[i])]
+        return np.array(list(neg[i]) + rest)
+    mp.np.random.permutation = fake_perm
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    batch = dict(mb)
+    out = model(batch)
+    ls_mtm = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    ls_vtm = agent.loss_func(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = agent.calc_mvm_loss(batch, out["out_mvm"], is_train=True)
+    (ls_mtm + ls_vtm + ls_mvm).backward()
+    with torch.no_grad():
+        if kind == "3d_feature":
+            tgt = model.feature_model(batch["unmask_img"].transpose(1, 2)).transpose(1, 2).permute(0, 1, 3, 4, 2).reshape(B, T, 49, -1)
+        else:
+            f = model.feature_model(batch["unmask_img"].flatten(0, 1), output_hidden_states=True)["hidden_states"][-1]
+            tgt = f.permute(0, 2, 1).reshape(B, T, -1, 49).permute(0, 1, 3, 2)
+    d = dict(ls_mtm=np.array(float(ls_mtm)), ls_vtm=np.array(float(ls_vtm)), ls_mvm=np.array(float(ls_mvm)), neg=neg)
+    put(d, "target", tgt, 512)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            assert k.startswith("feature_model.") or k == "enc_img.emb_odr", k
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("fc_mvm"):
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, f"feature{kind[:2]}.npz"), **d)
+    print(kind, "ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5, "target", tuple(tgt.shape), float(tgt.abs().mean()))
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -414,6 +503,11 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--feature-only" in sys.argv:
+        if "--2d" not in sys.argv:
+            gold_feature("3d_feature")
+        gold_feature("2d_feature")
+        sys.exit(0)
     if "--vq-only" not in sys.argv:
         gold_helpers(vs)
         gold_reduced_swin(vs)
@@ -422,3 +516,5 @@ if __name__ == "__main__":
         gold_masking(mp, agent)
         gold_optimizer()
     gold_vq()
+    gold_feature("3d_feature")
+    gold_feature("2d_feature")
