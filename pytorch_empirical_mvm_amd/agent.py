@@ -174,6 +174,8 @@ class Agent_Pretrain:
             r = {"mtm": ac_mtm, "vtm": ac_vtm}
             if "pixel" in self.args.mvm_target:
                 r["mvm_pixel"] = float(losses["mvm_pixel"].item())
+            if "3d_feature" in self.args.mvm_target or "2d_feature" in self.args.mvm_target:
+                r["mvm_3d_feature"] = float(losses["mvm_feature"].item())      # the reference reports both under this key (:526,:545)
             if "vq" in self.args.mvm_target:           # accuracy over covered positions (main_pretrain.py:503-506)
                 r["mvm_vq"] = float(outs["vq_acc"].item()) if "vq_acc" in outs else -1
             return r

@@ -67,6 +67,8 @@ def model_cfg(args):
                max_size_frame=args.max_size_frame, max_size_patch=args.max_size_patch, size_patch=args.size_patch,
                temp=args.temp, mvm_target=list(args.mvm_target), size_vq=args.get("size_vq", 8192),
                dvae_hid=args.get("dvae_hid", 256), dvae_vocab=args.get("dvae_vocab", 8192))
+    # frozen feature teachers of the '3d_feature' / '2d_feature' targets are always the "base" size (main_pretrain.py:157,168)
+    cfg["teacher_arch"] = dict(args["teacher_arch_override"]) if args.get("teacher_arch_override") else dict(ARCH["base"])
     return cfg
 
 
@@ -157,6 +159,40 @@ def param_shapes(cfg):
         s["fc_mvm.1.bias"] = (2 * c,)
         s["fc_mvm.3.weight"] = (cfg.get("size_vq", 8192), 2 * c)
         s["fc_mvm.3.bias"] = (cfg.get("size_vq", 8192),)
+    if "3d_feature" in cfg["mvm_target"] or "2d_feature" in cfg["mvm_target"]:      # main_pretrain.py:153-174
+        feat = cfg["teacher_arch"]["embed_dim"] * 8
+        s["fc_mvm.1.weight"] = (2 * H, H)
+        s["fc_mvm.1.bias"] = (2 * H,)
+        s["fc_mvm.3.weight"] = (feat, 2 * H)
+        s["fc_mvm.3.bias"] = (feat,)
+    return s
+
+
+def swin_param_shapes(arch, win, prefix="enc_img.swin."):
+    """{key: shape} of one SwinTransformer3D (video_swin.py:410-468) under `prefix` (the frozen feature teachers)."""
+    E, depths, heads = arch["embed_dim"], arch["depths"], arch["num_heads"]
+    s = {}
+    s[prefix + "patch_embed.proj.weight"] = (E, 3) + PATCH
+    s[prefix + "patch_embed.proj.bias"] = (E,)
+    s[prefix + "patch_embed.norm.weight"] = (E,)
+    s[prefix + "patch_embed.norm.bias"] = (E,)
+    ntab = (2 * win[0] - 1) * (2 * win[1] - 1) * (2 * win[2] - 1)
+    for i, (d, nh) in enumerate(zip(depths, heads)):
+        C = E * 2 ** i
+        for b in range(d):
+            p = prefix + f"layers.{i}.blocks.{b}."
+            for n, shp in (("norm1.weight", (C,)), ("norm1.bias", (C,)), ("attn.relative_position_bias_table", (ntab, nh)),
+                           ("attn.qkv.weight", (3 * C, C)), ("attn.qkv.bias", (3 * C,)), ("attn.proj.weight", (C, C)), ("attn.proj.bias", (C,)),
+                           ("norm2.weight", (C,)), ("norm2.bias", (C,)), ("mlp.fc1.weight", (4 * C, C)), ("mlp.fc1.bias", (4 * C,)),
+                           ("mlp.fc2.weight", (C, 4 * C)), ("mlp.fc2.bias", (C,))):
+                s[p + n] = shp
+        if i < len(depths) - 1:
+            p = prefix + f"layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,)
+            s[p + "norm.bias"] = (4 * C,)
+    s[prefix + "norm.weight"] = (E * 8,)
+    s[prefix + "norm.bias"] = (E * 8,)
     return s
 
 

@@ -31,8 +31,9 @@ class ParamStore:
     PAD = 8
     TAIL = 1 << 16
 
-    def __init__(self, shapes, device):
+    def __init__(self, shapes, device, frozen=False):
         self.device = device
+        self.frozen = frozen                # frozen teacher arena: parameters + bf16 copy only (no grad / Adam state / W^T copies)
         order = sorted(shapes.keys(), key=lambda n: (4 if n in self.FROZEN else CFG.param_group(n)))   # stable
         self.index = OrderedDict()
         off = 0
@@ -53,11 +54,11 @@ class ParamStore:
         self.segments = [(bounds[i], bounds[i + 1]) for i in range(5)]       # 4 optimizer groups + frozen
         self.n_trainable = bounds[4]
         self.flat = torch.zeros(off + self.TAIL, device=device, dtype=F32)
-        self.grad = torch.zeros(off + self.TAIL, device=device, dtype=F32)
-        self.m = torch.zeros(off, device=device, dtype=F32)
-        self.v = torch.zeros(off, device=device, dtype=F32)
+        self.grad = None if frozen else torch.zeros(off + self.TAIL, device=device, dtype=F32)
+        self.m = None if frozen else torch.zeros(off, device=device, dtype=F32)
+        self.v = None if frozen else torch.zeros(off, device=device, dtype=F32)
         self.shadow = torch.zeros(off + self.TAIL, device=device, dtype=BF16)
-        self.shadowT = torch.zeros(off + self.TAIL, device=device, dtype=BF16) if torch.device(device).type == "cuda" else None
+        self.shadowT = torch.zeros(off + self.TAIL, device=device, dtype=BF16) if (torch.device(device).type == "cuda" and not frozen) else None
         self.tmap, self.ttable = {}, None
         self.swin_tail = self._swin_tail_ranges()
 
@@ -136,7 +137,7 @@ class ParamStore:
         self.ttable = torch.tensor(ents, dtype=torch.int32, device=self.device).contiguous() if ents else None
 
     def refresh_transposed(self):
-        if self.device.type != "cuda":
+        if self.device.type != "cuda" or self.frozen:
             return
         if self.ttable is None and not self.tmap:
             self.build_transpose_table()
@@ -189,6 +190,7 @@ class VioletEngine:
         self._idx_cache = {}
         self.tape = []
         self.teacher = None                 # frozen dVAE tokenizer (MVM 'vq' target), set by the model
+        self.feature_teacher = None         # frozen Swin teacher (MVM '3d_feature' / '2d_feature' targets), set by the model
         self.on_swin_tail_ready = None      # data-parallel hook (dist.GradReducer.reduce_swin_tail)
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
         if self.device.type == "cuda":
@@ -322,8 +324,9 @@ class VioletEngine:
         self.tape.append(bwd)
         return out, (D2, H2, W2)
 
-    def swin_forward(self, img, cov, dp_all):
-        """img f32 (B,T,3,H,W) -> V([B*T*h*w, 8E]) channels-last tokens (after the final norm)."""
+    def swin_forward(self, img, cov, dp_all, final_norm=True):
+        """img f32 (B,T,3,H,W) -> V([B*T*h*w, 8E]) channels-last tokens (after the final norm; `final_norm=False`: the last
+        stage's output, what HF SwinModel reports as hidden_states[-1])."""
         cfg, S = self.cfg, self.store
         B, T, _, H, W = img.shape
         xv = self._patch_embed(img, cov)
@@ -342,6 +345,8 @@ class VioletEngine:
             if i < len(cfg["depths"]) - 1:
                 xv, dims = self._patch_merge(xv, B, dims, C, f"enc_img.swin.layers.{i}.downsample.")
                 C *= 2
+        if not final_norm:
+            return xv, dims, C
         x = xv.t
         gam, bet = S.p("enc_img.swin.norm.weight"), S.p("enc_img.swin.norm.bias")
         y, mean, rstd = K.layernorm_fwd(x, gam, bet, 1e-5)
@@ -477,6 +482,9 @@ class VioletEngine:
         if train and dp_all is None:
             dp_all = self.sample_drop_path(B)
         train = train if dropout is None else bool(dropout)      # dropout sites follow `train` unless overridden
+        feat_target = batch.get("feature_target")
+        if feat_target is None and self.feature_teacher is not None:
+            feat_target = self.feature_teacher.features(img)     # frozen Swin teacher first: its activations are gone before the student's pile up
         pool, Lv, hw = self.encode(img, cov, txt, dp_all, train)
         Lq = Lv + X
         # ---- sequence assembly indices (pass 1: (img_i, txt_i); pass 2: (img_i, txt_i), (img_i, txt_neg) ...)
@@ -498,7 +506,7 @@ class VioletEngine:
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
         out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
-        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq")}
+        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature")}
         outs = {}
 
         # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560)
@@ -581,7 +589,22 @@ class VioletEngine:
             if want_outputs:
                 outs["vq_logits"], outs["vq_targets"] = lg_q, tgt_q
                 outs["vq_acc"] = (lg_q.argmax(-1) == tgt_q).float().mean()
-        losses["mvm"] = losses["mvm_pixel"] + losses["mvm_vq"]
+        # ---- MVM feature head (main_pretrain.py:153-174,508-545): fc_mvm (Dropout, Linear H -> 2H, ReLU, Linear 2H -> F) on every
+        # non-cls visual token; targets = the frozen Swin teacher's features of the UN-masked clip; L1 over covered patches
+        use_feat = "3d_feature" in targets or "2d_feature" in targets
+        if use_feat:
+            tgt_f = feat_target                                                          # bf16 [B*T*hw, F], no grad
+            r_f = r_p if use_pix else K.gather_rows(out1.t, vis_rows, B * T * hw)
+            p_f = 0.1 if train else 0.0
+            off_f = self._next_offset(r_f.numel())
+            r_fd = K.dropout(r_f, p_f, self.seed, off_f) if p_f > 0 else r_f
+            h_f = K.gemm(r_fd, S.b("fc_mvm.1.weight"), bias=S.p("fc_mvm.1.bias"), act=2)
+            pred_f = K.gemm(h_f, S.b("fc_mvm.3.weight"), bias=S.p("fc_mvm.3.bias"))
+            cov_sum = cov.to(F32).sum().view(1)
+            dpred_f = K.feature_l1(pred_f, tgt_f, cov.reshape(-1), cov_sum, losses["mvm_feature"])
+            if want_outputs:
+                outs["pred_feature"], outs["feature_target"] = pred_f, tgt_f
+        losses["mvm"] = losses["mvm_pixel"] + losses["mvm_vq"] + losses["mvm_feature"]
         if want_outputs:
             outs["out_mvm"] = out1.t.view(B, Lq, Hd)[:, :Lv]
         if not backward:
@@ -590,18 +613,28 @@ class VioletEngine:
 
         # =============================== backward ===============================
         # heads -> gradients of the two encoder outputs
-        npx = B * T * hw if use_pix else 0
-        dcat = torch.empty((npx + B * X, Hd), device=dev, dtype=BF16)              # [pixel rows ; mlm rows]
+        use_vis = use_pix or use_feat
+        npx = B * T * hw if use_vis else 0
+        dcat = torch.empty((npx + B * X, Hd), device=dev, dtype=BF16)              # [visual-token rows ; mlm rows]
         if use_pix:
             self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
                              dx_kw=dict(out=dcat[:npx]), wT=S.bt("decoder_pixel.0.weight"))
+        if use_feat:
+            dh_f = self._linear_bwd(dpred_f, h_f, "fc_mvm.3.weight", "fc_mvm.3.bias", dx_kw=dict(act=4, aux=h_f))   # ReLU' folded into the dgrad
+            dr_f = self._linear_bwd(dh_f, r_fd, "fc_mvm.1.weight", "fc_mvm.1.bias")
+            if p_f > 0:
+                dr_f = K.dropout(dr_f, p_f, self.seed, off_f)
+            if use_pix:
+                K.add_bf16(dcat[:npx], dr_f, out=dcat[:npx])
+            else:
+                dcat[:npx].copy_(dr_f)
         K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
         K.gemm(dlog, tn, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
         dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
         dt_m, _ = K.layernorm_bwd(dtn, t_m, gm, mean_m, rstd_m, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
         du_m = K.gelu_bwd(dt_m, u_m)
         self._linear_bwd(du_m, r_m, pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dcat[npx:]))
-        inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X, use_pix), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows] if use_pix else [txt_rows]))
+        inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X, use_vis), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows] if use_vis else [txt_rows]))
         out1.g = K.gather_rows(dcat, inv1, B * Lq)
         if use_vq and n_mp > 0:
             dh_q = self._linear_bwd(dlg_q, h_q, "fc_mvm.3.weight", "fc_mvm.3.bias", dx_kw=dict(act=4, aux=h_q))     # ReLU' folded into the dgrad

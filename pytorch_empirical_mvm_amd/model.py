@@ -66,6 +66,14 @@ class VIOLET_Pretrain(torch.nn.Module):
             self.dalle = DalleTeacher(self.cfg["dvae_hid"], self.cfg["dvae_vocab"], device=self.engine.device, dtype=args.get("dvae_dtype"),
                                       seed=args.get("seed", 88))
             self.engine.teacher = self.dalle
+        # MVM feature targets: frozen Swin-B teacher (main_pretrain.py:153-174); its tensors load from `feature_model.*`
+        self.feature_model = None
+        for kind in ("3d_feature", "2d_feature"):
+            if kind in self.cfg["mvm_target"]:
+                from .teacher import SwinTeacher
+                self.feature_model = SwinTeacher(kind[:2], self.cfg["teacher_arch"], self.engine.device, seed=args.get("seed", 88))
+                self.feature_model.init_weights(args.get("seed", 88))
+                self.engine.feature_teacher = self.feature_model
 
     # ------------------------------------------------------------------ init / state
     @torch.no_grad()
@@ -83,8 +91,11 @@ class VIOLET_Pretrain(torch.nn.Module):
             elif last == "bias":
                 if name in ("fc.1.bias", "fc.3.bias", "decoder_pixel.0.bias", "enc_img.fc.bias", "enc_img.swin.patch_embed.proj.bias",
                             "decoder_vq.0.bias", "fc_mvm.1.bias", "fc_mvm.3.bias"):
+                    feat_head = "3d_feature" in self.cfg["mvm_target"] or "2d_feature" in self.cfg["mvm_target"]
                     fan_in = {"fc.1.bias": self.hidden_size, "fc.3.bias": 2 * self.hidden_size, "decoder_pixel.0.bias": self.hidden_size,
-                              "decoder_vq.0.bias": self.hidden_size, "fc_mvm.1.bias": self.hidden_size // 8, "fc_mvm.3.bias": self.hidden_size // 4,
+                              "decoder_vq.0.bias": self.hidden_size,
+                              "fc_mvm.1.bias": self.hidden_size if feat_head else self.hidden_size // 8,
+                              "fc_mvm.3.bias": 2 * self.hidden_size if feat_head else self.hidden_size // 4,
                               "enc_img.fc.bias": self.cfg["embed_dim"] * 8, "enc_img.swin.patch_embed.proj.bias": 96}[name]
                     b = 1.0 / math.sqrt(fan_in)
                     t.uniform_(-b, b, generator=gen)
@@ -109,6 +120,9 @@ class VIOLET_Pretrain(torch.nn.Module):
         prefix = k.get("prefix", "")
         if prefix + key in sd:                              # HF ties decoder.bias to predictions.bias (both keys are saved)
             sd[prefix + "fc_mtm.predictions.decoder.bias"] = sd[prefix + key]
+        if getattr(self, "feature_model", None) is not None:        # frozen teacher tensors travel with the checkpoint, as in the reference
+            for k_, v_ in self.feature_model.state_dict().items():
+                sd[prefix + k_] = v_
         return sd
 
     def load_state_dict(self, sd, strict=False):
@@ -120,6 +134,9 @@ class VIOLET_Pretrain(torch.nn.Module):
         self.engine.store.load_state({k: v for k, v in sd.items() if k in self.engine.store.index})
         if self.dalle is not None:
             self.dalle.load_state_dict(sd)
+        if self.feature_model is not None:
+            self.feature_model.load_state_dict(sd)
+            unexpected = [k for k in unexpected if not k.startswith("feature_model.")]
         return missing, unexpected
 
     def load_ckpt(self, ckpt):

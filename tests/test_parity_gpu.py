@@ -390,3 +390,49 @@ def test_device_masking_matches_oracle_on_the_same_draws():
     mb = agent.masking_device(img.cuda(), txt.cuda(), mask.cuda(), generator=g)
     r = agent.step(mb, is_train=True)
     assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
+
+
+@pytest.mark.parametrize("kind", ["3d_feature", "2d_feature"])
+def test_feature_targets_vs_reference_golden(kind):
+    """MVM feature targets on the HIP path.  Fixtures `feature3d.npz` / `feature2d.npz` come from the REFERENCE
+    (VIOLET_Pretrain + calc_mvm_loss with a VideoSwin-B / HF Swin-B teacher): the frozen teacher's features (bf16 kernels vs
+    fp32 reference), the fc_mvm head, the masked-L1 loss, the gradients; then the checkpoint round trip of the teacher tensors
+    and one optimizer step through the agent surface (train mode)."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, f"feature{kind[:2]}.npz"))
+    cfg = R.make_cfg("tiny", T=4, mvm_target=[kind])
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, mvm_target=[kind]))
+    sd = R.make_state_dict(cfg)
+    missing, unexpected = model.load_state_dict(sd)
+    assert not unexpected, unexpected[:5]
+    img, txt, mask = R.make_batch(cfg, 2)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    dev = "cuda"
+    tgt = model.feature_model.features(img.to(dev)).float().view(2, 4, 49, -1)
+    _check_samples(d, "target", tgt, tol=5e-2)
+    batch = dict(img=img.to(dev), cov=cov.to(dev).contiguous(), txt=mb["txt"].to(dev), mask=mask.to(dev), ans_mtm=mb["ans_mtm"].to(dev))
+    eng = model.engine
+    eng.store.grad.zero_()
+    losses, outs = eng.forward_backward(batch, negatives=d["neg"], train=False, want_outputs=True, backward=True)
+    torch.cuda.synchronize()
+    got = float(losses["mvm"].item())
+    assert abs(got - float(d["ls_mvm"])) <= 2e-2 * float(d["ls_mvm"]), (got, float(d["ls_mvm"]))
+    assert abs(float(losses["mtm"].item()) - float(d["ls_mtm"])) <= 2e-2 * float(d["ls_mtm"])
+    gn = float(eng.store.grad[:eng.store.n_trainable].double().pow(2).sum().sqrt().item())
+    assert abs(gn - float(d["grad_norm"])) <= 5e-2 * float(d["grad_norm"]), (gn, float(d["grad_norm"]))
+    # (the L1 gradient is sign(pred - target): where the two are within bf16 rounding of each other a sign may flip, so single
+    #  elements are allowed 1e-1 of the tensor scale; the cosine >= 0.995 inside _check_samples is the tight part)
+    for k in ("fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
+        _check_samples(d, "g." + k, eng.store.g(k).reshape(tuple(d[f"g.{k}.shape"])), tol=1e-1)
+    # checkpoint surface: the teacher's tensors come back under the reference's key names, bit-identical
+    out_sd = model.state_dict()
+    tkeys = [k for k in sd if k.startswith("feature_model.")]
+    assert len(tkeys) > 300
+    for k in tkeys:
+        assert torch.equal(out_sd[k].cpu(), sd[k]), k
+    agent = Agent_Pretrain(args, model)
+    masked = dict(mb); masked.update(cov=cov, unmask_img=img)
+    r = agent.step(agent.prepare_batch(masked), is_train=True)
+    assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
