@@ -120,7 +120,8 @@ def main():
     ap.add_argument("--img", type=int, default=224, help="frame size; --size large --img 384 --frames 16 is BASELINE config 5's geometry (run at bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-masking", action="store_true", help="mask the batches on the host before the timed region (the round-1 default until device-side masking existed)")
-    ap.add_argument("--mvm-target", default="pixel", help="pixel (C2/C3, the headline config) or vq (C4: frozen dVAE tokenizer, random weights)")
+    ap.add_argument("--mvm-target", default="pixel", help="pixel (C2/C3, the headline config), vq (C4: frozen dVAE tokenizer, random weights), 2d_feature (args_pretrain.json's own "
+                    "default: frozen HF Swin-B teacher) or 3d_feature (frozen VideoSwin-B teacher)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
@@ -154,7 +155,7 @@ def main():
     torch.cuda.synchronize()
     # masking INSIDE the timed step (device-side, vmvm_masking; fresh rm/bm draws every step) for the pixel target; the vq
     # target needs host-built index lists of the covered patches, so its batches are masked before the timed region
-    mask_in_step = (a.mvm_target == "pixel") and not a.host_masking
+    mask_in_step = (a.mvm_target != "vq") and not a.host_masking
     gen = torch.Generator(device=device).manual_seed(88 + rank)
 
     def one_step(i):
@@ -190,7 +191,8 @@ def main():
     headline = a.size == "base" and a.frames == 8 and a.img == 224
     window = "(8,12,12)" if (a.size == "large" and a.img == 384) else "(8,7,7)"
     if headline:
-        label = "C2" if a.mvm_target == "pixel" else "C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)"
+        label = {"pixel": "C2", "vq": "C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)"}.get(
+            a.mvm_target, f"C2 shapes with the {a.mvm_target} target (frozen Swin-B teacher on the same kernels, random weights)")
     elif a.size == "large" and a.img == 384 and a.frames == 16:
         label = "C5 geometry at bf16 (the fp8 GEMM path of config 5 is not built; streaming attention kernels)"
     else:
