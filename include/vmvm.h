@@ -210,11 +210,14 @@ int vmvm_count_valid(const int64_t* target, int32_t M, float* n_valid, void* str
 int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, int32_t V, const int64_t* target,
                        const float* n_valid, float* loss_sum, void* dlogits, int32_t ld_d, void* stream);
 
-/* MVM pixel loss (main_pretrain.py:420-432): pred bf16 [B*T*hw][3*ps*ps] (1x1-conv output, channel = c*ps*ps+dy*ps+dx,
- * PixelShuffle(ps) video order), target = unmask_img f32 (B,T,3,H,W), mask = cov u8 (B,T,h,w) patch cover.
- * loss_sum += sum |pred-img|*mask ; dpred bf16 = sign(pred-img)*mask*coef with coef = 1/((3*ps*ps*sum(cov))+1e-5)/3 */
+/* MVM pixel / HOG map loss (main_pretrain.py:420-432 pixel, :453-468 hog): pred bf16 [B*T*hw][channels*ps*ps] (1x1-conv output,
+ * channel = c*ps*ps+dy*ps+dx, PixelShuffle(ps) video order); target f32 (B,T,channels,H,W) = the un-masked normalised frames
+ * (channels 3) or the data loader's HOG maps (channels 1); mask = cov u8 (B,T,h,w) patch cover expanded x ps.
+ * coef = inv_div / (mask_sum + 1e-5), mask_sum = device f32 (pixel: 3*ps*ps*sum(cov), inv_div 1/3; hog: ps*ps*sum(cov), inv_div 1);
+ * loss_sum (ACCUMULATED) += coef * sum |pred-target|*mask ; dpred bf16 = sign(pred-target)*mask*coef. */
 int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum,
-                  float* loss_sum, void* dpred, int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, void* stream);
+                  float* loss_sum, void* dpred, int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps,
+                  int32_t channels, float inv_div, void* stream);
 
 /* MVM feature targets (calc_mvm_loss '3d_feature' main_pretrain.py:508-526 / '2d_feature' :527-545): masked L1 between the
  * fc_mvm prediction and the frozen Swin teacher's features, bf16 [M][C] each, row = (b, t, patch); cov u8 [M] is the patch cover

@@ -139,6 +139,9 @@ def param_shapes(cfg):
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    if "hog" in cfg["mvm_target"]:          # main_pretrain.py:180-183
+        s["decoder_hog.0.weight"] = (cfg["size_patch"] ** 2, H, 1, 1)
+        s["decoder_hog.0.bias"] = (cfg["size_patch"] ** 2,)
     if "vq" in cfg["mvm_target"]:
         # main_pretrain.py:194-209 (on-the-fly dVAE branch): Conv2d 1x1 H -> 2H, PixelShuffle(32/8), Dropout, Linear, ReLU, Linear
         up = cfg["size_patch"] // 8
@@ -284,7 +287,7 @@ def closed_form(key, shape, dtype=torch.float32):
     elif key.startswith("dalle.") and key.endswith(".b"):
         v = 0.05 * u                                           # (zeros in the reference; non-zero here so the bias path is exercised)
     elif "patch_embed.proj.weight" in key or key.startswith("decoder_pixel") or key.startswith("fc.") or key.startswith("decoder_vq") \
-            or key.startswith("fc_mvm"):
+            or key.startswith("fc_mvm") or key.startswith("decoder_hog"):
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else n
         v = u / math.sqrt(fan_in)
     else:
@@ -678,6 +681,28 @@ def vq_loss(sd, cfg, out_mvm, unmask_img, mvm_mask, tokens=None):
     return cross_entropy_ignore(lg.flatten(0, 1), ans.flatten()), lg, ans
 
 
+def make_hog(cfg, B, dtype=torch.float32):
+    """Closed-form stand-in for the data loader's HOG maps (dataset.py:197-206 -> batch["hog"], (B,T,H,W), non-negative)."""
+    T, S = cfg["T"], cfg["img"]
+    i = torch.arange(B * T * S * S, dtype=torch.float64)
+    return (0.5 * torch.sin(i * 0.0173).abs() * (1.0 + torch.cos(i * 0.00031))).reshape(B, T, S, S).to(dtype)
+
+
+def hog_loss(sd, cfg, out_mvm, hog, mvm_mask):
+    """calc_mvm_loss 'hog' branch main_pretrain.py:453-468"""
+    B, T, H, W = hog.shape
+    ps = cfg["size_patch"]
+    h, w = H // ps, W // ps
+    _, L, C = out_mvm.shape
+    l = L // T
+    x = torch.cat([out_mvm[:, l * t + 1:l * (t + 1), :] for t in range(T)], dim=1)
+    x = x.permute(0, 2, 1).reshape(B, C, T, h, w).permute(0, 2, 1, 3, 4).reshape(B * T, C, h, w)
+    x = F.pixel_shuffle(F.conv2d(x, sd["decoder_hog.0.weight"], sd["decoder_hog.0.bias"]), ps).view(B, T, H, W)
+    ls = (x - hog).abs()
+    m = (mvm_mask.sum(dim=2) > 0)
+    return (ls.float() * m.float()).sum() / (m.float().sum() + 1e-5)
+
+
 # ----------------------------------------------------------------------------
 # MVM feature targets (SURVEY 8f.3): frozen Swin teachers + fc_mvm head + masked L1
 # ----------------------------------------------------------------------------
@@ -765,6 +790,8 @@ def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
     if "vq" in cfg["mvm_target"]:                             # the step sums the terms of calc_mvm_loss (main_pretrain.py:563-564)
         lv, _, _ = vq_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("vq_tokens"))
         ls_mvm = ls_mvm + lv
+    if "hog" in cfg["mvm_target"]:
+        ls_mvm = ls_mvm + hog_loss(sd, cfg, out["out_mvm"], batch["hog"], batch["mvm_mask"])
     if "3d_feature" in cfg["mvm_target"] or "2d_feature" in cfg["mvm_target"]:
         lf, pred_f, tgt_f = feature_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("feature_target"))
         ls_mvm = ls_mvm + lf

@@ -154,7 +154,7 @@ class Agent_Pretrain:
         b = dict(img=src_img.to(eng.device, torch.float32).contiguous(), cov=batch["cov"].to(eng.device).contiguous(),
                  txt=batch["txt"].to(eng.device).contiguous(), mask=batch["mask"].to(eng.device).contiguous(),
                  ans_mtm=batch["ans_mtm"].to(eng.device).contiguous())
-        for k in ("vq_patch_rows", "vq_tok_index", "vq_tokens"):
+        for k in ("vq_patch_rows", "vq_tok_index", "vq_tokens", "hog"):
             if k in batch and batch[k] is not None:
                 b[k] = batch[k].to(eng.device).contiguous()
         if is_train:
@@ -174,6 +174,8 @@ class Agent_Pretrain:
             r = {"mtm": ac_mtm, "vtm": ac_vtm}
             if "pixel" in self.args.mvm_target:
                 r["mvm_pixel"] = float(losses["mvm_pixel"].item())
+            if "hog" in self.args.mvm_target:
+                r["mvm_hog"] = float(losses["mvm_hog"].item())
             if "3d_feature" in self.args.mvm_target or "2d_feature" in self.args.mvm_target:
                 r["mvm_3d_feature"] = float(losses["mvm_feature"].item())      # the reference reports both under this key (:526,:545)
             if "vq" in self.args.mvm_target:           # accuracy over covered positions (main_pretrain.py:503-506)
@@ -188,6 +190,8 @@ class Agent_Pretrain:
         ret = {}
         for batch in dl:
             masked = self.masking(batch["img"], batch["txt"], batch["mask"], batch.get("vq"))
+            if batch.get("hog") is not None:
+                masked["hog"] = batch["hog"]
             r = self.step(self.prepare_batch(masked), is_train)
             for k, v in r.items():
                 ret.setdefault(k, []).append(v)

@@ -150,6 +150,9 @@ def param_shapes(cfg):
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
+    if "hog" in cfg["mvm_target"]:         # main_pretrain.py:180-183
+        s["decoder_hog.0.weight"] = (cfg["size_patch"] ** 2, H, 1, 1)
+        s["decoder_hog.0.bias"] = (cfg["size_patch"] ** 2,)
     if "vq" in cfg["mvm_target"]:          # main_pretrain.py:194-209 (on-the-fly tokenizer branch)
         up = cfg["size_patch"] // 8
         c = 2 * H // (up * up)

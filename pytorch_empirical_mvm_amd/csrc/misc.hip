@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 // ---------------------------------------------------------------- MVM pixel masked L1
 __global__ __launch_bounds__(256) void pixel_l1_kernel(const u16* __restrict__ pred, const float* __restrict__ img, const uint8_t* __restrict__ cov,
                                                        const float* __restrict__ mask_sum, float* __restrict__ loss_sum, u16* __restrict__ dpred,
-                                                       int B, int T, int h, int w, int ps) {
+                                                       int B, int T, int h, int w, int ps, int nch, float inv_div) {
   __shared__ float sh[4];
   const long row = blockIdx.x;                 // (b*T+t)*h*w + i*w + j
-  const int hw = h * w, C3 = 3 * ps * ps;
+  const int hw = h * w, C3 = nch * ps * ps;
   const int ij = (int)(row % hw);
   const long bt = row / hw;
   const int i = ij / w, j = ij % w;
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void pixel_l1_kernel(const u16* __restrict__ p
     return;
   }
   const int H = h * ps, W = w * ps;
-  const float coef = 1.0f / (*mask_sum + 1e-5f) / 3.0f;
+  const float coef = inv_div / (*mask_sum + 1e-5f);
   float acc = 0.f;
   for (int k = threadIdx.x * 4; k < C3; k += 256 * 4) {
     const int c = k / (ps * ps), rem = k - c * ps * ps, dy = rem / ps, dx = rem - dy * ps;
-    const float4 t4 = *reinterpret_cast<const float4*>(img + ((bt * 3 + c) * H + (i * ps + dy)) * (long)W + j * ps + dx);
+    const float4 t4 = *reinterpret_cast<const float4*>(img + ((bt * nch + c) * H + (i * ps + dy)) * (long)W + j * ps + dx);
     const uint2 p2 = *reinterpret_cast<const uint2*>(pred + row * C3 + k);
     const float pv[4] = {__uint_as_float(p2.x << 16), __uint_as_float(p2.x & 0xffff0000u), __uint_as_float(p2.y << 16), __uint_as_float(p2.y & 0xffff0000u)};
     const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
@@ -604,10 +604,10 @@ extern "C" int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, in
   return VMVM_OK;
 }
 extern "C" int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum, float* loss_sum, void* dpred,
-                             int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, void* stream) {
-  if (!pred || !img || !cov || !mask_sum || !loss_sum || !dpred || (ps & 3)) return VMVM_EINVAL;
+                             int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, int32_t channels, float inv_div, void* stream) {
+  if (!pred || !img || !cov || !mask_sum || !loss_sum || !dpred || (ps & 3) || channels <= 0 || ((channels * ps * ps) & 7)) return VMVM_EINVAL;
   hipLaunchKernelGGL(pixel_l1_kernel, dim3(B * T * h * w), dim3(256), 0, ST, reinterpret_cast<const u16*>(pred), img, cov, mask_sum, loss_sum,
-                     reinterpret_cast<u16*>(dpred), B, T, h, w, ps);
+                     reinterpret_cast<u16*>(dpred), B, T, h, w, ps, channels, inv_div);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -506,7 +506,7 @@ class VioletEngine:
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
         out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
-        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature")}
+        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature", "mvm_hog")}
         outs = {}
 
         # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560)
@@ -546,11 +546,20 @@ class VioletEngine:
         ps = cfg["size_patch"]
         h_, w_ = H // ps, W // ps
         targets = cfg["mvm_target"]
-        use_pix, use_vq = "pixel" in targets, "vq" in targets
+        use_pix, use_vq, use_hog = "pixel" in targets, "vq" in targets, "hog" in targets
         vis_rows = self._cached(("vis_rows", B, T, hw, Lq), lambda: _dev_i32(
             np.concatenate([i * Lq + t * (1 + hw) + 1 + np.arange(hw) for i in range(B) for t in range(T)]), dev))
-        if use_pix:
+        if use_pix or use_hog:
             r_p = K.gather_rows(out1.t, vis_rows, B * T * hw)
+        if use_hog:
+            # MVM HOG head (main_pretrain.py:180-183,453-468): 1x1 conv H -> ps*ps + PixelShuffle(ps) -> one map per frame; L1 against
+            # the data loader's HOG maps batch["hog"] (B,T,H,W) over pixels of covered patches, / (mask.sum() + 1e-5)
+            Whog = S.b("decoder_hog.0.weight", (ps * ps, Hd))
+            pred_h = K.gemm(r_p, Whog, bias=S.p("decoder_hog.0.bias"))
+            msum_h = (cov.to(F32).sum() * float(ps * ps)).view(1)
+            dpred_h = K.pixel_l1(pred_h, batch["hog"].to(F32).contiguous(), cov.reshape(-1), msum_h, losses["mvm_hog"], B, T, h_, w_, ps,
+                                 channels=1, inv_div=1.0)
+        if use_pix:
             Wpix = S.b("decoder_pixel.0.weight", (3 * ps * ps, Hd))
             pred = K.gemm(r_p, Wpix, bias=S.p("decoder_pixel.0.bias"))
             mask_sum = (cov.to(F32).sum() * float(3 * ps * ps)).view(1)
@@ -594,7 +603,7 @@ class VioletEngine:
         use_feat = "3d_feature" in targets or "2d_feature" in targets
         if use_feat:
             tgt_f = feat_target                                                          # bf16 [B*T*hw, F], no grad
-            r_f = r_p if use_pix else K.gather_rows(out1.t, vis_rows, B * T * hw)
+            r_f = r_p if (use_pix or use_hog) else K.gather_rows(out1.t, vis_rows, B * T * hw)
             p_f = 0.1 if train else 0.0
             off_f = self._next_offset(r_f.numel())
             r_fd = K.dropout(r_f, p_f, self.seed, off_f) if p_f > 0 else r_f
@@ -604,7 +613,7 @@ class VioletEngine:
             dpred_f = K.feature_l1(pred_f, tgt_f, cov.reshape(-1), cov_sum, losses["mvm_feature"])
             if want_outputs:
                 outs["pred_feature"], outs["feature_target"] = pred_f, tgt_f
-        losses["mvm"] = losses["mvm_pixel"] + losses["mvm_vq"] + losses["mvm_feature"]
+        losses["mvm"] = losses["mvm_pixel"] + losses["mvm_vq"] + losses["mvm_feature"] + losses["mvm_hog"]
         if want_outputs:
             outs["out_mvm"] = out1.t.view(B, Lq, Hd)[:, :Lv]
         if not backward:
@@ -613,18 +622,26 @@ class VioletEngine:
 
         # =============================== backward ===============================
         # heads -> gradients of the two encoder outputs
-        use_vis = use_pix or use_feat
+        use_vis = use_pix or use_feat or use_hog
         npx = B * T * hw if use_vis else 0
         dcat = torch.empty((npx + B * X, Hd), device=dev, dtype=BF16)              # [visual-token rows ; mlm rows]
+        vis_filled = False
         if use_pix:
             self._linear_bwd(dpred, r_p, None, None, w=Wpix, gw=S.g("decoder_pixel.0.weight", (3 * ps * ps, Hd)), gb=S.g("decoder_pixel.0.bias"),
                              dx_kw=dict(out=dcat[:npx]), wT=S.bt("decoder_pixel.0.weight"))
+            vis_filled = True
+        if use_hog:
+            dr_h = self._linear_bwd(dpred_h, r_p, None, None, w=Whog, gw=S.g("decoder_hog.0.weight", (ps * ps, Hd)), gb=S.g("decoder_hog.0.bias"),
+                                    dx_kw=None if vis_filled else dict(out=dcat[:npx]), wT=S.bt("decoder_hog.0.weight"))
+            if vis_filled:
+                K.add_bf16(dcat[:npx], dr_h, out=dcat[:npx])
+            vis_filled = True
         if use_feat:
             dh_f = self._linear_bwd(dpred_f, h_f, "fc_mvm.3.weight", "fc_mvm.3.bias", dx_kw=dict(act=4, aux=h_f))   # ReLU' folded into the dgrad
             dr_f = self._linear_bwd(dh_f, r_fd, "fc_mvm.1.weight", "fc_mvm.1.bias")
             if p_f > 0:
                 dr_f = K.dropout(dr_f, p_f, self.seed, off_f)
-            if use_pix:
+            if vis_filled:
                 K.add_bf16(dcat[:npx], dr_f, out=dcat[:npx])
             else:
                 dcat[:npx].copy_(dr_f)

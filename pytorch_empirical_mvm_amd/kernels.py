@@ -214,10 +214,10 @@ def cross_entropy(logits, V, target, loss_sum, want_grad=True, ld_d=None):
     return dlog
 
 
-def pixel_l1(pred, img, cov, mask_sum, loss_sum, B, T, h, w, ps):
+def pixel_l1(pred, img, cov, mask_sum, loss_sum, B, T, h, w, ps, channels=3, inv_div=1.0 / 3.0):
     dpred = torch.empty_like(pred)
     L.check(L.load().vmvm_pixel_l1(pred.data_ptr(), img.data_ptr(), cov.data_ptr(), mask_sum.data_ptr(), loss_sum.data_ptr(),
-                                   dpred.data_ptr(), B, T, h, w, ps, L.stream()), "pixel_l1")
+                                   dpred.data_ptr(), B, T, h, w, ps, channels, inv_div, L.stream()), "pixel_l1")
     return dpred
 
 

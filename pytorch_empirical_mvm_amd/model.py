@@ -90,10 +90,10 @@ class VIOLET_Pretrain(torch.nn.Module):
                 t.fill_(1.0 if last == "weight" else 0.0)
             elif last == "bias":
                 if name in ("fc.1.bias", "fc.3.bias", "decoder_pixel.0.bias", "enc_img.fc.bias", "enc_img.swin.patch_embed.proj.bias",
-                            "decoder_vq.0.bias", "fc_mvm.1.bias", "fc_mvm.3.bias"):
+                            "decoder_vq.0.bias", "fc_mvm.1.bias", "fc_mvm.3.bias", "decoder_hog.0.bias"):
                     feat_head = "3d_feature" in self.cfg["mvm_target"] or "2d_feature" in self.cfg["mvm_target"]
                     fan_in = {"fc.1.bias": self.hidden_size, "fc.3.bias": 2 * self.hidden_size, "decoder_pixel.0.bias": self.hidden_size,
-                              "decoder_vq.0.bias": self.hidden_size,
+                              "decoder_vq.0.bias": self.hidden_size, "decoder_hog.0.bias": self.hidden_size,
                               "fc_mvm.1.bias": self.hidden_size if feat_head else self.hidden_size // 8,
                               "fc_mvm.3.bias": 2 * self.hidden_size if feat_head else self.hidden_size // 4,
                               "enc_img.fc.bias": self.cfg["embed_dim"] * 8, "enc_img.swin.patch_embed.proj.bias": 96}[name]

@@ -206,3 +206,24 @@ def test_feature_targets_teacher_head_and_loss(kind):
     np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
     for k in ("fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-5)
+
+
+@pytest.mark.timeout(600)
+def test_hog_target_head_and_loss():
+    """MVM 'hog' target (decoder_hog 1x1 conv + PixelShuffle(32), L1 on pixels of covered patches) against the
+    reference's calc_mvm_loss; the HOG maps are a closed-form stand-in for the data loader's output."""
+    d = load("hog.npz")
+    cfg = R.make_cfg("tiny", T=4, mvm_target=["hog"])
+    sd = R.make_state_dict(cfg)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 2)
+    batch = R.default_masking(cfg, img, txt, mask, seed=5)
+    batch["hog"] = R.make_hog(cfg, 2)
+    ls = R.pretrain_losses(params, cfg, batch, negatives=d["neg"])
+    np.testing.assert_allclose(float(ls["mtm"].detach()), float(d["ls_mtm"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ls["mvm"].detach()), float(d["ls_mvm"]), rtol=1e-5)
+    ls["total"].backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
+    for k in ("decoder_hog.0.weight", "decoder_hog.0.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=2e-3, atol=2e-6)

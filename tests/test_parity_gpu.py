@@ -436,3 +436,35 @@ def test_feature_targets_vs_reference_golden(kind):
     masked = dict(mb); masked.update(cov=cov, unmask_img=img)
     r = agent.step(agent.prepare_batch(masked), is_train=True)
     assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r
+
+
+def test_hog_target_vs_reference_golden():
+    """MVM 'hog' target on the HIP path (decoder_hog GEMM + vmvm_pixel_l1 with one channel) against the fixture
+    produced by the reference's calc_mvm_loss; then one optimizer step with pixel + hog together through the agent surface."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, "hog.npz"))
+    cfg = R.make_cfg("tiny", T=4, mvm_target=["hog"])
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, mvm_target=["hog"]))
+    model.load_state_dict(R.make_state_dict(cfg))
+    img, txt, mask = R.make_batch(cfg, 2)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    hog = R.make_hog(cfg, 2)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    dev = "cuda"
+    batch = dict(img=img.to(dev), cov=cov.to(dev).contiguous(), txt=mb["txt"].to(dev), mask=mask.to(dev), ans_mtm=mb["ans_mtm"].to(dev), hog=hog.to(dev))
+    eng = model.engine
+    eng.store.grad.zero_()
+    losses, _ = eng.forward_backward(batch, negatives=d["neg"], train=False, backward=True)
+    torch.cuda.synchronize()
+    got = float(losses["mvm"].item())
+    assert abs(got - float(d["ls_mvm"])) <= 2e-2 * float(d["ls_mvm"]), (got, float(d["ls_mvm"]))
+    gn = float(eng.store.grad[:eng.store.n_trainable].double().pow(2).sum().sqrt().item())
+    assert abs(gn - float(d["grad_norm"])) <= 5e-2 * float(d["grad_norm"]), (gn, float(d["grad_norm"]))
+    for k in ("decoder_hog.0.weight", "decoder_hog.0.bias"):
+        _check_samples(d, "g." + k, eng.store.g(k).reshape(tuple(d[f"g.{k}.shape"])), tol=1e-1)       # L1 sign gradient (see the feature test)
+    model2, args2 = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, mvm_target=["pixel", "hog"]))
+    agent = Agent_Pretrain(args2, model2)
+    masked = dict(mb); masked.update(cov=cov, unmask_img=img, hog=hog)
+    r = agent.step(agent.prepare_batch(masked), is_train=True)
+    assert all(np.isfinite(v) for v in r.values()) and r["mvm"] > 0, r

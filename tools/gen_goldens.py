@@ -430,6 +430,60 @@ def gold_feature(kind, size="tiny", T=4, B=2, S=224):
     print(kind, "ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5, "target", tuple(tgt.shape), float(tgt.abs().mean()))
 
 
+def gold_hog(size="tiny", T=4, B=2, S=224):
+    """MVM 'hog' target head + loss through the reference's calc_mvm_loss (HOG maps: closed-form stand-in for the
+    data loader's skimage output)."""
+    import main_pretrain as mp
+    cfg = R.make_cfg(size, T=T, img=S, mvm_target=["hog"])
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="hog")
+    model = mp.VIOLET_Pretrain(args, None).eval()
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    enc_t = model.trsfr
+    def go_cross(feat_img, mask_img, feat_txt, mask_txt, **kw):
+        feat = torch.cat([feat_img, feat_txt], dim=1)
+        mask = mask_ext(model.get_attn_mask(mask_img, mask_txt))
+        o = enc_t(feat, attention_mask=mask)
+        return (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), ()
+    model.go_cross = go_cross
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    calls = {"i": 0}
+    def fake_perm(lst):
+        i = calls["i"]; calls["i"] += 1
+        rest = [j for j in lst if j not in list(neg[i])]
+        return np.array(list(neg[i]) + rest)
+    mp.np.random.permutation = fake_perm
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    batch = dict(mb)
+    batch["hog"] = R.make_hog(cfg, B)
+    out = model(batch)
+    ls_mtm = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    ls_vtm = agent.loss_func(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = agent.calc_mvm_loss(batch, out["out_mvm"], is_train=True)
+    (ls_mtm + ls_vtm + ls_mvm).backward()
+    d = dict(ls_mtm=np.array(float(ls_mtm.detach())), ls_vtm=np.array(float(ls_vtm.detach())), ls_mvm=np.array(float(ls_mvm.detach())), neg=neg)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("decoder_hog"):
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, "hog.npz"), **d)
+    print("hog ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5)
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -503,6 +557,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--hog-only" in sys.argv:
+        gold_hog()
+        sys.exit(0)
     if "--feature-only" in sys.argv:
         if "--2d" not in sys.argv:
             gold_feature("3d_feature")
@@ -518,3 +575,4 @@ if __name__ == "__main__":
     gold_vq()
     gold_feature("3d_feature")
     gold_feature("2d_feature")
+    gold_hog()
