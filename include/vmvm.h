@@ -258,7 +258,10 @@ int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed,
  * multiples of 8) writes dst[offset + k*N + n] = src[offset + n*K + k] -- keeps W^T copies of all weights so dgrad (dX = dY W) runs
  * on the k-major fast path */
 int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream);
-int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* stream);
+/* *out_accum += sum g[i]^2 (clip_grad_norm_, agent.py:188).  With a scratch buffer (>= 8 KiB) the per-workgroup partials are summed
+ * in a fixed order, so data-parallel ranks holding identical (all-reduced) gradients get bit-identical clip coefficients and their
+ * replicas stay bit-identical; workspace NULL: f32 atomics (order-dependent rounding). */
+int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* workspace, uint64_t workspace_bytes, void* stream);
 typedef struct {
   float* param; const float* grad; float* m; float* v; void* param_bf16;
   int64_t n;

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __res
 }
 
 // ---------------------------------------------------------------- optimizer
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * 256 * 4;
@@ -423,7 +423,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     }
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) {
+    if (partial) partial[blockIdx.x] = s;            // deterministic path: fixed-order second pass (sumsq_final_kernel)
+    else atomicAdd(out, s);
+  }
+}
+// fixed-order sum of the per-block partials: every data-parallel rank gets bit-identical clip coefficients from identical gradients
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *out += s;
 }
 __global__ __launch_bounds__(256) void adamw_kernel(const vmvm_adamw_desc d) {
   float coef = d.grad_scale;
@@ -694,12 +705,17 @@ extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
-extern "C" int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* stream) {
+extern "C" int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* workspace, uint64_t workspace_bytes, void* stream) {
   if (!g || !out_accum || n <= 0) return VMVM_EINVAL;
   int grid = nblk((n + 3) / 4, 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, (long)n, out_accum);
+  float* partial = (workspace && workspace_bytes >= (uint64_t)grid * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, (long)n, out_accum, partial);
   VMVM_CHECK_LAUNCH();
+  if (partial) {
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, ST, partial, grid, out_accum);
+    VMVM_CHECK_LAUNCH();
+  }
   return VMVM_OK;
 }
 extern "C" int vmvm_adamw(const vmvm_adamw_desc* d, void* stream) {

@@ -19,6 +19,10 @@ def init_from_env(backend=None):
     if world < 2 and not os.environ.get("VMVM_FORCE_DIST"):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VMVM_DIST_BACKEND"):            # test hook: e.g. gloo with several ranks sharing one GPU (see VMVM_SHARE_GPU)
+        backend = os.environ["VMVM_DIST_BACKEND"]
+    if os.environ.get("VMVM_SHARE_GPU") and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()      # N ranks on fewer GPUs: exercises the whole multi-rank path on a 1-GPU box (gloo)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":

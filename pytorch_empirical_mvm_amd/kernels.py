@@ -290,7 +290,9 @@ def transpose_batched(src, dst, table):
 
 
 def sumsq(g, out):
-    L.check(L.load().vmvm_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.stream()), "sumsq")
+    ws = _WORKSPACE.get(g.device)
+    L.check(L.load().vmvm_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
+                                    L.stream()), "sumsq")
     return out
 
 

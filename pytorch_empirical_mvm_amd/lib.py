@@ -104,7 +104,7 @@ _PROTOS = {
     "vmvm_gelu_bwd_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_dropout_bf16": ([c_void_p, c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
     "vmvm_transpose_batched_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
-    "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p], c_int),
+    "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p, c_u64, c_void_p], c_int),
     "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
     "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),
 }

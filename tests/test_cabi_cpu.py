@@ -50,7 +50,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     l = lib.load()
     d = lib.GemmDesc()
     assert l.vmvm_gemm_bf16(ctypes.byref(d), None) == -1          # VMVM_EINVAL: null operands
-    assert l.vmvm_sumsq_f32(None, 10, None, None) == -1
+    assert l.vmvm_sumsq_f32(None, 10, None, None, 0, None) == -1
     a = lib.AttnFwdDesc()
     assert l.vmvm_attention_fwd(ctypes.byref(a), None) == -1
 

@@ -1,0 +1,45 @@
+"""Two data-parallel ranks through the whole GPU step.  The box has one GPU, so both ranks share cuda:0 and the collectives go
+through gloo (VMVM_DIST_BACKEND / VMVM_SHARE_GPU test hooks of dist.init_from_env): everything but RCCL itself runs -- rank-0
+broadcast, the reductions hooked into the backward on the side stream, the 1/world scale, replica consistency -- and bench.py's
+multi-rank contract (barrier, max over ranks, ONE JSON line from rank 0)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(script_args, timeout):
+    env = dict(os.environ, VMVM_DIST_BACKEND="gloo", VMVM_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_gradient_mean_and_identical_replicas():
+    p = _run(["tools/dp_check.py"], 500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "replicas identical=True" in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_bench_contract_two_ranks():
+    p = _run(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"], 800)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak" and o["config"]["global_batch"] == 8
+    assert o["value"] > 0 and abs(o["value"] - 8 * 2 / (o["ms_per_step"] * 2 / 1e3)) < 1e-2 * o["value"]
+    assert "cpu_baseline" not in o and o["roofline"]["frac"] > 0

@@ -1,0 +1,80 @@
+"""Multi-rank data-parallel step on the GPU path (launched by torch.distributed.run).  On a 1-GPU box: VMVM_DIST_BACKEND=gloo
+VMVM_SHARE_GPU=1 puts every rank on cuda:0 and moves the collectives through gloo, which exercises everything except RCCL itself:
+rank-0 broadcast, the side-stream reductions hooked into the backward (non-Swin groups, Swin tail, rest), the 1/world scale in
+AdamW, replica consistency.  Checks after 3 steps: parameters bit-identical on all ranks; the reduced gradient of step 1 equals
+the mean of the per-rank gradients computed without the reducer."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import bench  # noqa: E402
+from pytorch_empirical_mvm_amd import config as CFG, dist as D  # noqa: E402
+from pytorch_empirical_mvm_amd.agent import Agent_Pretrain  # noqa: E402
+from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain  # noqa: E402
+
+
+def main():
+    rank, world, local = D.init_from_env("nccl")
+    assert world >= 2, "launch with torch.distributed.run --nproc-per-node >= 2"
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    args = CFG.get_args(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, mvm_target=["pixel"], max_iter=100, seed=88 + 17 * rank,
+                        bert_layers=2)
+    model = VIOLET_Pretrain(args, None, device=dev)          # different seeds: the broadcast must make the replicas identical
+    agent = Agent_Pretrain(args, model)
+    agent.prepare_dist_model()
+    agent.sched_step = 5
+    S = model.engine.store
+    B = 4
+    img, txt, mask = bench.synth_batch(args, B, dev, 500 + rank)
+    import random
+    random.seed(3 + rank); np.random.seed(3 + rank); torch.manual_seed(3 + rank)
+    mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
+    neg = model.engine.sample_negatives(B, np.random.RandomState(1))
+    dp = model.engine.sample_drop_path(B, np.random.RandomState(2))
+    # reference gradient of this rank WITHOUT the reducer (same dropout stream: rng_offset restored)
+    eng = model.engine
+    off0 = eng.rng_offset
+    b = dict(img=mb["img"].float(), cov=mb["cov"], txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"])
+    S.grad.zero_()
+    eng.forward_backward(b, negatives=neg, train=True, dp_all=dp)
+    own = S.grad[:S.n_trainable].clone()
+    gather = [torch.empty_like(own) for _ in range(world)]
+    dist.all_gather(gather, own)
+    mean_ref = sum(gather) / world
+    # the same step through the agent (hooks + side stream); AdamW applies 1/world, so compare the SUM in the arena
+    eng.rng_offset = off0
+    S.grad.zero_()
+    eng.on_swin_tail_ready = agent.comm.reduce_swin_tail
+    eng.forward_backward(b, negatives=neg, train=True, dp_all=dp, on_other_grads_ready=agent.comm.reduce_other)
+    agent.comm.reduce_swin_and_wait()
+    torch.cuda.synchronize()
+    red = S.grad[:S.n_trainable] / world
+    err = float((red - mean_ref).abs().max() / (mean_ref.abs().max() + 1e-12))
+    assert err < 1e-5, err
+    S.grad.zero_()
+    for _ in range(3):
+        r = agent.step(mb, is_train=True)
+    torch.cuda.synchronize()
+    flat = S.flat[:S.total].clone()
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    same = bool(torch.equal(flat, ref))
+    if not same:
+        d = (flat - ref).abs()
+        print(f"rank {rank}: {int((d > 0).sum())} of {flat.numel()} parameters differ from rank 0, max abs diff {float(d.max()):.3e}", flush=True)
+    t = torch.tensor([1.0 if same else 0.0], device=dev)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(f"dp_check world={world} backend={dist.get_backend()} grad-mean rel err {err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
+    assert int(t.item()) == world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
