@@ -1516,8 +1516,12 @@ __host__ __device__ inline SmemS smem_stream(int L, int hd, int mode, int table_
   return s;
 }
 
-template <int HD, int MODE, int NW, int KC>
+// Scores live in the log2 domain (s2 = s * log2 e: the table is staged pre-multiplied, the q k^T term enters through one fma), so
+// the softmax needs exp2 only; MASK = false: no region map (un-shifted windows), the compare/select/add per element is compiled out;
+// the key < L guard runs only in the last chunk.
+template <int HD, int MODE, int NW, int KC, bool MASK>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_attn_fwd_desc p, const int nqb) {
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTC = KC / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1538,7 +1542,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
       rc[i] = i < L ? p.rc[i] : 0;
       reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
     }
-    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h] * LOG2E;
   } else {
     for (int i = tid; i < sm.lpk; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
   }
@@ -1565,8 +1569,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
     fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
     fill_wait();
     __syncthreads();
-    const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
-    const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
+    const int rcq = (MODE == 0) ? rc[qv ? q : 0] + p.rc0 : 0;
+    const int regq = (MODE == 0 && MASK) ? reg[qv ? q : 0] : 0;
+    const bool tail = k0 + KC > L;
+    const float sc2 = p.scale * LOG2E;
     f32x4 acc[NTC];
     float cmx = NEG_INF;
 #pragma unroll
@@ -1581,35 +1587,38 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
       const int key0 = k0 + t * 16 + g * 4;
       if (MODE == 0) {
         const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
-        const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0);
         const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
-        const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
+        int gks[4] = {0, 0, 0, 0};
+        if (MASK) { const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0); gks[0] = gk.x; gks[1] = gk.y; gks[2] = gk.z; gks[3] = gk.w; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float s = acc[t][j] + tab[rcq - rks[j] + p.rc0] + (regq != gks[j] ? -100.f : 0.f);
-          s = (key0 + j < L) ? s : NEG_INF;
-          acc[t][j] = s; cmx = fmaxf(cmx, s);
+          float s = __builtin_fmaf(acc[t][j], LOG2E, tab[rcq - rks[j]]);
+          if (MASK) s += (regq != gks[j] ? -100.f * LOG2E : 0.f);
+          acc[t][j] = s;
         }
       } else {
         const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
         const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float s = mks[j] ? acc[t][j] * p.scale : NEG_INF;
-          acc[t][j] = s; cmx = fmaxf(cmx, s);
-        }
+        for (int j = 0; j < 4; ++j) acc[t][j] = mks[j] ? acc[t][j] * sc2 : NEG_INF;
       }
+      if (MODE == 0 && tail) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (key0 + j < L) ? acc[t][j] : NEG_INF;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cmx = fmaxf(cmx, acc[t][j]);
     }
     cmx = fmaxf(cmx, __shfl_xor(cmx, 16, 64));
     cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
     const float mnew = fmaxf(m, cmx);
-    const float alpha = __expf(m - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
     m = mnew;
     float csum = 0.f;
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float e = __expf(acc[t][j] - mnew); acc[t][j] = e; csum += e; }
+      for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(acc[t][j] - mnew); acc[t][j] = e; csum += e; }
     }
     lsum = lsum * alpha + csum;
 #pragma unroll
@@ -1641,7 +1650,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
   float sum = lsum;
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = m + __logf(sum);
+  if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = (m + __builtin_amdgcn_logf(sum)) * LN2;      // v_log_f32 = log2
   if (qv) {
     const float inv = seq_scale / sum;
     u16* op = reinterpret_cast<u16*>(p.out) + ((size_t)seq * L + q) * p.ld_out + h * HD + g * 4;
@@ -1653,8 +1662,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
 
 // dQ (+ delta): workgroup (sequence chunk, head, query block) walks its sequences (the per-head table is staged once); K / V
 // stream through LDS in KC-token chunks.  The bias-table gradient has its own kernel (attn_bwd_dbias_stream_kernel).
-template <int HD, int MODE, int NW, int KC>
+template <int HD, int MODE, int NW, int KC, bool MASK>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb) {
+  constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1674,7 +1684,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   if (MODE == 0) {
     for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
-    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h] * LOG2E;     // log2-domain scores
   }
   const int qt = qb * NW + wave;
   const int q = qt * 16 + r;
@@ -1704,7 +1714,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
     if (g == 0 && qv) pb.delta[((size_t)seq * heads + h) * L + q] = dl;
-    const float lse = qv ? p.lse[((size_t)seq * heads + h) * L + q] : 0.f;
+    const float lse2 = qv ? p.lse[((size_t)seq * heads + h) * L + q] * LOG2E : __builtin_huge_valf();   // padded query: p = exp2(-inf) = 0
+    const float sc2 = p.scale * LOG2E;
     f32x4 dq[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1715,8 +1726,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
       fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
       fill_wait();
       __syncthreads();
-      const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
-      const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
+      const int rcq = (MODE == 0) ? rc[qv ? q : 0] + p.rc0 : 0;
+      const int regq = (MODE == 0 && MASK) ? reg[qv ? q : 0] : 0;
+      const bool tail = k0 + KC > L;
       uint4 own = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int c = 0; c < KC / 32; ++c) {
@@ -1742,23 +1754,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
           }
           if (MODE == 0) {
             const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
-            const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0);
             const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
-            const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
+            int gks[4] = {0, 0, 0, 0};
+            if (MASK) { const uchar4 gk = *reinterpret_cast<const uchar4*>(reg + key0); gks[0] = gk.x; gks[1] = gk.y; gks[2] = gk.z; gks[3] = gk.w; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int bi = rcq - rks[j] + p.rc0;
-              const float s = s4[j] + tab[bi] + (regq != gks[j] ? -100.f : 0.f);
-              const float pr = (key0 + j < L && qv) ? __expf(s - lse) : 0.f;
-              const float d = pr * (dp4[j] * seq_scale - dl);
-              ds[u][j] = d;
+              float s = __builtin_fmaf(s4[j], LOG2E, tab[rcq - rks[j]]) - lse2;
+              if (MASK) s += (regq != gks[j] ? -100.f * LOG2E : 0.f);
+              float pr = __builtin_amdgcn_exp2f(s);
+              if (tail) pr = (key0 + j < L) ? pr : 0.f;
+              ds[u][j] = pr * __builtin_fmaf(dp4[j], seq_scale, -dl);
             }
           } else {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
             const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float pr = (mks[j] && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
+              const float pr = mks[j] ? __builtin_amdgcn_exp2f(__builtin_fmaf(s4[j], sc2, -lse2)) : 0.f;
               float dpj = dp4[j] * seq_scale;
               if (has_drop) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
               ds[u][j] = pr * (dpj - dl);
@@ -1890,8 +1902,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dbias_stream_kernel(const vm
 }
 
 // dK / dV: workgroup = (sequence, head, block of NW*KT key tiles); Q / dO (+ lse, delta) stream through LDS in KC-query chunks.
-template <int HD, int MODE, int NW, int KC>
+template <int HD, int MODE, int NW, int KC, bool MASK>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm_attn_bwd_desc pb, const int nkb) {
+  constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1921,7 +1934,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
     }
   }
   if (MODE == 0)
-    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
+    for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h] * LOG2E;      // log2-domain scores
   __syncthreads();
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
@@ -1929,6 +1942,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
   const uint32_t thr8 = drop_thr8(p.dropout_p);
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   const int nt = (L + 15) / 16;
+  const float sc2 = p.scale * LOG2E;
 
   constexpr int KT = (HD == 32) ? 2 : 1;
   int key[KT]; bool kv[KT];
@@ -1945,7 +1959,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
       kf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.k_off + h * HD + g * 8 + s * 32, kv[t]);
       vf[t][s] = load_frag_global(qkv + (size_t)key[t] * p.ld_qkv + p.v_off + h * HD + g * 8 + s * 32, kv[t]);
     }
-    rck[t] = (MODE == 0) ? rc[kv[t] ? key[t] : 0] : 0;
+    rck[t] = (MODE == 0) ? rc[kv[t] ? key[t] : 0] - p.rc0 : 0;
     regk[t] = reg[kv[t] ? key[t] : 0];
     own[t] = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -1957,7 +1971,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
     fill_rowmajor<HD>(Qsm, qkv + (size_t)q0c * p.ld_qkv + p.q_off + h * HD, p.ld_qkv, L - q0c, KC, tid, NW * 64);
     fill_rowmajor<HD>(dOsm, dO + (size_t)q0c * pb.ld_dout, pb.ld_dout, L - q0c, KC, tid, NW * 64);
     for (int i = tid; i < KC; i += NW * 64) {
-      lse_s[i] = (q0c + i < L) ? lse_g[q0c + i] : __builtin_huge_valf();     // +inf -> p = 0 for padded queries
+      lse_s[i] = (q0c + i < L) ? lse_g[q0c + i] * LOG2E : __builtin_huge_valf();     // log2 domain; +inf -> p = 0 for padded queries
       delta_s[i] = (q0c + i < L) ? delta_g[q0c + i] : 0.f;
     }
     fill_wait();
@@ -1995,17 +2009,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
           const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
           if (MODE == 0) {
             const int4 rq = *reinterpret_cast<const int4*>(rc + q0);
-            const uchar4 gq = *reinterpret_cast<const uchar4*>(reg + q0);
             const int rqs[4] = {rq.x, rq.y, rq.z, rq.w};
-            const int gqs[4] = {gq.x, gq.y, gq.z, gq.w};
+            int gqs[4] = {0, 0, 0, 0};
+            if (MASK) { const uchar4 gq = *reinterpret_cast<const uchar4*>(reg + q0); gqs[0] = gq.x; gqs[1] = gq.y; gqs[2] = gq.z; gqs[3] = gq.w; }
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float sv = s4[t][j] + tab[rqs[j] - rck[t] + p.rc0] + (gqs[j] != regk[t] ? -100.f : 0.f);
-                const float pr = kv[t] ? __expf(sv - ls[j]) : 0.f;
+                float sv = __builtin_fmaf(s4[t][j], LOG2E, tab[rqs[j] - rck[t]]) - ls[j];
+                if (MASK) sv += (gqs[j] != regk[t] ? -100.f * LOG2E : 0.f);
+                const float pr = kv[t] ? __builtin_amdgcn_exp2f(sv) : 0.f;
                 pt[t][u][j] = pr;
-                ds[t][u][j] = pr * (dp4[t][j] * seq_scale - dls[j]);
+                ds[t][u][j] = pr * __builtin_fmaf(dp4[t][j], seq_scale, -dls[j]);
               }
           } else {
 #pragma unroll
@@ -2017,7 +2032,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm
               }
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float pr = (kv[t] && regk[t]) ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
+                const float pr = (kv[t] && regk[t]) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s4[t][j], sc2, -ls[j])) : 0.f;
                 float dpj = dp4[t][j] * seq_scale, pj = pr;
                 if (has_drop) {
                   const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
@@ -2105,13 +2120,14 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     const SmemS ss = smem_stream(d->L, d->head_dim, d->mode, d->table_len, 0, KCS);
     const int nqb = ((d->L + 15) / 16 + NWS - 1) / NWS;
     const int grid = d->nseq * d->heads * nqb;
-#define LAUNCH_FWD_S(HD, MODE)                                                                                       \
+#define LAUNCH_FWD_S(HD, MODE, MASK)                                                                                 \
     do {                                                                                                             \
-      int rc_ = set_smem(attn_fwd_stream_kernel<HD, MODE, NWS, KCS>, ss.total);                                       \
+      int rc_ = set_smem(attn_fwd_stream_kernel<HD, MODE, NWS, KCS, MASK>, ss.total);                                 \
       if (rc_) return rc_;                                                                                           \
-      hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, MODE, NWS, KCS>), dim3(grid), dim3(NWS * 64), ss.total, st, *d, nqb); \
+      hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, MODE, NWS, KCS, MASK>), dim3(grid), dim3(NWS * 64), ss.total, st, *d, nqb); \
     } while (0)
-    if (d->mode == 0) LAUNCH_FWD_S(32, 0); else LAUNCH_FWD_S(64, 1);
+    if (d->mode == 0) { if (d->region) LAUNCH_FWD_S(32, 0, true); else LAUNCH_FWD_S(32, 0, false); }
+    else LAUNCH_FWD_S(64, 1, false);
     VMVM_CHECK_LAUNCH();
     return VMVM_OK;
   }
@@ -2190,32 +2206,37 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     if (nchs > d->f.nseq || d->f.mode == 1) nchs = d->f.nseq;
     const int kt_ = d->f.mode == 0 ? 2 : 1;
     const int nkb = (nt_ + NWS * kt_ - 1) / (NWS * kt_);
-#define LAUNCH_BWD_S(HD, MODE)                                                                                       \
+#define LAUNCH_BWD_S(HD, MODE, MASK)                                                                                 \
     do {                                                                                                             \
-      int rc_ = set_smem(attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS>, sa.total);                                    \
+      int rc_ = set_smem(attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS, MASK>, sa.total);                              \
       if (rc_) return rc_;                                                                                           \
-      hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS>), dim3(nchs * d->f.heads * nqb), dim3(NWS * 64), sa.total, st, *d, nchs, nqb); \
+      hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<HD, MODE, NWS, KCS, MASK>), dim3(nchs * d->f.heads * nqb), dim3(NWS * 64), sa.total, st, *d, nchs, nqb); \
       VMVM_CHECK_LAUNCH();                                                                                           \
-      rc_ = set_smem(attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS>, sb.total);                                       \
+      rc_ = set_smem(attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS, MASK>, sb.total);                                 \
       if (rc_) return rc_;                                                                                           \
-      hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS>), dim3(d->f.nseq * d->f.heads * nkb), dim3(NWS * 64), sb.total, st, *d, nkb); \
+      hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS, MASK>), dim3(d->f.nseq * d->f.heads * nkb), dim3(NWS * 64), sb.total, st, *d, nkb); \
       VMVM_CHECK_LAUNCH();                                                                                           \
     } while (0)
-    if (d->f.mode == 0) LAUNCH_BWD_S(32, 0); else LAUNCH_BWD_S(64, 1);
+    if (d->f.mode == 0) { if (d->f.region) LAUNCH_BWD_S(32, 0, true); else LAUNCH_BWD_S(32, 0, false); }
+    else LAUNCH_BWD_S(64, 1, false);
     if (d->f.mode == 0 && d->dbias_table) {
       const int nkc = (d->f.L + KCS - 1) / KCS;
       // window positions (the bias + mask block is per position); without a region map every sequence shares one block
       int nwin = d->f.region ? ((d->f.n_win > 0 && d->f.nseq % d->f.n_win == 0) ? d->f.n_win : d->f.nseq) : 1;
-      int ncb = 2048 / (d->f.heads * nqb * nkc);
+      int ncb = 2048 / (d->f.heads * nqb * 2 * nkc);
       if (ncb < 1) ncb = 1;
       if (!d->f.region && ncb > 1) {                  // no mask: split the sequences themselves to fill the chip
         nwin = ncb < d->f.nseq ? ncb : d->f.nseq;
         while (d->f.nseq % nwin) --nwin;
       }
       if (ncb > nwin) ncb = nwin;
-      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWS, KCS>, sa.total);
+      // 4-wave workgroups here: the kernel holds two 16 x 128 blocks per wave in registers (3 waves per SIMD), and what hides the
+      // per-sequence load latency is the number of workgroups in flight per CU (3 at this size, 1 with 8 waves)
+      constexpr int NWB = 4;
+      const int nqbb = (nt_ + NWB - 1) / NWB;
+      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWB, KCS>, sa.total);
       if (rc_) return rc_;
-      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWS, KCS>), dim3(ncb * d->f.heads * nqb * nkc), dim3(NWS * 64), sa.total, st, *d, ncb, nqb, nwin);
+      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWB, KCS>), dim3(ncb * d->f.heads * nqbb * nkc), dim3(NWB * 64), sa.total, st, *d, ncb, nqbb, nwin);
       VMVM_CHECK_LAUNCH();
     }
     return VMVM_OK;
