@@ -152,6 +152,11 @@ typedef struct {
    * kernels: K/V pass through LDS in 128-token chunks with an online softmax, same masks / bias / dropout stream as the
    * resident kernels.  stream_min_len > 0 lowers that threshold (L >= stream_min_len streams; parity tests); 0 = default. */
   int32_t stream_min_len;
+  /* mode 1 only, 0 = off: the seq2seq mask of VIOLET_Base.get_attn_mask(attn_mask_type="seq2seq") (model.py:191-199; the smtm pass
+   * main_pretrain.py:217-224): keys < causal_from (visual tokens) follow `keymask` for every query; a key >= causal_from (text) is
+   * visible only to queries q >= causal_from with key <= q (lower triangle; the text padding mask is NOT applied there, as in the
+   * reference).  Resident kernels only (L <= 448). */
+  int32_t causal_from;
 } vmvm_attn_fwd_desc;
 int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
 

@@ -199,7 +199,9 @@ __device__ __forceinline__ uint4 quad_bcast_i(const uint4& b, int i) {   // i is
 #define TILE_ON(t) (NX ? ((t) < NX) : ((t) < nt))
 #define PAIR_ON(c) (NX ? ((c) < (NX + 1) / 2) : ((c) < nt2))
 #define KEY_OK(t, key) ((NX && (t) < NX - 1) ? true : ((key) < L))
-template <int HD, int MODE, int NT_MAX, int NW, int NX, bool MASK>
+// CAUSAL (mode 1, `causal_from` = cf > 0): the seq2seq mask of VIOLET_Base.get_attn_mask (model.py:191-199) -- keys below cf (the
+// visual tokens) follow the key mask for every query; a key >= cf (text) is visible only to text queries at or after it.
+template <int HD, int MODE, int NT_MAX, int NW, int NX, bool MASK, bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,7 +284,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float s = mks[j] ? acc[t][j] * p.scale : NEG_INF;
+            bool ok = mks[j] != 0;
+            if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q >= p.causal_from && key0 + j <= q && key0 + j < L);
+            float s = ok ? acc[t][j] * p.scale : NEG_INF;
             acc[t][j] = s; mx = fmaxf(mx, s);
           }
         }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 // ================================================================================================
 // backward A: dQ (+ delta, + relative-position-bias table gradient)
 // ================================================================================================
-template <int HD, int MODE, int NW, int NXB>
+template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bwd_desc pb, const int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -463,7 +467,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
             const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float pr = (mks[j] && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
+              bool ok = mks[j] != 0;
+              if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q >= p.causal_from && key0 + j <= q && key0 + j < L);
+              const float pr = (ok && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
               float dpj = dp4[j] * seq_scale;
               if (has_drop) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
               ds[u][j] = pr * (dpj - dl);
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
 // ================================================================================================
 // backward B: dK, dV (per key tile; probabilities recomputed from lse; delta from kernel A)
 // ================================================================================================
-template <int HD, int MODE, int NW, int NXB>
+template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -1207,7 +1213,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
               }
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float pr = (kv[t] && regk[t]) ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
+                bool ok = kv[t] && regk[t];
+                if (CAUSAL) ok = (key[t] < p.causal_from) ? ok : (kv[t] && q0 + j >= p.causal_from && key[t] <= q0 + j);
+                const float pr = ok ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
                 float dpj = dp4[t][j] * seq_scale, pj = pr;
                 if (has_drop) {
                   const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
@@ -2097,6 +2105,8 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
   if (d->L > 16384) return VMVM_ENOSUPPORT;        // dropout block ids carry key/4 in 12 bits; above 448 tokens the streaming kernels run
   if (d->region && d->n_win <= 0) return VMVM_EINVAL;
   if (d->seq_scale && d->seqs_per_scale <= 0) return VMVM_EINVAL;
+  if (d->causal_from < 0 || (d->causal_from > 0 && d->mode != 1)) return VMVM_EINVAL;
+  if (d->causal_from > 0 && (d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len))) return VMVM_ENOSUPPORT;   // no streaming seq2seq build
   return VMVM_OK;
 }
 
@@ -2164,7 +2174,12 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   } else {
     // (exact-NT instantiations of the head_dim-64 kernel need the compiler barrier in the score loop: hoisted en bloc, the K
     //  fragment loads of 27 unguarded tiles exceed 256 VGPRs)
-    if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4, 0, true);
+    if (d->causal_from > 0) {                                       // seq2seq mask (smtm pass): generic tile loops
+      int rc_ = set_smem(attn_fwd_kernel<64, 1, 28, 8, 0, true, true>, sm.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 28, 8, 0, true, true>), dim3(nb), dim3(8 * 64), sm.total, st, *d);
+    }
+    else if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4, 0, true);
     else if (sm.nt == 27) LAUNCH_FWD(64, 1, 28, 8, 27, true);       // L = 432 (fusion encoder): exact tile count, no per-tile guards
     else LAUNCH_FWD(64, 1, 28, 8, 0, true);
   }
@@ -2327,7 +2342,17 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     }
   } else {
     const Smem sb_ = smem_layout(d->f.L, 64, 1, d->f.table_len, 1);
-    if (sb_.nt == 27) {        // L = 432 (fusion encoder): exact tile count, fully unrolled tile loops
+    if (d->f.causal_from > 0) {                                     // seq2seq mask (smtm pass)
+      const Smem s1_ = smem_layout(d->f.L, 64, 1, d->f.table_len, 1), s2_ = smem_layout(d->f.L, 64, 1, d->f.table_len, 2);
+      int rc_ = set_smem(attn_bwd_dq_kernel<64, 1, 8, 0, true>, s1_.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 1, 8, 0, true>), dim3(nchunks * d->f.heads), dim3(8 * 64), s1_.total, st, *d, nchunks);
+      VMVM_CHECK_LAUNCH();
+      rc_ = set_smem(attn_bwd_dkv_kernel<64, 1, 8, 0, true>, s2_.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, 8, 0, true>), dim3(nb), dim3(8 * 64), s2_.total, st, *d);
+      VMVM_CHECK_LAUNCH();
+    } else if (sb_.nt == 27) {        // L = 432 (fusion encoder): exact tile count, fully unrolled tile loops
       LAUNCH_BWD_DQ(64, 1, 8, 27);
       LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2, 27);
     } else {

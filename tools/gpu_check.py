@@ -509,6 +509,34 @@ def check_attn_stream():
     rep("stream vs resident window dtable", t1, t0, tol=1e-2)
 
 
+def check_attn_seq2seq():
+    """mode-1 attention with the seq2seq mask (model.py:191-199; smtm pass): visual keys for everyone, text keys lower-triangular for
+    text queries only (no padding mask there), with attention dropout off and on (mask recovered through the resident kernel)."""
+    for (nseq, Lq, Lv, heads) in [(3, 232, 200, 4), (2, 432, 400, 2)]:
+        Hd = heads * 64
+        qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+        km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+        km[:, Lq - 7:] = 0                                     # text padding: ignored inside the triangle, as in the reference
+        kw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, causal_from=Lv)
+        out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, **kw)
+        allow = torch.zeros(Lq, Lq, dtype=torch.bool, device=dev)
+        allow[:, :Lv] = True
+        allow[Lv:, Lv:] = torch.tril(torch.ones(Lq - Lv, Lq - Lv, dtype=torch.bool, device=dev))
+        bias = torch.where(allow, 0.0, float("-inf"))[None, None]
+        qf = qkv.float().requires_grad_(True)
+        x = qf.view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        o = attn_ref(x[0] * 0.125, x[1], x[2], bias)
+        ref = o.transpose(1, 2).reshape(nseq * Lq, Hd)
+        tag = f"seq2seq attn nseq={nseq} L={Lq} Lv={Lv}"
+        rep(tag + " fwd", out, ref)
+        dout = rnd(nseq * Lq, Hd)
+        ref.backward(dout.float())
+        dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, **kw)
+        rep(tag + " bwd dq", dqkv[:, :Hd], qf.grad[:, :Hd])
+        rep(tag + " bwd dk", dqkv[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
+        rep(tag + " bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+
+
 # ------------------------------------------------------------------ misc
 def check_misc():
     B, T, H, W = 2, 4, 64, 96
@@ -744,9 +772,9 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "misc", "bench"]
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, misc=check_misc)
+                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, misc=check_misc)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
