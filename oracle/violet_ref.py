@@ -42,9 +42,10 @@ BERT = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512,
 
 def make_cfg(size="base", T=8, img=224, n_txt=32, max_size_frame=None, max_size_patch=14,
              size_patch=32, temp=0.05, bert_layers=12, mvm_target="pixel", arch=None, vocab=None,
-             size_vq=8192, dvae_hid=256, dvae_vocab=8192, teacher_arch=None):
+             size_vq=8192, dvae_hid=256, dvae_vocab=8192, teacher_arch=None, pretrain_tasks=("vtm", "mlm", "mvm")):
     a = dict(ARCH[size]) if arch is None else dict(arch)
     cfg = dict(a)
+    cfg["pretrain_tasks"] = tuple(pretrain_tasks)        # args_pretrain.json:19-23 ; "smtm" adds the seq2seq MLM pass
     cfg["teacher_arch"] = dict(ARCH["base"]) if teacher_arch is None else dict(teacher_arch)   # main_pretrain.py:157,168: always "base"
     cfg.update(size=size, T=T, img=img, n_txt=n_txt, max_size_frame=max_size_frame or max(T, 6),
                max_size_patch=max_size_patch, size_patch=size_patch, temp=temp,
@@ -534,9 +535,21 @@ def bert_layer(sd, p, x, add_mask):
     return layer_norm(y + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT["eps"])
 
 
-def go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask_txt):
-    """VIOLET_Base.go_cross model.py:204-214 ; mask -> (1-m)*finfo.min, broadcast (B,1,1,L)"""
+def go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask_txt, seq2seq=False):
+    """VIOLET_Base.go_cross model.py:204-214 ; mask -> (1-m)*finfo.min, broadcast (B,1,1,L).
+    seq2seq=True: get_smtm_output main_pretrain.py:217-224 with get_attn_mask(attn_mask_type="seq2seq") model.py:191-199 --
+    (B,L,L): every query sees the visual keys (mask_img), text queries see text keys lower-triangularly (mask_txt unused)."""
     feat = torch.cat([feat_img, feat_txt], dim=1)
+    if seq2seq:
+        B, Lv = mask_img.shape
+        Lt = mask_txt.shape[1]
+        m = torch.zeros(B, Lv + Lt, Lv + Lt, dtype=feat.dtype)
+        m[:, :, :Lv] = mask_img[:, None, :].to(feat.dtype)
+        m[:, Lv:, Lv:] = torch.tril(torch.ones(Lt, Lt, dtype=feat.dtype))
+        add = (1.0 - m[:, None, :, :]) * torch.finfo(feat.dtype).min
+        for l in range(cfg["bert_layers"]):
+            feat = bert_layer(sd, f"trsfr.layer.{l}.", feat, add)
+        return feat
     mask = torch.cat([mask_img, mask_txt], dim=1)
     add = (1.0 - mask[:, None, None, :].to(feat.dtype)) * torch.finfo(feat.dtype).min
     for l in range(cfg["bert_layers"]):
@@ -580,6 +593,9 @@ def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None):
     out = go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask)
     out_mtm = mlm_head(sd, out[:, Lv:])
     out_mvm = out[:, :Lv]
+    out_smtm = None
+    if "smtm" in cfg.get("pretrain_tasks", ()):              # main_pretrain.py:238-240
+        out_smtm = mlm_head(sd, go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask, seq2seq=True)[:, Lv:])
     if negatives is None:
         negatives = vtm_negatives_default(B)
     ii, jj = [], []
@@ -589,7 +605,7 @@ def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None):
             ii.append(i); jj.append(int(negatives[i][k]))
     out2 = go_cross(sd, cfg, feat_img[ii], mask_img[ii], feat_txt[jj], mask[jj])
     out_vtm = vtm_head(sd, out2[:, Lv, :], cfg["temp"]).reshape(B, O)
-    return dict(out_vtm=out_vtm, out_mvm=out_mvm, out_mtm=out_mtm, feat_img=feat_img, feat_txt=feat_txt,
+    return dict(out_vtm=out_vtm, out_mvm=out_mvm, out_mtm=out_mtm, out_smtm=out_smtm, feat_img=feat_img, feat_txt=feat_txt,
                 ans_vtm=torch.zeros(B, dtype=torch.long))
 
 
@@ -796,7 +812,13 @@ def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
         lf, pred_f, tgt_f = feature_loss(sd, cfg, out["out_mvm"], batch["unmask_img"], batch["mvm_mask"], batch.get("feature_target"))
         ls_mvm = ls_mvm + lf
         out["pred_feature"], out["feature_target"] = pred_f, tgt_f
-    return dict(mtm=ls_mtm, vtm=ls_vtm, mvm=ls_mvm, total=ls_mtm + ls_vtm + ls_mvm, out=out)
+    total = ls_mtm + ls_vtm + ls_mvm
+    res = dict(mtm=ls_mtm, vtm=ls_vtm, mvm=ls_mvm, out=out)
+    if out.get("out_smtm") is not None:                       # main_pretrain.py:566-568
+        res["smtm"] = cross_entropy_ignore(out["out_smtm"].flatten(0, 1), batch["ans_mtm"].flatten())
+        total = total + res["smtm"]
+    res["total"] = total
+    return res
 
 
 # ----------------------------------------------------------------------------

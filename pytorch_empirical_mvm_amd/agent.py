@@ -183,7 +183,8 @@ class Agent_Pretrain:
             return r
         if not sync:
             return losses
-        return {"mtm": float(losses["mtm"].item()), "mvm": float(losses["mvm"].item()), "vtm": float(losses["vtm"].item()), "smtm": -1}
+        smtm = float(losses["smtm"].item()) if "smtm" in self.args.get("pretrain_tasks", ()) else -1
+        return {"mtm": float(losses["mtm"].item()), "mvm": float(losses["mvm"].item()), "vtm": float(losses["vtm"].item()), "smtm": smtm}
 
     def go_dl(self, ep, dl, is_train):
         """main_pretrain.py:588-610 : one pass over a loader of {img, txt, mask} batches; returns rank-averaged means."""

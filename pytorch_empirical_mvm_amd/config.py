@@ -69,6 +69,7 @@ def model_cfg(args):
                dvae_hid=args.get("dvae_hid", 256), dvae_vocab=args.get("dvae_vocab", 8192))
     # frozen feature teachers of the '3d_feature' / '2d_feature' targets are always the "base" size (main_pretrain.py:157,168)
     cfg["teacher_arch"] = dict(args["teacher_arch_override"]) if args.get("teacher_arch_override") else dict(ARCH["base"])
+    cfg["pretrain_tasks"] = tuple(args.get("pretrain_tasks", ("vtm", "mlm", "mvm")))      # "smtm" adds the seq2seq MLM pass
     return cfg
 
 

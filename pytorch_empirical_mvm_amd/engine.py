@@ -412,7 +412,7 @@ class VioletEngine:
         return out, Lv, hw
 
     # -------------------------------------------------------------- fusion encoder
-    def _bert_layer(self, xv, nseq, Lq, keymask, l, train):
+    def _bert_layer(self, xv, nseq, Lq, keymask, l, train, causal_from=0):
         S, dev = self.store, self.device
         pre = f"trsfr.layer.{l}."
         Hd, nh = self.cfg["hidden"], CFG.BERT["heads"]
@@ -426,7 +426,7 @@ class VioletEngine:
         x = xv.t
         qkv = K.gemm(x, Wqkv, bias=bqkv)
         o_att = self._next_offset(nseq * nh * Lq * Lq)
-        akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att)
+        akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att, causal_from=causal_from)
         ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), **akw)
         o1 = self._next_offset(M * Hd)
         a = K.gemm(ctx, S.b(pre + "attention.output.dense.weight"), bias=S.p(pre + "attention.output.dense.bias"), resid=x,
@@ -457,14 +457,15 @@ class VioletEngine:
         self.tape.append(bwd)
         return out
 
-    def go_cross(self, pool, idx, keymask, nseq, Lq, train):
-        """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214)."""
+    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0):
+        """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214).
+        causal_from = Lv: the seq2seq mask of the smtm pass (main_pretrain.py:217-224, model.py:191-199)."""
         Hd = self.cfg["hidden"]
         x = K.gather_rows(pool.t, idx, nseq * Lq)
         xv = V(x)
         cur = xv
         for l in range(self.cfg["bert_layers"]):
-            cur = self._bert_layer(cur, nseq, Lq, keymask, l, train)
+            cur = self._bert_layer(cur, nseq, Lq, keymask, l, train, causal_from)
         return cur, xv, idx
 
     # -------------------------------------------------------------- full step
@@ -506,27 +507,48 @@ class VioletEngine:
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
         out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
-        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature", "mvm_hog")}
+        use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
+        if use_smtm:                            # third pass under the seq2seq mask (main_pretrain.py:238-240)
+            out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train, causal_from=Lv)
+        losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature", "mvm_hog", "smtm")}
         outs = {}
 
-        # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560)
+        # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560) -- also the head of the smtm pass (:240,:567)
         pm = "fc_mtm.predictions."
         Vv = cfg["vocab"]
         Vpad = -(-Vv // 8) * 8
         txt_rows = self._cached(("txt_rows", B, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(B)]), dev))
-        r_m = K.gather_rows(out1.t, txt_rows, B * X)
-        u_m = torch.empty((B * X, Hd), device=dev, dtype=BF16)
-        t_m = K.gemm(r_m, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_m)
         gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
-        tn, mean_m, rstd_m = K.layernorm_fwd(t_m, gm, bm, CFG.BERT["eps"])
         Wdec = S.b(pm + "decoder.weight")
         Nlog = -(-Vv // 4) * 4
-        logits = torch.empty((B * X, Vpad), device=dev, dtype=F32)
-        K.gemm(tn, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=logits)
         tgt_m = ans_mtm.reshape(-1).contiguous()
-        dlog = K.cross_entropy(logits, Vv, tgt_m, losses["mtm"], want_grad=backward, ld_d=Vpad)
+
+        def mlm_head(outv, loss):
+            r_ = K.gather_rows(outv.t, txt_rows, B * X)
+            u_ = torch.empty((B * X, Hd), device=dev, dtype=BF16)
+            t_ = K.gemm(r_, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
+            tn_, mean_, rstd_ = K.layernorm_fwd(t_, gm, bm, CFG.BERT["eps"])
+            lg_ = torch.empty((B * X, Vpad), device=dev, dtype=F32)
+            K.gemm(tn_, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=lg_)
+            dlog_ = K.cross_entropy(lg_, Vv, tgt_m, loss, want_grad=backward, ld_d=Vpad)
+            return dict(r=r_, u=u_, t=t_, tn=tn_, mean=mean_, rstd=rstd_, logits=lg_, dlog=dlog_)
+
+        def mlm_head_bwd(hd, dx_out):
+            """head gradients (accumulated into the shared fc_mtm.* tensors) ; d(text rows of the encoder output) -> dx_out"""
+            K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
+            K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
+            dtn = K.gemm(hd["dlog"], Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
+            dt_, _ = K.layernorm_bwd(dtn, hd["t"], gm, hd["mean"], hd["rstd"], S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
+            du_ = K.gelu_bwd(dt_, hd["u"])
+            self._linear_bwd(du_, hd["r"], pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dx_out))
+
+        h_mlm = mlm_head(out1, losses["mtm"])
+        if use_smtm:
+            h_smtm = mlm_head(out3, losses["smtm"])
         if want_outputs:
-            outs["out_mtm"] = logits[:, :Vv].reshape(B, X, Vv)
+            outs["out_mtm"] = h_mlm["logits"][:, :Vv].reshape(B, X, Vv)
+            if use_smtm:
+                outs["out_smtm"] = h_smtm["logits"][:, :Vv].reshape(B, X, Vv)
 
         # ---- VTM head (main_pretrain.py:146-147,260-262,561)
         cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
@@ -645,12 +667,12 @@ class VioletEngine:
                 K.add_bf16(dcat[:npx], dr_f, out=dcat[:npx])
             else:
                 dcat[:npx].copy_(dr_f)
-        K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
-        K.gemm(dlog, tn, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
-        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
-        dt_m, _ = K.layernorm_bwd(dtn, t_m, gm, mean_m, rstd_m, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
-        du_m = K.gelu_bwd(dt_m, u_m)
-        self._linear_bwd(du_m, r_m, pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dcat[npx:]))
+        mlm_head_bwd(h_mlm, dcat[npx:])
+        if use_smtm:
+            d3 = torch.empty((B * X, Hd), device=dev, dtype=BF16)
+            mlm_head_bwd(h_smtm, d3)
+            inv3 = self._cached(("inv3", B, Lq, Lv, X), lambda: self._inverse_rows(B * Lq, [txt_rows]))
+            out3.g = K.gather_rows(d3, inv3, B * Lq)
         inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X, use_vis), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows] if use_vis else [txt_rows]))
         out1.g = K.gather_rows(dcat, inv1, B * Lq)
         if use_vq and n_mp > 0:
@@ -675,11 +697,13 @@ class VioletEngine:
 
         # encoders (tape holds: encode, pass-1 layers, pass-2 layers) -> run pass 2 and pass 1, then scatter into the pool
         n_layers = cfg["bert_layers"]
-        for _ in range(2 * n_layers):
+        for _ in range((3 if use_smtm else 2) * n_layers):
             self.tape.pop()()
         dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
         K.scatter_add_rows(in1.g, idx1_d, dpool)
         K.scatter_add_rows(in2.g, idx2_d, dpool)
+        if use_smtm:
+            K.scatter_add_rows(in3.g, idx1_d, dpool)
         pool.g = K.cast_bf16(dpool)
         self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
         if on_other_grads_ready is not None:

@@ -227,3 +227,25 @@ def test_hog_target_head_and_loss():
     np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
     for k in ("decoder_hog.0.weight", "decoder_hog.0.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.timeout(600)
+def test_smtm_seq2seq_pass():
+    """the smtm task (third fusion pass under the seq2seq attention mask + MLM head + CE) against the reference's
+    VIOLET_Pretrain.forward / get_smtm_output / get_attn_mask("seq2seq")."""
+    d = load("smtm.npz")
+    cfg = R.make_cfg("tiny", T=4, pretrain_tasks=("vtm", "mlm", "mvm", "smtm"))
+    sd = R.make_state_dict(cfg)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 2)
+    batch = R.default_masking(cfg, img, txt, mask, seed=5)
+    ls = R.pretrain_losses(params, cfg, batch, negatives=d["neg"])
+    for k in ("mtm", "vtm", "mvm", "smtm"):
+        np.testing.assert_allclose(float(ls[k].detach()), float(d["ls_" + k]), rtol=1e-5)
+    check_samp(d, "out_smtm", ls["out"]["out_smtm"], rtol=2e-3, atol=2e-4)
+    ls["total"].backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-4)
+    for k in [k for k in d.files if k.startswith("g.") and k.endswith(".val")]:
+        name = k[2:-4]
+        check_samp(d, "g." + name, params[name].grad, rtol=5e-3, atol=2e-6)

@@ -484,6 +484,64 @@ def gold_hog(size="tiny", T=4, B=2, S=224):
     print("hog ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), "gn", gsq ** 0.5)
 
 
+def gold_smtm(size="tiny", T=4, B=2):
+    """the smtm task -- a third fusion pass under the seq2seq attention mask (get_smtm_output main_pretrain.py:217-224,
+    get_attn_mask model.py:191-199) + the MLM head, through the reference's own VIOLET_Pretrain.forward / step arithmetic."""
+    import main_pretrain as mp
+    cfg = R.make_cfg(size, T=T, pretrain_tasks=("vtm", "mlm", "mvm", "smtm"))
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    args.update(pretrain_tasks=["vtm", "mlm", "mvm", "smtm"])
+    model = mp.VIOLET_Pretrain(args, None).eval()
+    # API-drift shims (SURVEY 8c import recipe, step 6): Transformers-4.26 mask_ext semantics and BertEncoder call signature
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": ()}
+    model.trsfr.forward = trsfr_forward
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    calls = {"i": 0}
+    def fake_perm(lst):
+        i = calls["i"]; calls["i"] += 1
+        rest = [j for j in lst if j not in list(neg[i])]
+        return np.array(list(neg[i]) + rest)
+    mp.np.random.permutation = fake_perm
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    batch = dict(mb)
+    out = model(batch)
+    assert out["out_smtm"] is not None
+    ls_mtm = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    ls_vtm = agent.loss_func(out["out_vtm"], out["ans_vtm"])
+    ls_mvm = agent.calc_mvm_loss(batch, out["out_mvm"], is_train=True)
+    ls_smtm = agent.loss_func(out["out_smtm"].flatten(0, 1), out["ans_mtm"].flatten())
+    (ls_mtm + ls_vtm + ls_mvm + ls_smtm).backward()
+    d = dict(ls_mtm=np.array(float(ls_mtm.detach())), ls_vtm=np.array(float(ls_vtm.detach())), ls_mvm=np.array(float(ls_mvm.detach())),
+             ls_smtm=np.array(float(ls_smtm.detach())), neg=neg)
+    put(d, "out_smtm", out["out_smtm"], 256)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("trsfr.layer.0.attention.self") or k.startswith("fc_mtm.predictions.transform.dense"):
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, "smtm.npz"), **d)
+    print("smtm ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), float(ls_smtm), "gn", gsq ** 0.5)
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -557,6 +615,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--smtm-only" in sys.argv:
+        gold_smtm()
+        sys.exit(0)
     if "--hog-only" in sys.argv:
         gold_hog()
         sys.exit(0)
@@ -576,3 +637,4 @@ if __name__ == "__main__":
     gold_feature("3d_feature")
     gold_feature("2d_feature")
     gold_hog()
+    gold_smtm()
