@@ -157,6 +157,11 @@ typedef struct {
    * visible only to queries q >= causal_from with key <= q (lower triangle; the text padding mask is NOT applied there, as in the
    * reference).  Resident kernels only (L <= 448). */
   int32_t causal_from;
+  /* mode 1 forward only, NULL = off: att_colsum f32 [nseq][L] ACCUMULATED += att_scale * sum_heads sum_queries P[q][key] (P after
+   * attention dropout = HF's `attentions`).  With att_scale = 1/heads and the same buffer passed to every layer this is
+   * VIOLET_Pretrain.get_att's `cat([a.mean(dim=1, keepdim=True) ...]).sum(dim=(1, 2))` (main_pretrain.py:211-215), the sampling
+   * weights of the attention-guided 'am' masking, without materialising attentions.  Resident kernels only (L <= 448). */
+  float* att_colsum; float att_scale;
 } vmvm_attn_fwd_desc;
 int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
 

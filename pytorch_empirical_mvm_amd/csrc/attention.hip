@@ -201,7 +201,10 @@ __device__ __forceinline__ uint4 quad_bcast_i(const uint4& b, int i) {   // i is
 #define KEY_OK(t, key) ((NX && (t) < NX - 1) ? true : ((key) < L))
 // CAUSAL (mode 1, `causal_from` = cf > 0): the seq2seq mask of VIOLET_Base.get_attn_mask (model.py:191-199) -- keys below cf (the
 // visual tokens) follow the key mask for every query; a key >= cf (text) is visible only to text queries at or after it.
-template <int HD, int MODE, int NT_MAX, int NW, int NX, bool MASK, bool CAUSAL = false>
+// COLSUM (mode 1, `att_colsum` set): also accumulates att_colsum[seq][key] += att_scale * sum_q P[q][key] over the heads -- the
+// layer- and head-averaged attention column sums of VIOLET_Pretrain.get_att (main_pretrain.py:211-215, attention-guided masking)
+// without materialising any attention matrix.  P is what HF returns as `attentions`: the probabilities AFTER attention dropout.
+template <int HD, int MODE, int NT_MAX, int NW, int NX, bool MASK, bool CAUSAL = false, bool COLSUM = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,6 +320,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           const uint32_t w = u4_get(blk, q & 3);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
+        }
+      }
+    }
+    if (COLSUM) {                                       // 16 queries of the tile live in one 16-lane row: xor-shuffles 1..8 stay inside it
+      const float wq = qv ? p.att_scale / sum : 0.f;
+      float* cs = p.att_colsum + (size_t)seq * L;
+#pragma unroll
+      for (int t = 0; t < NT_MAX; ++t) {
+        if (TILE_ON(t)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[t][j] * wq;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int key = t * 16 + g * 4 + j;
+            if (r == 0 && key < L) atomicAdd(cs + key, v);
+          }
         }
       }
     }
@@ -2106,6 +2125,8 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
   if (d->region && d->n_win <= 0) return VMVM_EINVAL;
   if (d->seq_scale && d->seqs_per_scale <= 0) return VMVM_EINVAL;
   if (d->causal_from < 0 || (d->causal_from > 0 && d->mode != 1)) return VMVM_EINVAL;
+  if (d->att_colsum && (d->mode != 1 || d->causal_from > 0)) return VMVM_EINVAL;
+  if (d->att_colsum && (d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len))) return VMVM_ENOSUPPORT;
   if (d->causal_from > 0 && (d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len))) return VMVM_ENOSUPPORT;   // no streaming seq2seq build
   return VMVM_OK;
 }
@@ -2174,7 +2195,12 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   } else {
     // (exact-NT instantiations of the head_dim-64 kernel need the compiler barrier in the score loop: hoisted en bloc, the K
     //  fragment loads of 27 unguarded tiles exceed 256 VGPRs)
-    if (d->causal_from > 0) {                                       // seq2seq mask (smtm pass): generic tile loops
+    if (d->att_colsum) {                                            // get_att pass: + attention column sums
+      int rc_ = set_smem(attn_fwd_kernel<64, 1, 28, 8, 0, true, false, true>, sm.total);
+      if (rc_) return rc_;
+      hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 28, 8, 0, true, false, true>), dim3(nb), dim3(8 * 64), sm.total, st, *d);
+    }
+    else if (d->causal_from > 0) {                                  // seq2seq mask (smtm pass): generic tile loops
       int rc_ = set_smem(attn_fwd_kernel<64, 1, 28, 8, 0, true, true>, sm.total);
       if (rc_) return rc_;
       hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 28, 8, 0, true, true>), dim3(nb), dim3(8 * 64), sm.total, st, *d);

@@ -114,7 +114,7 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
 
 
 def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
-               keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len=0, causal_from=0):
+               keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len=0, causal_from=0, att_colsum=None):
     d = L.AttnFwdDesc()
     d.qkv, d.ld_qkv, d.q_off, d.k_off, d.v_off = qkv.data_ptr(), _ld(qkv), q_off, k_off, v_off
     d.out, d.ld_out, d.lse = out.data_ptr(), _ld(out), lse.data_ptr()
@@ -127,15 +127,16 @@ def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_
     d.seq_scale, d.seqs_per_scale = L.ptr(seq_scale), seqs_per_scale
     d.stream_min_len = stream_min_len
     d.causal_from = causal_from
+    d.att_colsum, d.att_scale = L.ptr(att_colsum), 1.0 / heads
     return d
 
 
 def attention_fwd(qkv, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0, region=None,
-                  n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0, stream_min_len=0, causal_from=0):
+                  n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0, stream_min_len=0, causal_from=0, att_colsum=None):
     out = torch.empty((nseq * Lq, heads * hd), device=qkv.device, dtype=BF16)
     lse = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
     d = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
-                   keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from)
+                   keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, att_colsum)
     L.check(L.load().vmvm_attention_fwd(C.byref(d), L.stream()), "attention_fwd")
     return out, lse
 

@@ -537,6 +537,35 @@ def check_attn_seq2seq():
         rep(tag + " bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
 
 
+def check_attn_colsum():
+    """get_att's attention column sums (main_pretrain.py:211-215) from the forward kernel: sum over queries of the head-averaged
+    probabilities, accumulated over calls (layers), against fp32 PyTorch; the attention output itself must not change."""
+    for (nseq, Lq, heads) in [(3, 232, 4), (2, 432, 12)]:
+        Hd = heads * 64
+        km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+        km[1, Lq - 9:] = 0
+        cs = torch.zeros(nseq, Lq, device=dev)
+        ref_cs = torch.zeros(nseq, Lq, device=dev)
+        for layer in range(2):
+            qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+            out0, _ = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km)
+            out1, _ = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, att_colsum=cs)
+            x = qkv.float().view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+            bias = torch.where(km.bool(), 0.0, float("-inf"))[:, None, None, :]
+            P = ((x[0] * 0.125) @ x[1].transpose(-1, -2) + bias).softmax(-1)
+            ref_cs += P.mean(dim=1).sum(dim=1)
+            rep(f"colsum pass leaves the output alone L={Lq} layer {layer}", out1, out0, tol=1e-6)
+        rep(f"attention column sums nseq={nseq} L={Lq} h={heads} (2 layers)", cs, ref_cs, tol=5e-3)
+    # with dropout the expectation is unchanged: sum over keys = number of queries per layer (within a few %)
+    nseq, Lq, heads = 2, 432, 12
+    Hd = heads * 64
+    qkv = rnd(nseq * Lq, 3 * Hd, scale=1.0)
+    cs = torch.zeros(nseq, Lq, device=dev)
+    K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=5, offset=77, att_colsum=cs)
+    tot = cs.sum(1)
+    rep("column sums under dropout: total mass ~ L", tot, torch.full_like(tot, float(Lq)), tol=2e-2)
+
+
 # ------------------------------------------------------------------ misc
 def check_misc():
     B, T, H, W = 2, 4, 64, 96
@@ -772,9 +801,9 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "misc", "bench"]
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "attna", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, misc=check_misc)
+                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, misc=check_misc)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
