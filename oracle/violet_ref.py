@@ -518,8 +518,9 @@ def enc_txt(sd, txt):
     return layer_norm(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], BERT["eps"])
 
 
-def bert_layer(sd, p, x, add_mask):
-    """HF BertLayer (post-LN), eval mode; call site model.py:213"""
+def bert_layer(sd, p, x, add_mask, probs_out=None):
+    """HF BertLayer (post-LN), eval mode; call site model.py:213.  probs_out: list receiving the attention probabilities
+    (B, heads, L, L) -- HF's `attentions` (output_attentions=True, model.py:213)"""
     B, L, H = x.shape
     nh, hd = BERT["heads"], H // BERT["heads"]
     q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
@@ -527,7 +528,10 @@ def bert_layer(sd, p, x, add_mask):
     v = F.linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"])
     q, k, v = (t.view(B, L, nh, hd).transpose(1, 2) for t in (q, k, v))
     s = q @ k.transpose(-1, -2) / math.sqrt(hd) + add_mask
-    a = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, L, H)
+    pr = s.softmax(-1)
+    if probs_out is not None:
+        probs_out.append(pr)
+    a = (pr @ v).transpose(1, 2).reshape(B, L, H)
     a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
     x = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], BERT["eps"])
     y = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
@@ -555,6 +559,53 @@ def go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask_txt, seq2seq=False):
     for l in range(cfg["bert_layers"]):
         feat = bert_layer(sd, f"trsfr.layer.{l}.", feat, add)
     return feat
+
+
+def get_att(sd, cfg, img, txt, mask):
+    """VIOLET_Pretrain.get_att main_pretrain.py:211-215 (eval mode): layer-summed, head-averaged attention column sums (B, L) --
+    the sampling weights of the attention-guided 'am' masking (:320-343)."""
+    feat_img, mask_img = enc_video(sd, cfg, img)
+    feat_txt = enc_txt(sd, txt)
+    feat = torch.cat([feat_img, feat_txt], dim=1)
+    m = torch.cat([mask_img, mask], dim=1)
+    add = (1.0 - m[:, None, None, :].to(feat.dtype)) * torch.finfo(feat.dtype).min
+    probs = []
+    for l in range(cfg["bert_layers"]):
+        feat = bert_layer(sd, f"trsfr.layer.{l}.", feat, add, probs)
+    att = torch.cat([a.mean(dim=1, keepdim=True) for a in probs], dim=1).sum(dim=(1, 2))
+    return feat_img, att
+
+
+def am_masking(cfg, img, txt, mask, att, p_mask=0.15, generator=None):
+    """The 'am' branch of Agent_Pretrain.masking (main_pretrain.py:320-343,354-364) for every sample, given the attention weights:
+    zero the special positions, draw int(L * p) positions without replacement (torch.multinomial), split them into patch and
+    token positions.  Returns the batch dict of apply_masking plus `failed` (no text position drawn -> the reference falls back
+    to 'rm' for that sample and, by its sticky flag, every later one)."""
+    B, T, _, H, W = img.shape
+    h, w = H // cfg["size_patch"], W // cfg["size_patch"]
+    X = txt.shape[1]
+    Lv = (1 + h * w) * T
+    spc_txt = (txt == SPECIAL["cls"]) | (txt == SPECIAL["sep"]) | (txt == SPECIAL["pad"]) | (txt == SPECIAL["mask"])
+    spc_v = torch.tensor(sum([[True] + [False] * (h * w) for _ in range(T)], []))
+    sel = torch.zeros(B, X, dtype=torch.bool)
+    cov = torch.zeros(B, T, h, w)
+    failed = []
+    for i in range(B):
+        a = att[i].clone().float()
+        a[torch.cat([spc_v, spc_txt[i]])] = 0.0
+        pos = torch.multinomial(a, int((Lv + X) * p_mask), generator=generator).numpy()
+        n_txt = 0
+        for p_ in pos:
+            if p_ < Lv:
+                i_t, q = p_ // (1 + h * w), p_ % (1 + h * w) - 1
+                cov[i, i_t, q // w, q % w] = 1.0
+            else:
+                sel[i, p_ - Lv] = True
+                n_txt += 1
+        failed.append(n_txt == 0)
+    out = apply_masking(img, txt, mask, sel, cov, cfg["size_patch"])
+    out["cov"], out["failed"] = cov, failed
+    return out
 
 
 def mlm_head(sd, x):

@@ -58,21 +58,47 @@ class Agent_Pretrain:
         spc = (txt == self.cls_token_id) | (txt == self.sep_token_id) | (txt == self.pad_token_id) | (txt == self.mask_token_id)
         ans_mtm = torch.full_like(txt, -1)
         cov = torch.zeros(B, T, h, w, dtype=torch.uint8)
+        Lv = (1 + h * w) * T
+        att_all = None                       # get_att's weights for the whole batch (the reference recomputes them per 'am' sample, :321-324)
+        failed_masking = False               # sticky across the batch, as in the reference (:300, :342-343)
         if p_mask > 0:
             for i in range(B):
                 mask_type = random.choice(self.args.pretrain_masks)
-                if mask_type == "am":
-                    raise NotImplementedError("attention-guided masking ('am') is outside the accelerated path (SURVEY 8f.2)")
-                sel = (~spc[i].cpu()) & (torch.rand(X) < p_mask)
-                if mask_type == "bm":
+                sel, cov_i = None, torch.zeros(T, h, w, dtype=torch.uint8)
+                if mask_type == "bm":                                    # :304-318
+                    sel = (~spc[i].cpu()) & (torch.rand(X) < p_mask)
                     for _ in range(T):
                         t = np.random.randint(1, T) if T > 1 else 1
                         hh, ww = np.random.randint(1, h * 2 // 3), np.random.randint(1, w * 2 // 3)
                         t1, h1, w1 = np.random.randint(0, T - t + 1), np.random.randint(0, h - hh + 1), np.random.randint(0, w - ww + 1)
-                        cov[i, t1:t1 + t, h1:h1 + hh, w1:w1 + ww] = 1
-                else:
+                        cov_i[t1:t1 + t, h1:h1 + hh, w1:w1 + ww] = 1
+                if mask_type == "am":
+                    # attention-guided masking (:320-343): positions drawn without replacement with the layer- and head-averaged
+                    # attention mass each position receives; special positions (per-frame cls, [CLS]/[SEP]/pad/[MASK]) excluded.
+                    # The weights come from the HIP path (attention kernels with the column-sum output, one pass for the whole
+                    # batch), the draw is torch.multinomial on the CPU generator.
+                    if att_all is None:
+                        att_all = self.model.get_att(img, txt, mask)[1].detach().float().cpu()
+                    a = att_all[i].clone()
+                    spc_v = torch.tensor(sum([[True] + [False] * (h * w) for _ in range(T)], []))
+                    a[torch.cat([spc_v, spc[i].cpu()])] = 0.0
+                    try:
+                        pos = torch.multinomial(a, int((Lv + X) * p_mask)).numpy()
+                        sel = torch.zeros(X, dtype=torch.bool)
+                        for p_ in pos:
+                            if p_ < Lv:
+                                i_t, q = p_ // (1 + h * w), p_ % (1 + h * w) - 1
+                                cov_i[i_t, q // w, q % w] = 1
+                            else:
+                                sel[p_ - Lv] = True
+                        failed_masking = not bool(sel.any())
+                    except Exception:
+                        failed_masking = True
+                if mask_type == "rm" or failed_masking:                  # :344-352 (also the fallback of a failed 'am' draw)
+                    sel = (~spc[i].cpu()) & (torch.rand(X) < p_mask)
                     r = torch.rand((1 + h * w) * T) < p_mask
-                    cov[i] = r.view(T, 1 + h * w)[:, 1:].reshape(T, h, w).to(torch.uint8)
+                    cov_i = r.view(T, 1 + h * w)[:, 1:].reshape(T, h, w).to(torch.uint8)
+                cov[i] = cov_i
                 sel = sel.to(txt.device)
                 ans_mtm[i] = torch.where(sel, txt[i], ans_mtm[i])
                 txt[i] = torch.where(sel, torch.full_like(txt[i], self.mask_token_id), txt[i])

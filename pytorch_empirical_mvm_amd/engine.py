@@ -412,7 +412,7 @@ class VioletEngine:
         return out, Lv, hw
 
     # -------------------------------------------------------------- fusion encoder
-    def _bert_layer(self, xv, nseq, Lq, keymask, l, train, causal_from=0):
+    def _bert_layer(self, xv, nseq, Lq, keymask, l, train, causal_from=0, att_out=None):
         S, dev = self.store, self.device
         pre = f"trsfr.layer.{l}."
         Hd, nh = self.cfg["hidden"], CFG.BERT["heads"]
@@ -427,7 +427,7 @@ class VioletEngine:
         qkv = K.gemm(x, Wqkv, bias=bqkv)
         o_att = self._next_offset(nseq * nh * Lq * Lq)
         akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att, causal_from=causal_from)
-        ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), **akw)
+        ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), att_colsum=att_out, **akw)
         o1 = self._next_offset(M * Hd)
         a = K.gemm(ctx, S.b(pre + "attention.output.dense.weight"), bias=S.p(pre + "attention.output.dense.bias"), resid=x,
                    dropout_p=p_h, seed=self.seed, offset=o1)
@@ -457,7 +457,7 @@ class VioletEngine:
         self.tape.append(bwd)
         return out
 
-    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0):
+    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0, att_out=None):
         """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214).
         causal_from = Lv: the seq2seq mask of the smtm pass (main_pretrain.py:217-224, model.py:191-199)."""
         Hd = self.cfg["hidden"]
@@ -465,8 +465,29 @@ class VioletEngine:
         xv = V(x)
         cur = xv
         for l in range(self.cfg["bert_layers"]):
-            cur = self._bert_layer(cur, nseq, Lq, keymask, l, train, causal_from)
+            cur = self._bert_layer(cur, nseq, Lq, keymask, l, train, causal_from, att_out)
         return cur, xv, idx
+
+    @torch.no_grad()
+    def get_att(self, img, txt, mask, train=True, dp_all=None):
+        """VIOLET_Pretrain.get_att (main_pretrain.py:211-215): one (img_i, txt_i) fusion pass whose attention kernels also
+        accumulate the head-averaged column sums of every layer -> (B, T*(1+hw)+X) f32, the sampling weights of the 'am' masking.
+        `train` keeps dropout / DropPath on, as the reference calls it from masking() with the model in train mode."""
+        dev = self.device
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        saved, self.tape = self.tape, []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(B)
+        pool, Lv, hw = self.encode(img.to(dev, F32).contiguous(), None, txt.to(dev).contiguous(), dp_all, train)
+        Lq = Lv + X
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx1 = _dev_i32(np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)]), dev)
+        km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), (mask.to(dev) != 0).to(torch.uint8)], 1).contiguous()
+        att = torch.zeros((B, Lq), device=dev, dtype=F32)
+        self.go_cross(pool, idx1, km1, B, Lq, train, att_out=att)
+        self.tape = saved
+        return att
 
     # -------------------------------------------------------------- full step
     def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,

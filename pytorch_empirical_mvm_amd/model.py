@@ -114,6 +114,11 @@ class VIOLET_Pretrain(torch.nn.Module):
             sd[name] = t
         self.engine.store.load_state(sd)
 
+    @torch.no_grad()
+    def get_att(self, img, txt, mask, odr=None):
+        """main_pretrain.py:211-215 -> (feat_img placeholder None, att (B, L)); the reference's callers only use `att`"""
+        return None, self.engine.get_att(img, txt, mask, train=self.training)
+
     def state_dict(self, *a, **k):
         sd = super().state_dict(*a, **k)
         key = "fc_mtm.predictions.bias"

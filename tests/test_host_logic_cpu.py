@@ -146,3 +146,39 @@ def test_masking_from_uniform_matches_reference_distributions():
     # mvm_mask is the x32 expansion of cov and img is zeroed under it (main_pretrain.py:362-364)
     assert torch.equal(o["mvm_mask"][:, :, 0, ::32, ::32], o["cov"])
     assert float((o["img"] * o["mvm_mask"]).abs().max()) == 0.0
+
+
+def test_agent_am_masking_reproduces_reference_branch():
+    """The attention-guided 'am' branch of Agent_Pretrain.masking (main_pretrain.py:320-343) for fixed attention weights and a
+    fixed torch seed, against what the reference's masking() produced (tests/golden/am.npz); then the fallback to 'rm' when the
+    draw contains no text position (the reference's sticky `failed_masking`)."""
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, "am.npz"))
+    cfg = R.make_cfg("tiny", T=4)
+    img, txt, mask = R.make_batch(cfg, 2)
+    fake = torch.from_numpy(d["fake"])
+
+    class _Model:
+        def __init__(self, att):
+            self.att = att
+
+        def get_att(self, *a, **k):
+            return None, self.att.clone()
+    args = CFG.get_args(pretrain_masks=["am"])
+    ag = Agent_Pretrain.__new__(Agent_Pretrain)
+    ag.args, ag.patch_size, ag.model = args, 32, _Model(fake)
+    ag.cls_token_id, ag.sep_token_id, ag.pad_token_id, ag.mask_token_id = 101, 102, 0, 103
+    random.seed(7); np.random.seed(7); torch.manual_seed(7)
+    o = ag.masking(img.clone(), txt.clone(), mask.clone(), None)
+    np.testing.assert_array_equal(o["txt"].numpy(), d["am_txt"])
+    np.testing.assert_array_equal(o["ans_mtm"].numpy(), d["am_ans_mtm"])
+    np.testing.assert_array_equal(o["cov"].numpy(), d["am_cov"])
+    n = int(((1 + 49) * 4 + 32) * 0.15)
+    for i in range(2):
+        assert int(o["cov"][i].sum()) + int((o["ans_mtm"][i] != -1).sum()) == n
+    # all weight on the visual positions -> no text position can be drawn -> 'rm' fallback (Bernoulli field, ~15 % cover)
+    vis_only = fake.clone(); vis_only[:, 200:] = 0.0
+    ag.model = _Model(vis_only)
+    torch.manual_seed(3)
+    o2 = ag.masking(img.clone(), txt.clone(), mask.clone(), None)
+    assert 0.05 < float(o2["cov"].float().mean()) < 0.3

@@ -249,3 +249,22 @@ def test_smtm_seq2seq_pass():
     for k in [k for k in d.files if k.startswith("g.") and k.endswith(".val")]:
         name = k[2:-4]
         check_samp(d, "g." + name, params[name].grad, rtol=5e-3, atol=2e-6)
+
+
+@pytest.mark.timeout(600)
+def test_attention_guided_masking():
+    """SURVEY 8f.2 'am': get_att's attention column sums (reference: VIOLET_Pretrain.get_att with HF BertSelfAttention's own
+    probabilities) and the 'am' branch of Agent_Pretrain.masking for fixed weights and a fixed torch seed."""
+    d = load("am.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    sd = R.make_state_dict(cfg)
+    img, txt, mask = R.make_batch(cfg, 2)
+    with torch.no_grad():
+        _, att = R.get_att(sd, cfg, img, txt, mask)
+    np.testing.assert_allclose(att.numpy(), d["att"], rtol=2e-4, atol=2e-4)
+    torch.manual_seed(7)
+    o = R.am_masking(cfg, img, txt, mask, torch.from_numpy(d["fake"]))
+    assert not any(o["failed"])
+    np.testing.assert_array_equal(o["txt"].numpy(), d["am_txt"])
+    np.testing.assert_array_equal(o["ans_mtm"].numpy(), d["am_ans_mtm"])
+    np.testing.assert_array_equal(o["cov"].numpy().astype(np.uint8), d["am_cov"])

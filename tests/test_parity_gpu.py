@@ -549,3 +549,34 @@ def test_smtm_pass_vs_reference_golden():
     masked = dict(mb); masked.update(cov=cov, unmask_img=img)
     r = agent.step(agent.prepare_batch(masked), is_train=True)
     assert all(np.isfinite(v) for v in r.values()) and r["smtm"] > 0, r
+
+
+def test_get_att_and_attention_guided_masking():
+    """SURVEY 8f.2 'am': get_att on the HIP path (attention kernels with the column-sum output, no attention matrix in memory)
+    against the weights the REFERENCE's get_att produced (am.npz, eval mode), then a train step on an 'am'-masked batch."""
+    import random
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    d = np.load(os.path.join(G, "am.npz"))
+    cfg = R.make_cfg("tiny", T=4)
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, pretrain_masks=["am"]))
+    model.load_state_dict(R.make_state_dict(cfg))
+    img, txt, mask = R.make_batch(cfg, 2)
+    model.eval()
+    _, att = model.get_att(img.cuda(), txt.cuda(), mask.cuda())
+    att = att.cpu().double().numpy()
+    ref = d["att"]
+    assert att.shape == ref.shape == (2, 232)
+    np.testing.assert_allclose(att.sum(1), ref.sum(1), rtol=1e-3)          # 12 layers x 232 queries of unit mass
+    assert np.abs(att - ref).max() <= 3e-2 * ref.max(), (np.abs(att - ref).max(), ref.max())
+    assert float(np.corrcoef(att.flatten(), ref.flatten())[0, 1]) >= 0.999
+    model.train()
+    agent = Agent_Pretrain(args, model)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    mb = agent.masking(img, txt, mask, None)
+    n = int(((1 + 49) * 4 + 32) * 0.15)
+    for i in range(2):
+        tot = int(mb["cov"][i].sum()) + int((mb["ans_mtm"][i] != -1).sum())
+        assert tot == n or 0.05 < float(mb["cov"][i].float().mean()) < 0.3, tot       # 'am' draw, or its 'rm' fallback
+    r = agent.step(agent.prepare_batch(mb), is_train=True)
+    assert all(np.isfinite(v) for v in r.values()), r

@@ -10,6 +10,7 @@ oracle/violet_ref.py, so fixtures hold outputs only.
 """
 import json
 import os
+import random
 import sys
 import types
 
@@ -542,6 +543,51 @@ def gold_smtm(size="tiny", T=4, B=2):
     print("smtm ok losses", float(ls_mtm), float(ls_vtm), float(ls_mvm), float(ls_smtm), "gn", gsq ** 0.5)
 
 
+def gold_am(size="tiny", T=4, B=2):
+    """attention-guided masking.  (1) VIOLET_Pretrain.get_att (eval mode) on the C1 batch with the attention
+    probabilities taken from HF's BertSelfAttention modules (Transformers 5.15 no longer returns them from BertEncoder: forward
+    hooks on `layer.attention.self`, eager attention); (2) Agent_Pretrain.masking with every sample drawn as 'am' and get_att
+    replaced by a closed-form weight vector, torch seeded -- pins the position arithmetic and RNG use of the 'am' branch."""
+    import main_pretrain as mp
+    cfg = R.make_cfg(size, T=T)
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    args.update(pretrain_masks=["am"])
+    model = mp.VIOLET_Pretrain(args, None).eval()
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    caps = []
+    for lyr in model.trsfr.layer:
+        lyr.attention.self.register_forward_hook(lambda m_, i_, o_: caps.append(o_[1]))
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        caps.clear()
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": tuple(caps)}
+    model.trsfr.forward = trsfr_forward
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    with torch.no_grad():
+        _, att = model.get_att(img, txt, mask)
+    d = dict(att=att.numpy().astype(np.float64))
+    # (2) the 'am' branch of masking() with fixed weights
+    Lv, X = (1 + 49) * T, txt.shape[1]
+    fake = (1.0 + torch.sin(torch.arange(B * (Lv + X), dtype=torch.float64) * 0.37)).float().view(B, Lv + X)
+    model.get_att = lambda *a, **k: (None, fake.clone())
+    agent = mp.Agent_Pretrain.__new__(mp.Agent_Pretrain)
+    agent.args, agent.model, agent.patch_size = args, model, 32
+    agent.cls_token_id, agent.sep_token_id, agent.pad_token_id, agent.mask_token_id = 101, 102, 0, 103
+    agent.prepare_batch = lambda b: b
+    random.seed(7); np.random.seed(7); torch.manual_seed(7)
+    o = agent.masking(img.clone(), txt.clone(), mask.clone(), None)
+    d.update(fake=fake.numpy(), am_txt=o["txt"].numpy(), am_ans_mtm=o["ans_mtm"].numpy(),
+             am_cov=o["mvm_mask"][:, :, 0, ::32, ::32].numpy().astype(np.uint8))
+    np.savez_compressed(os.path.join(OUT, "am.npz"), **d)
+    print("am ok att", tuple(att.shape), float(att.sum()), "masked txt", int((o["ans_mtm"] != -1).sum()), "covered", int(d["am_cov"].sum()))
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -615,6 +661,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--am-only" in sys.argv:
+        gold_am()
+        sys.exit(0)
     if "--smtm-only" in sys.argv:
         gold_smtm()
         sys.exit(0)
@@ -638,3 +687,4 @@ if __name__ == "__main__":
     gold_feature("2d_feature")
     gold_hog()
     gold_smtm()
+    gold_am()
