@@ -131,6 +131,8 @@ def param_shapes(cfg):
     s["fc.1.bias"] = (2 * H,)
     s["fc.3.weight"] = (1, 2 * H)
     s["fc.3.bias"] = (1,)
+    if cfg.get("task", "pretrain") == "retrieval":       # VIOLET_Retrieval main_retrieval.py:56-61: VIOLET_Base + fc
+        return s
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
     s["fc_mtm.predictions.transform.dense.bias"] = (H,)
@@ -839,6 +841,30 @@ def feature_loss(sd, cfg, out_mvm, unmask_img, mvm_mask, target=None):
     m = m.view(B, T, h * w, 1)
     ls = (pred - target).abs()
     return (ls.float() * m).sum() / (m.sum() + 1e-5) / Cin, pred, target
+
+
+# ----------------------------------------------------------------------------
+# downstream: text-to-video retrieval
+# ----------------------------------------------------------------------------
+def retrieval_forward(sd, cfg, img, txt, mask):
+    """VIOLET_Retrieval.forward main_retrieval.py:63-85 (eval mode): out[i][j] = fc(fusion([img_i ; txt_j])[text CLS])"""
+    B, T, _, H, W = img.shape
+    h, w = H // 32, W // 32
+    feat_img, mask_img = enc_video(sd, cfg, img)
+    feat_txt = enc_txt(sd, txt)
+    ii = [i for i in range(B) for _ in range(B)]
+    jj = [j for _ in range(B) for j in range(B)]
+    out = go_cross(sd, cfg, feat_img[ii], mask_img[ii], feat_txt[jj], mask[jj])
+    x = out[:, (1 + h * w) * T, :]
+    x = F.relu(F.linear(x, sd["fc.1.weight"], sd["fc.1.bias"]))
+    return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"]).squeeze(-1).view(B, B)
+
+
+def norm_softmax_loss(x, temperature):
+    """NormSoftmaxLoss agent.py:34-50"""
+    i_logsm = F.log_softmax(x / temperature, dim=1)
+    j_logsm = F.log_softmax(x.t() / temperature, dim=1)
+    return -torch.diag(i_logsm).mean() - torch.diag(j_logsm).mean()
 
 
 def cross_entropy_ignore(logits, target):

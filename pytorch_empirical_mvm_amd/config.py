@@ -70,6 +70,7 @@ def model_cfg(args):
     # frozen feature teachers of the '3d_feature' / '2d_feature' targets are always the "base" size (main_pretrain.py:157,168)
     cfg["teacher_arch"] = dict(args["teacher_arch_override"]) if args.get("teacher_arch_override") else dict(ARCH["base"])
     cfg["pretrain_tasks"] = tuple(args.get("pretrain_tasks", ("vtm", "mlm", "mvm")))      # "smtm" adds the seq2seq MLM pass
+    cfg["task"] = args.get("task", "pretrain")
     return cfg
 
 
@@ -142,6 +143,8 @@ def param_shapes(cfg):
     s["fc.1.bias"] = (2 * H,)
     s["fc.3.weight"] = (1, 2 * H)
     s["fc.3.bias"] = (1,)
+    if cfg.get("task", "pretrain") == "retrieval":       # VIOLET_Retrieval (main_retrieval.py:56-61): VIOLET_Base + fc only
+        return s
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
     s["fc_mtm.predictions.transform.dense.bias"] = (H,)

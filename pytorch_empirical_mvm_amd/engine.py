@@ -581,7 +581,7 @@ class VioletEngine:
         inv_temp = 1.0 / cfg["temp"]
         lg_v = K.rowdot(h_v, S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp)           # [B*O]
         tgt_v = torch.zeros(B, dtype=torch.int64, device=dev)
-        dlg_v = K.cross_entropy(lg_v.view(B, O), O, tgt_v, losses["vtm"], want_grad=backward, ld_d=O)
+        K.cross_entropy(lg_v.view(B, O), O, tgt_v, losses["vtm"], want_grad=False)
         if want_outputs:
             outs["out_vtm"] = lg_v.view(B, O)
 
@@ -708,7 +708,11 @@ class VioletEngine:
             S.g("decoder_vq.0.bias").index_add_(0, perm, gbq)
             out1.g.index_add_(0, prow.long(), dr_q)                                     # covered-patch rows (unique) of the fusion output
         # VTM
-        dlg = dlg_v.float().reshape(-1).contiguous()
+        # d(vtm)/d(logits) of the (B,O) matrix in f32: positives and negatives of a clip nearly cancel, a bf16-rounded softmax
+        # would add rounding noise of the size of the signal (the reference's autocast runs cross_entropy in fp32 as well)
+        dlg = torch.softmax(lg_v.view(B, O), 1)
+        dlg[:, 0] -= 1.0
+        dlg = (dlg / B).reshape(-1).contiguous()
         dh_v = K.rowdot_bwd(h_v, S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
         dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
         if p_fc > 0:
@@ -732,6 +736,68 @@ class VioletEngine:
         while self.tape:
             self.tape.pop()()
         return losses, outs
+
+    # -------------------------------------------------------------- downstream: text-to-video retrieval
+    def retrieval_forward_backward(self, img, txt, mask, train=True, backward=True, dp_all=None, dlogits=None):
+        """VIOLET_Retrieval.forward + NormSoftmaxLoss (main_retrieval.py:63-85, agent.py:34-50): every (video i, text j) pair of the
+        batch goes through the fusion encoder (B*B sequences gathered from one token pool), the `fc` head reads the text [CLS]
+        state, and the loss is the symmetric cross entropy of the (B,B) score matrix / temp with the diagonal as targets.
+        Returns (loss f32[1], scores (B,B) f32).  `dlogits` (B,B) f32 replaces d(loss)/d(scores / temp) in the backward (tests:
+        the loss gradient itself is a difference of nearly equal terms whenever the scores are close, a poor probe of the
+        backward path)."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        Hd = cfg["hidden"]
+        self.tape = []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(B)
+        pool, Lv, hw = self.encode(img, None, txt, dp_all, train)
+        Lq = Lv + X
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        pairs = [(i, j) for i in range(B) for j in range(B)]
+        idx_d = self._cached(("ret_idx", B, Lv, X), lambda: _dev_i32(
+            np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs]), dev))
+        km_txt = (mask != 0).to(torch.uint8)
+        tj = torch.tensor([j for _, j in pairs], device=dev)
+        km = torch.cat([torch.ones(B * B, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
+        out, inn, _ = self.go_cross(pool, idx_d, km, B * B, Lq, train)
+        cls_rows = self._cached(("ret_cls", B, Lq, Lv), lambda: _dev_i32(np.arange(B * B) * Lq + Lv, dev))
+        r_v = K.gather_rows(out.t, cls_rows, B * B)
+        p_fc = 0.1 if train else 0.0
+        off_fc = self._next_offset(r_v.numel())
+        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
+        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        inv_temp = 1.0 / cfg["temp"]
+        lg = K.rowdot(h_v, S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp).view(B, B)
+        tgt = torch.arange(B, dtype=torch.int64, device=dev)
+        loss = torch.zeros(1, device=dev, dtype=F32)
+        K.cross_entropy(lg.contiguous(), B, tgt, loss, want_grad=False)                              # -mean diag log_softmax over rows
+        K.cross_entropy(lg.t().contiguous(), B, tgt, loss, want_grad=False)                          # ... and over columns
+        scores = lg * cfg["temp"]
+        if not backward:
+            self.tape = []
+            return loss, scores
+        # d(loss)/d(logits) of the (B,B) matrix in f32: the useful part of this gradient is what is left after the rows / columns
+        # cancel, a bf16-rounded softmax would bury it (tiny matrix: plumbing)
+        eye = torch.eye(B, device=dev, dtype=F32)
+        dlg = ((torch.softmax(lg, 1) - eye) / B + (torch.softmax(lg, 0) - eye) / B).reshape(-1).contiguous()
+        if dlogits is not None:
+            dlg = dlogits.to(dev, F32).reshape(-1).contiguous()
+        dh_v = K.rowdot_bwd(h_v, S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
+        dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
+        if p_fc > 0:
+            dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
+        inv = self._cached(("ret_inv", B, Lq, Lv), lambda: self._inverse_rows(B * B * Lq, [cls_rows]))
+        out.g = K.gather_rows(dr_v, inv, B * B * Lq)
+        for _ in range(cfg["bert_layers"]):
+            self.tape.pop()()
+        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
+        K.scatter_add_rows(inn.g, idx_d, dpool)
+        pool.g = K.cast_bf16(dpool)
+        while self.tape:
+            self.tape.pop()()
+        return loss, scores
 
     def _inverse_rows(self, n_rows, row_lists):
         inv = np.full(n_rows, -1, dtype=np.int32)

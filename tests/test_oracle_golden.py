@@ -268,3 +268,23 @@ def test_attention_guided_masking():
     np.testing.assert_array_equal(o["txt"].numpy(), d["am_txt"])
     np.testing.assert_array_equal(o["ans_mtm"].numpy(), d["am_ans_mtm"])
     np.testing.assert_array_equal(o["cov"].numpy().astype(np.uint8), d["am_cov"])
+
+
+@pytest.mark.timeout(600)
+def test_retrieval_forward_and_norm_softmax_loss():
+    """VIOLET_Retrieval.forward (B x B pairs) + NormSoftmaxLoss against the reference's own classes."""
+    d = load("retrieval.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"] = "retrieval"
+    sd = R.make_state_dict(cfg)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 3)
+    out = R.retrieval_forward(params, cfg, img, txt, mask)
+    np.testing.assert_allclose(out.detach().numpy(), d["out"], rtol=1e-4, atol=1e-5)
+    ls = R.norm_softmax_loss(out, cfg["temp"])
+    np.testing.assert_allclose(float(ls.detach()), float(d["loss"]), rtol=1e-5)
+    ls.backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
+    for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-5)

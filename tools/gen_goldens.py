@@ -588,6 +588,46 @@ def gold_am(size="tiny", T=4, B=2):
     print("am ok att", tuple(att.shape), float(att.sum()), "masked txt", int((o["ans_mtm"] != -1).sum()), "covered", int(d["am_cov"].sum()))
 
 
+def gold_retrieval(size="tiny", T=4, B=3):
+    """VIOLET_Retrieval.forward (B x B pairs through the fusion encoder, fc head) + NormSoftmaxLoss + backward through
+    the reference's own classes (main_retrieval.py, agent.py:34-50)."""
+    import main_retrieval as mr
+    import agent as ag
+    cfg = R.make_cfg(size, T=T)
+    cfg["task"] = "retrieval"
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    model = mr.VIOLET_Retrieval(args, None).eval()
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": ()}
+    model.trsfr.forward = trsfr_forward
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    out, ans = model(img, txt, mask, None)
+    ls = ag.NormSoftmaxLoss(temperature=args.temp)(out)
+    ls.backward()
+    d = dict(out=out.detach().numpy().astype(np.float64), loss=np.array(float(ls.detach())), ans=ans.numpy())
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("fc."):
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, "retrieval.npz"), **d)
+    print("retrieval ok out", out.detach().numpy().round(4).tolist(), "loss", float(ls), "gn", gsq ** 0.5)
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -661,6 +701,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--retrieval-only" in sys.argv:
+        gold_retrieval()
+        sys.exit(0)
     if "--am-only" in sys.argv:
         gold_am()
         sys.exit(0)
@@ -688,3 +731,4 @@ if __name__ == "__main__":
     gold_hog()
     gold_smtm()
     gold_am()
+    gold_retrieval()
