@@ -133,6 +133,10 @@ def param_shapes(cfg):
     s["fc.3.bias"] = (1,)
     if cfg.get("task", "pretrain") == "retrieval":       # VIOLET_Retrieval main_retrieval.py:56-61: VIOLET_Base + fc
         return s
+    if cfg.get("task", "pretrain") == "qaoe":            # VIOLET_QAOE main_qaoe.py:42-47
+        s["fc.3.weight"] = (int(cfg["size_vocab"]), 2 * H)
+        s["fc.3.bias"] = (int(cfg["size_vocab"]),)
+        return s
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
     s["fc_mtm.predictions.transform.dense.bias"] = (H,)
@@ -858,6 +862,17 @@ def retrieval_forward(sd, cfg, img, txt, mask):
     x = out[:, (1 + h * w) * T, :]
     x = F.relu(F.linear(x, sd["fc.1.weight"], sd["fc.1.bias"]))
     return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"]).squeeze(-1).view(B, B)
+
+
+def qaoe_forward(sd, cfg, img, txt, mask):
+    """VIOLET_QAOE.forward main_qaoe.py:49-58 (eval mode): logits (B, size_vocab) from the text [CLS] state of one fusion pass"""
+    B, T, _, H, W = img.shape
+    h, w = H // 32, W // 32
+    feat_img, mask_img = enc_video(sd, cfg, img)
+    feat_txt = enc_txt(sd, txt)
+    out = go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask)
+    x = F.relu(F.linear(out[:, (1 + h * w) * T, :], sd["fc.1.weight"], sd["fc.1.bias"]))
+    return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"])
 
 
 def norm_softmax_loss(x, temperature):

@@ -71,6 +71,7 @@ def model_cfg(args):
     cfg["teacher_arch"] = dict(args["teacher_arch_override"]) if args.get("teacher_arch_override") else dict(ARCH["base"])
     cfg["pretrain_tasks"] = tuple(args.get("pretrain_tasks", ("vtm", "mlm", "mvm")))      # "smtm" adds the seq2seq MLM pass
     cfg["task"] = args.get("task", "pretrain")
+    cfg["size_vocab"] = args.get("size_vocab", 0)        # open-ended QA answer vocabulary (main_qaoe.py:47)
     return cfg
 
 
@@ -144,6 +145,10 @@ def param_shapes(cfg):
     s["fc.3.weight"] = (1, 2 * H)
     s["fc.3.bias"] = (1,)
     if cfg.get("task", "pretrain") == "retrieval":       # VIOLET_Retrieval (main_retrieval.py:56-61): VIOLET_Base + fc only
+        return s
+    if cfg.get("task", "pretrain") == "qaoe":            # VIOLET_QAOE (main_qaoe.py:42-47): fc ends in Linear(2H, size_vocab)
+        s["fc.3.weight"] = (int(cfg["size_vocab"]), 2 * H)
+        s["fc.3.bias"] = (int(cfg["size_vocab"]),)
         return s
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)

@@ -799,6 +799,56 @@ class VioletEngine:
             self.tape.pop()()
         return loss, scores
 
+    # -------------------------------------------------------------- downstream: open-ended video QA
+    def qaoe_forward_backward(self, img, txt, mask, ans, train=True, backward=True, dp_all=None):
+        """VIOLET_QAOE.forward + CrossEntropyLoss(ignore_index=-1) (main_qaoe.py:49-58,72-76, agent.py:57): one (video, question)
+        fusion pass, `fc` (Dropout, Linear, ReLU, Linear -> answer vocabulary) on the text [CLS] state.  Returns (loss f32[1],
+        logits (B, size_vocab) f32)."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        B, T, _, H, W = img.shape
+        X = txt.shape[1]
+        Hd, NV = cfg["hidden"], int(cfg["size_vocab"])
+        self.tape = []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(B)
+        pool, Lv, hw = self.encode(img, None, txt, dp_all, train)
+        Lq = Lv + X
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx_d = self._cached(("qa_idx", B, Lv, X), lambda: _dev_i32(
+            np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)]), dev))
+        km = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), (mask != 0).to(torch.uint8)], 1).contiguous()
+        out, inn, _ = self.go_cross(pool, idx_d, km, B, Lq, train)
+        cls_rows = self._cached(("qa_cls", B, Lq, Lv), lambda: _dev_i32(np.arange(B) * Lq + Lv, dev))
+        r_v = K.gather_rows(out.t, cls_rows, B)
+        p_fc = 0.1 if train else 0.0
+        off_fc = self._next_offset(r_v.numel())
+        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
+        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        NVp = -(-NV // 8) * 8
+        logits = torch.zeros((B, NVp), device=dev, dtype=F32)
+        K.gemm(h_v, S.b("fc.3.weight"), N=-(-NV // 4) * 4, bias=S.p("fc.3.bias"), out=logits)
+        loss = torch.zeros(1, device=dev, dtype=F32)
+        dlog = K.cross_entropy(logits, NV, ans.to(dev).reshape(-1).contiguous(), loss, want_grad=backward, ld_d=NVp)
+        if not backward:
+            self.tape = []
+            return loss, logits[:, :NV]
+        K.colsum(dlog, S.g("fc.3.bias"), accumulate=True, M=B, N=NVp)
+        K.gemm(dlog, h_v, a_kmajor=False, b_kmajor=False, M=NV, N=2 * Hd, K=B, out=S.g("fc.3.weight"), accumulate=True)
+        dh_v = K.gemm(dlog, S.b("fc.3.weight"), b_kmajor=False, M=B, N=2 * Hd, K=NV, act=4, aux=h_v)          # ReLU' folded in
+        dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
+        if p_fc > 0:
+            dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
+        inv = self._cached(("qa_inv", B, Lq, Lv), lambda: self._inverse_rows(B * Lq, [cls_rows]))
+        out.g = K.gather_rows(dr_v, inv, B * Lq)
+        for _ in range(cfg["bert_layers"]):
+            self.tape.pop()()
+        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
+        K.scatter_add_rows(inn.g, idx_d, dpool)
+        pool.g = K.cast_bf16(dpool)
+        while self.tape:
+            self.tape.pop()()
+        return loss, logits[:, :NV]
+
     def _inverse_rows(self, n_rows, row_lists):
         inv = np.full(n_rows, -1, dtype=np.int32)
         off = 0

@@ -288,3 +288,23 @@ def test_retrieval_forward_and_norm_softmax_loss():
     np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
     for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-5)
+
+
+@pytest.mark.timeout(600)
+def test_qaoe_forward_and_loss():
+    """VIOLET_QAOE.forward + CrossEntropyLoss(ignore_index=-1) against the reference's own classes."""
+    d = load("qaoe.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"], cfg["size_vocab"] = "qaoe", 1000
+    sd = R.make_state_dict(cfg)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    img, txt, mask = R.make_batch(cfg, 3)
+    out = R.qaoe_forward(params, cfg, img, txt, mask)
+    check_samp(d, "out", out, rtol=2e-4, atol=2e-5)
+    ls = R.cross_entropy_ignore(out, torch.from_numpy(d["ans"]))
+    np.testing.assert_allclose(float(ls.detach()), float(d["loss"]), rtol=1e-5)
+    ls.backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
+    for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-6)

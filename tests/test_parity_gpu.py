@@ -643,3 +643,38 @@ def test_retrieval_pairs_scores_loss_and_step():
     assert np.isfinite(v) and v > 0
     ac = agent.step(img, txt, mask, None, is_train=False)
     assert 0.0 <= ac <= 1.0
+
+
+def test_qaoe_logits_loss_grads_and_step():
+    """open-ended video QA on the HIP path (VIOLET_QAOE / Agent_QAOE) against the fixture from the reference's classes
+    (qaoe.npz): logits, CE(ignore_index=-1) loss, head gradients, global gradient norm; then train / eval steps."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd.retrieval import Agent_QAOE, VIOLET_QAOE
+    d = np.load(os.path.join(G, "qaoe.npz"))
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"], cfg["size_vocab"] = "qaoe", 1000
+    args = CFG.get_args(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, size_vocab=1000)
+    model = VIOLET_QAOE(args, None, device="cuda")
+    missing, unexpected = model.load_state_dict(R.make_state_dict(cfg))
+    assert not unexpected, unexpected[:5]
+    img, txt, mask = R.make_batch(cfg, 3)
+    ans = torch.from_numpy(d["ans"])
+    eng = model.engine
+    eng.store.grad.zero_()
+    loss, logits = eng.qaoe_forward_backward(img.cuda(), txt.cuda(), mask.cuda(), ans, train=False, backward=True)
+    torch.cuda.synchronize()
+    _check_samples(d, "out", logits, tol=5e-2)
+    assert abs(float(loss.item()) - float(d["loss"])) <= 2e-2 * float(d["loss"]), (float(loss.item()), float(d["loss"]))
+    gn = float(eng.store.grad[:eng.store.n_trainable].double().pow(2).sum().sqrt().item())
+    assert abs(gn - float(d["grad_norm"])) <= 5e-2 * float(d["grad_norm"]), (gn, float(d["grad_norm"]))
+    # (fc.1.bias is the sum of TWO rows' ReLU-gated gradients here -- B = 3 with one ignored answer -- and a gate flips wherever
+    #  the bf16 pre-activation rounds across zero: compared through the global norm only)
+    for k in ("fc.1.weight", "fc.3.weight", "fc.3.bias"):
+        _check_samples(d, "g." + k, eng.store.g(k).reshape(tuple(d[f"g.{k}.shape"])), tol=5e-2)
+    model.train()
+    agent = Agent_QAOE(args, model)
+    v = agent.step(img, txt, mask, ans, is_train=True)
+    assert np.isfinite(v) and v > 0
+    acc = agent.step(img, txt, mask, ans, is_train=False)
+    assert len(acc) == 3 and all(a in (0.0, 1.0) for a in acc)

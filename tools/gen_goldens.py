@@ -628,6 +628,47 @@ def gold_retrieval(size="tiny", T=4, B=3):
     print("retrieval ok out", out.detach().numpy().round(4).tolist(), "loss", float(ls), "gn", gsq ** 0.5)
 
 
+def gold_qaoe(size="tiny", T=4, B=3, NV=1000):
+    """VIOLET_QAOE.forward + CrossEntropyLoss through the reference's classes (main_qaoe.py:42-76)."""
+    import main_qaoe as mq
+    cfg = R.make_cfg(size, T=T)
+    cfg["task"], cfg["size_vocab"] = "qaoe", NV
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    args.update(size_vocab=NV)
+    model = mq.VIOLET_QAOE(args, None).eval()
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": ()}
+    model.trsfr.forward = trsfr_forward
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    ans = torch.tensor([17, -1, 903])
+    out, _ = model(img, txt, mask, ans)
+    ls = torch.nn.CrossEntropyLoss(ignore_index=-1)(out, ans)
+    ls.backward()
+    d = dict(loss=np.array(float(ls.detach())), ans=ans.numpy())
+    put(d, "out", out, 256)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("fc."):
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    np.savez_compressed(os.path.join(OUT, "qaoe.npz"), **d)
+    print("qaoe ok loss", float(ls), "gn", gsq ** 0.5)
+
+
 def gold_masking(mp, agent):
     """Masking geometry: drive the reference's masking() with seeded global RNGs, record draws' effect."""
     import random
@@ -701,6 +742,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--qaoe-only" in sys.argv:
+        gold_qaoe()
+        sys.exit(0)
     if "--retrieval-only" in sys.argv:
         gold_retrieval()
         sys.exit(0)
@@ -732,3 +776,4 @@ if __name__ == "__main__":
     gold_smtm()
     gold_am()
     gold_retrieval()
+    gold_qaoe()
