@@ -588,7 +588,7 @@ def test_retrieval_pairs_scores_loss_and_step():
     temp = 1 (at temp = 0.05 the near-uniform scores make gradient entries rounding noise), then train / eval steps."""
     from oracle import violet_ref as R
     from pytorch_empirical_mvm_amd import config as CFG
-    from pytorch_empirical_mvm_amd.retrieval import Agent_Retrieval, VIOLET_Retrieval
+    from pytorch_empirical_mvm_amd.downstream import Agent_Retrieval, VIOLET_Retrieval
     d = np.load(os.path.join(G, "retrieval.npz"))
     cfg = R.make_cfg("tiny", T=4)
     cfg["task"] = "retrieval"
@@ -650,7 +650,7 @@ def test_qaoe_logits_loss_grads_and_step():
     (qaoe.npz): logits, CE(ignore_index=-1) loss, head gradients, global gradient norm; then train / eval steps."""
     from oracle import violet_ref as R
     from pytorch_empirical_mvm_amd import config as CFG
-    from pytorch_empirical_mvm_amd.retrieval import Agent_QAOE, VIOLET_QAOE
+    from pytorch_empirical_mvm_amd.downstream import Agent_QAOE, VIOLET_QAOE
     d = np.load(os.path.join(G, "qaoe.npz"))
     cfg = R.make_cfg("tiny", T=4)
     cfg["task"], cfg["size_vocab"] = "qaoe", 1000
