@@ -75,8 +75,15 @@ typedef struct {
   float* colsum;          /* optional, a_kmajor=0 only: colsum[m] += sum_k A(m,k)  (f32 [M]).  The bias gradient of a Linear is the
                              column sum of dY, and dY is the A operand of its weight-gradient GEMM dW = dY^T X: fused, the extra
                              pass over dY (vmvm_colsum_bf16) disappears into one more MFMA per fragment on the first N tile. */
+  /* fp8 operands (BASELINE config 5's "fp8 MFMA path"; forward Linear layers): in_fp8 = 1 -> A [M][lda] and B [N][ldb] are OCP
+   * e4m3 bytes, k-major both, K a multiple of 128, lda / ldb (in bytes = elements) multiples of 16; C = epilogue(alpha * sum_k
+   * A(m,k) B(n,k)) with alpha = 1 / (scale_A * scale_B) of the per-tensor quantisation (vmvm_cast_bf16_to_fp8); bias, act 1 (GELU,
+   * + C2 pre-activation) / 2 (ReLU), resid, bf16 or f32 output.  MFMA: v_mfma_scale_f32_16x16x128_f8f6f4, block scales 1.0. */
+  int32_t in_fp8; float alpha;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
+/* dst[i] (OCP e4m3, saturating at +-448) = src[i] (bf16) * scale ; n a multiple of 8 */
+int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, float scale, void* stream);
 
 /* column sums  out[n] (+)= sum_m scale[m/rows_per_scale] * X[m,n]   (bias gradients)  X bf16 [M][ldx], out f32 */
 int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale,

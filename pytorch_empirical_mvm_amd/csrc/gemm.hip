@@ -833,7 +833,10 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // =====================================================================================================================
 // F16: fp16 operands / outputs (v_mfma_f32_16x16x32_f16).  CONV: A is an NHWC activation read as an implicit 3x3 convolution
 // (K = 9 * C_in, one tap per C_in/64 consecutive K tiles; rows whose tap leaves the image get an out-of-range DMA offset = zeros).
-template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false>
+// FP8: A and B are OCP e4m3 bytes (k-major both); the descriptor reaches the kernel with K / lda / ldb counted in 2-byte units, so
+// the staging is unchanged: a 64-"element" K tile is 128 fp8 = one v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair (a lane's
+// operand = the two 16-byte chunks 2g, 2g+1 of its row; block scales fixed at 1.0, the per-tensor scale product is `alpha`).
+template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -950,6 +953,33 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       const int cur = it & 1;
       const unsigned char* la = smem + cur * 2 * TILE_BYTES;
       const unsigned char* lb = la + TILE_BYTES;
+      if (FP8) {
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        i32x8 fa8[4], fb8[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (wm * 4 + i) * 16 + r, sw = kswz<false>(row);
+          const uint4 lo = *reinterpret_cast<const uint4*>(la + row * 128 + (((2 * g) ^ sw) << 4));
+          const uint4 hi = *reinterpret_cast<const uint4*>(la + row * 128 + (((2 * g + 1) ^ sw) << 4));
+          fa8[i] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wn * 64 + (j >> 1) * 32 + 8 * (r >> 2) + 4 * (j & 1) + (r & 3), sw = kswz<true>(row);
+          const uint4 lo = *reinterpret_cast<const uint4*>(lb + row * 128 + (((2 * g) ^ sw) << 4));
+          const uint4 hi = *reinterpret_cast<const uint4*>(lb + row * 128 + (((2 * g + 1) ^ sw) << 4));
+          fb8[j] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+        if (kt + 1 < nk) issue(voA, voB, pyA, pxA, kt + 1, cur ^ 1);
+        else if (more) issue(nvoA, nvoB, npyA, npxA, nkt0, cur ^ 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j], fa8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        ++it;
+        continue;
+      }
       // software pipeline over the two 32-wide k-slices: slice 0's fragment reads go out right after the barrier (ahead of the
       // next tile's DMA requests), slice 1's reads are issued before slice 0's MFMAs so their LDS latency sits under the MFMAs
       bf16x8 fa[2][4], fb[2][4];
@@ -1057,6 +1087,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         const int n = n0 + wn * 64 + jb * 32 + g * 8;
         float v[8] = {acc[i][2 * jb][0], acc[i][2 * jb][1], acc[i][2 * jb][2], acc[i][2 * jb][3],
                       acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
+        if (FP8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        }
         if (rvalid[i] && n < N) epi_store8<F, F16>(p, ec, v, m, rdst[i], n, rrs[i], N - n, bz[jb], auxv[i][jb], resv[i][jb]);
       }
     }
@@ -1126,6 +1160,22 @@ int launch_pers_teacher(const vmvm_gemm_desc& d, hipStream_t st) {
   return VMVM_OK;
 }
 
+// fp8 build (forward Linear layers of config 5): bias, GELU (+ saved pre-activation), ReLU, residual, bf16 / f32 output
+constexpr int EF_FP8 = EF_BIAS | EF_ACT1 | EF_ACT24 | EF_RESID | EF_F32;
+int launch_pers_fp8(const vmvm_gemm_desc& d, hipStream_t st) {
+  const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, EF_FP8, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_done = true;
+  }
+  int grid = 512;
+  if (items < grid) grid = ((items + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_pers_kernel<true, true, EF_FP8, false, false, true>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
 template <bool AK, bool BKM>
 int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
   const int need = epi_need(d);
@@ -1150,6 +1200,18 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
   if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
+  if (d->in_fp8) {
+    // fp8 (OCP e4m3) operands: k-major both, whole 128-element K tiles, epilogue features within EF_FP8
+    if (!d->a_kmajor || !d->b_kmajor || d->in_fp16 || d->conv_taps) return VMVM_ENOSUPPORT;
+    if ((d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || d->lda < d->K || d->ldb < d->K) return VMVM_EINVAL;
+    if (d->row_scale || d->dropout_p > 0.f || d->row_map || d->accumulate || d->colsum || d->col_scale_n || d->splitk > 1 ||
+        (d->act != 0 && d->act != 1 && d->act != 2)) return VMVM_ENOSUPPORT;
+    if ((size_t)d->M * d->lda >= 0x7fffffffull || (size_t)d->N * d->ldb >= 0x7fffffffull) return VMVM_ENOSUPPORT;
+    vmvm_gemm_desc d8 = *d;
+    d8.K = d->K / 2; d8.lda = d->lda / 2; d8.ldb = d->ldb / 2;      // the kernel counts 2-byte units
+    d8.splitk = 1;
+    return launch_pers_fp8(d8, reinterpret_cast<hipStream_t>(stream));
+  }
   if (d->in_fp16 || d->conv_taps) {
     // fp16 / implicit 3x3 convolution builds of the persistent kernel (frozen dVAE tokenizer): k-major operands, whole K tiles,
     // epilogue features within EF_TEACHER

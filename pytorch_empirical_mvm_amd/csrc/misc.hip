@@ -409,6 +409,26 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __res
   }
 }
 
+// ---------------------------------------------------------------- bf16 -> fp8 (OCP e4m3) per-tensor quantisation
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const u16* __restrict__ src, uint8_t* __restrict__ dst, long n8, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + i * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = fminf(fmaxf(__uint_as_float(w[e] << 16) * scale, -448.f), 448.f);
+      f[2 * e + 1] = fminf(fmaxf(__uint_as_float(w[e] & 0xffff0000u) * scale, -448.f), 448.f);
+    }
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *reinterpret_cast<uint2*>(dst + i * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+  }
+}
+
 // ---------------------------------------------------------------- optimizer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ partial) {
   __shared__ float sh[4];
@@ -641,6 +661,14 @@ extern "C" int vmvm_rowdot_bwd(const void* hid, int32_t M, int32_t K, const floa
   if (!hid || !w || !dout || !dhid || !dw || !db) return VMVM_EINVAL;
   hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk(K, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(hid), M, K, w, dout, inv_temp,
                      reinterpret_cast<u16*>(dhid), dw, db, relu_mask);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, float scale, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 7)) return VMVM_EINVAL;
+  int grid = nblk(n / 8, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cast_fp8_kernel, dim3(grid), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<uint8_t*>(dst), (long)(n / 8), scale);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -26,7 +26,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None):
+         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -62,8 +62,16 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.colsum = L.ptr(colsum)
     d.in_fp16 = int(fp16)
     d.conv_taps, d.conv_h, d.conv_w = conv if conv is not None else (0, 0, 0)
+    d.in_fp8, d.alpha = int(fp8), float(alpha)
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
+
+
+def cast_fp8(x, scale=1.0):
+    """bf16 -> OCP e4m3 bytes (uint8 tensor of the same shape), y = sat(x * scale)"""
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    L.check(L.load().vmvm_cast_bf16_to_fp8(x.data_ptr(), y.data_ptr(), x.numel(), float(scale), L.stream()), "cast_fp8")
+    return y
 
 
 def colsum(X, out, row_scale=None, rows_per_scale=0, accumulate=True, M=None, N=None):

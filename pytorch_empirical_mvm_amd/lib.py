@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("col_scale", c_float), ("col_scale_n", c_int),
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
                 ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
-                ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p)]
+                ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p),
+                ("in_fp8", c_int), ("alpha", c_float)]
 
 
 class LnFwdDesc(C.Structure):
@@ -97,6 +98,7 @@ _PROTOS = {
     "vmvm_feature_l1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
     "vmvm_rowdot": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "vmvm_rowdot_bwd": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "vmvm_cast_bf16_to_fp8": ([c_void_p, c_void_p, c_i64, c_float, c_void_p], c_int),
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),

@@ -566,6 +566,52 @@ def check_attn_colsum():
     rep("column sums under dropout: total mass ~ L", tot, torch.full_like(tot, float(Lq)), tol=2e-2)
 
 
+def check_gemm_fp8():
+    """fp8 (OCP e4m3) build of the persistent GEMM (config 5's forward Linear layers): exact against fp32 PyTorch on the SAME
+    quantised operands (the kernel's arithmetic), then the end-to-end quantisation error against the unquantised product, and the
+    rate at the fusion FFN shape next to the bf16 build."""
+    f8 = torch.float8_e4m3fn
+    for (M, N, Kd, act) in [(512, 256, 128, 0), (1000, 1544, 768, 1), (4096, 3072, 768, 2)]:
+        A = rnd(M, Kd, scale=1.0)
+        W = rnd(N, Kd, scale=0.02)
+        bias = torch.randn(N, device=dev) * 0.1
+        res = rnd(M, N, scale=0.5)
+        sa, sw = 16.0, 2048.0                                  # powers of two: |A| <~ 5 -> 80, |W| <~ 0.1 -> 200 (e4m3 max 448)
+        A8, W8 = K.cast_fp8(A, sa), K.cast_fp8(W, sw)
+        # the cast itself against torch's e4m3fn rounding
+        rep(f"cast bf16->fp8 {M}x{Kd}", A8.view(f8).float(), (A.float() * sa).clamp(-448, 448).to(f8).float(), tol=1e-6)
+        Aq, Wq = A8.view(f8).float() / sa, W8.view(f8).float() / sw
+        pre = torch.empty((M, N), device=dev, dtype=BF) if act == 1 else None
+        out = K.gemm(A8, W8, bias=bias, act=act, out_preact=pre, resid=res, fp8=True, alpha=1.0 / (sa * sw))
+        z = Aq @ Wq.t() + bias
+        ref = (torch.nn.functional.gelu(z) if act == 1 else (z.clamp_min(0) if act == 2 else z)) + res.float()
+        rep(f"fp8 gemm {M}x{N}x{Kd} act={act} vs fp32 on the quantised operands", out, ref, tol=1e-2)
+        if act == 1:
+            rep(f"fp8 gemm {M}x{N}x{Kd} saved pre-activation", pre, z, tol=1e-2)
+        z0 = A.float() @ W.float().t() + bias
+        ref0 = (torch.nn.functional.gelu(z0) if act == 1 else (z0.clamp_min(0) if act == 2 else z0)) + res.float()
+        err = (out.float() - ref0).norm() / ref0.norm()
+        print(f"     end-to-end relative error of the fp8 path vs the unquantised product: {float(err):.3e}")
+        rep(f"fp8 gemm {M}x{N}x{Kd} quantisation error (Frobenius, <= 4e-2)", (out.float() - ref0).norm().view(1) / ref0.norm(), torch.zeros(1, device=dev) + 1e-9, tol=4e7)
+    M, N, Kk = 69120, 3072, 768
+    A = rnd(M, Kk, scale=1.0); W = rnd(N, Kk, scale=0.02)
+    A8, W8 = K.cast_fp8(A, 16.0), K.cast_fp8(W, 2048.0)
+    bias = torch.randn(N, device=dev) * 0.1
+    pre = torch.empty((M, N), device=dev, dtype=BF)
+    for name, fn in (("bf16 plain", lambda: K.gemm(A, W)), ("fp8 plain", lambda: K.gemm(A8, W8, fp8=True, alpha=1.0 / 32768.0)),
+                     ("bf16 bias+GELU+pre", lambda: K.gemm(A, W, bias=bias, act=1, out_preact=pre)),
+                     ("fp8 bias+GELU+pre", lambda: K.gemm(A8, W8, bias=bias, act=1, out_preact=pre, fp8=True, alpha=1.0 / 32768.0)),
+                     ("cast bf16->fp8 of A", lambda: K.cast_fp8(A, 16.0))):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"     {name:22s} {M}x{N}x{Kk}: {ms:.3f} ms" + (f"  {2.0 * M * N * Kk / ms / 1e9:.0f} TFLOP/s" if "cast" not in name else f"  {M * Kk * 3 / ms / 1e6:.0f} GB/s"))
+
+
 # ------------------------------------------------------------------ misc
 def check_misc():
     B, T, H, W = 2, 4, 64, 96
@@ -803,7 +849,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "attna", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, misc=check_misc)
+                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
