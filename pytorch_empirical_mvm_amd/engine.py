@@ -28,7 +28,7 @@ class ParamStore:
     """All parameters in ONE flat f32 buffer (+ grad, Adam m/v, bf16 compute copy), laid out by optimizer
     group (agent.py:84-113) so clip / AdamW / all-reduce are a handful of launches over contiguous memory."""
     FROZEN = ("enc_img.emb_odr",)          # never receives a gradient in pretraining (SURVEY section 9)
-    PAD = 8
+    PAD = 16                 # elements: bf16 views 32-byte, fp8 views 16-byte aligned (DMA chunks)
     TAIL = 1 << 16
 
     def __init__(self, shapes, device, frozen=False):
@@ -109,9 +109,26 @@ class ParamStore:
             o += self.index[n][1]
         return buf[o0:o].view(shape)
 
+    W8_SCALE = 512.0        # static per-tensor scale of the fp8 weight copies (|w| up to 0.875 before e4m3 saturates at 448)
+
     def refresh_shadow(self):
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
         self.refresh_transposed()
+        if getattr(self, "shadow8", None) is not None:
+            K.cast_fp8(self.shadow[:self.total8], self.W8_SCALE, out=self.shadow8[:self.total8])
+
+    def enable_fp8(self):
+        """allocate the e4m3 copy of the arena (BASELINE config 5's fp8 forward GEMMs); refreshed with the bf16 copy"""
+        if getattr(self, "shadow8", None) is None and self.device.type == "cuda":
+            self.total8 = -(-self.total // 8) * 8
+            self.shadow8 = torch.zeros(self.total8 + self.TAIL, device=self.device, dtype=torch.uint8)
+            K.cast_fp8(self.shadow[:self.total8], self.W8_SCALE, out=self.shadow8[:self.total8])
+
+    def b8(self, n, shape=None):
+        return self._view(self.shadow8, n, shape)
+
+    def fused8(self, names, shape):
+        return self.fused(self.shadow8, names, shape)
 
     # ---- W^T copies (bf16) of every Linear weight: dgrad dX = dY W then runs as a k-major x k-major GEMM
     def build_transpose_table(self):
@@ -193,6 +210,12 @@ class VioletEngine:
         self.feature_teacher = None         # frozen Swin teacher (MVM '3d_feature' / '2d_feature' targets), set by the model
         self.on_swin_tail_ready = None      # data-parallel hook (dist.GradReducer.reduce_swin_tail)
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
+        # BASELINE config 5 ("fp8 MFMA path"): forward GEMMs of the fusion encoder's qkv and FFN-in projections on e4m3 operands
+        # (per-tensor static scales, v_mfma_scale_f32_16x16x128_f8f6f4); backward stays bf16 on the bf16 activations
+        self.fp8 = bool(cfg.get("fp8_forward", False)) and self.device.type == "cuda"
+        self.A8_SCALE = 16.0
+        if self.fp8:
+            self.store.enable_fp8()
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
             K.set_workspace(self.workspace)
@@ -424,7 +447,11 @@ class VioletEngine:
         p_a = CFG.BERT["attn_dropout"] if train else 0.0
         M = nseq * Lq
         x = xv.t
-        qkv = K.gemm(x, Wqkv, bias=bqkv)
+        a8 = 1.0 / (self.A8_SCALE * S.W8_SCALE)
+        if self.fp8:
+            qkv = K.gemm(K.cast_fp8(x, self.A8_SCALE), S.fused8(qn, (3 * Hd, Hd)), bias=bqkv, fp8=True, alpha=a8)
+        else:
+            qkv = K.gemm(x, Wqkv, bias=bqkv)
         o_att = self._next_offset(nseq * nh * Lq * Lq)
         akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att, causal_from=causal_from)
         ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), att_colsum=att_out, **akw)
@@ -434,7 +461,11 @@ class VioletEngine:
         g1, b1 = S.p(pre + "attention.output.LayerNorm.weight"), S.p(pre + "attention.output.LayerNorm.bias")
         x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
         u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=BF16)
-        h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u)
+        if self.fp8:
+            h = K.gemm(K.cast_fp8(x1, self.A8_SCALE), S.b8(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"),
+                       act=1, out_preact=u, fp8=True, alpha=a8)
+        else:
+            h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u)
         o2 = self._next_offset(M * Hd)
         f = K.gemm(h, S.b(pre + "output.dense.weight"), bias=S.p(pre + "output.dense.bias"), resid=x1, dropout_p=p_h, seed=self.seed, offset=o2)
         g2, b2 = S.p(pre + "output.LayerNorm.weight"), S.p(pre + "output.LayerNorm.bias")

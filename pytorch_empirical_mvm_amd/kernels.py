@@ -67,9 +67,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     return out
 
 
-def cast_fp8(x, scale=1.0):
+def cast_fp8(x, scale=1.0, out=None):
     """bf16 -> OCP e4m3 bytes (uint8 tensor of the same shape), y = sat(x * scale)"""
-    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
     L.check(L.load().vmvm_cast_bf16_to_fp8(x.data_ptr(), y.data_ptr(), x.numel(), float(scale), L.stream()), "cast_fp8")
     return y
 
