@@ -190,8 +190,17 @@ def _acc(v, g):
     v.g = g if v.g is None else K.add_bf16(v.g, g)
 
 
+def _h2d(t, device):
+    """host -> device without stalling the launch queue: a copy from pageable memory blocks the host until everything already
+    enqueued has run (the staging copy is stream-ordered), which drains the GPU at the start of every step; pinned + non_blocking
+    lets the host keep running ahead (the caching host allocator keeps the pinned block alive until the copy has executed)."""
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def _dev_i32(a, device):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
+    return _h2d(torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)), device)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -554,7 +563,7 @@ class VioletEngine:
         idx1_d, idx2_d = _dev_i32(idx1, dev), _dev_i32(idx2, dev)
         km_txt = (mask != 0).to(torch.uint8)
         km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
-        tj = torch.tensor([j for _, j in pairs], device=dev)
+        tj = _h2d(torch.tensor([j for _, j in pairs]), dev)
         km2 = torch.cat([torch.ones(B * O, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
@@ -790,7 +799,7 @@ class VioletEngine:
         idx_d = self._cached(("ret_idx", B, Lv, X), lambda: _dev_i32(
             np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs]), dev))
         km_txt = (mask != 0).to(torch.uint8)
-        tj = torch.tensor([j for _, j in pairs], device=dev)
+        tj = _h2d(torch.tensor([j for _, j in pairs]), dev)
         km = torch.cat([torch.ones(B * B, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
         out, inn, _ = self.go_cross(pool, idx_d, km, B * B, Lq, train)
         cls_rows = self._cached(("ret_cls", B, Lq, Lv), lambda: _dev_i32(np.arange(B * B) * Lq + Lv, dev))
@@ -903,5 +912,5 @@ class VioletEngine:
         for p in self.dpr:
             keep = 1.0 - p
             rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
-        t = torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device)
+        t = _h2d(torch.from_numpy(np.stack(rows).astype(np.float32)), self.device)
         return [t[i] for i in range(t.shape[0])]

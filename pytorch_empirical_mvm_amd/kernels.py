@@ -11,6 +11,7 @@ from . import lib as L
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+_TYPES_CACHE = {}        # (mask-type list, device) -> int32 device tensor (no per-step host-to-device copy in masking())
 _WORKSPACE = {}          # device -> caller-owned split-K scratch (set by the engine; the C ABI never allocates)
 
 
@@ -169,7 +170,13 @@ def masking(txt, u_type, u_txt, u_rm, u_bm, types, T, h, w, p, tokens):
     ans = torch.empty_like(txt)
     cov = torch.empty((B, T, h, w), device=txt.device, dtype=torch.uint8)
     has_bm = int(bool((types == 1).any().item())) if types.device.type == "cpu" else 1
-    tdev = types.to(txt.device)
+    key = (tuple(types.tolist()), txt.device) if types.device.type == "cpu" else None
+    if key is not None and key in _TYPES_CACHE:
+        tdev = _TYPES_CACHE[key]
+    else:
+        tdev = types.to(txt.device)
+        if key is not None:
+            _TYPES_CACHE[key] = tdev
     L.check(L.load().vmvm_masking(txt.data_ptr(), ans.data_ptr(), cov.data_ptr(), u_type.data_ptr(), u_txt.data_ptr(), u_rm.data_ptr(),
                                   u_bm.data_ptr(), tdev.data_ptr(), tdev.numel(), has_bm, B, X, T, h, w, float(p),
                                   tokens["cls"], tokens["sep"], tokens["pad"], tokens["mask"], L.stream()), "masking")

@@ -8,4 +8,5 @@ DB=$(find /tmp/prof_step -name "*.db" | head -1)
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_shapes.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_shapes.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_gaps.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_gaps.txt 2>&1
 head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
