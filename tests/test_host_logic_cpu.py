@@ -182,3 +182,29 @@ def test_agent_am_masking_reproduces_reference_branch():
     torch.manual_seed(3)
     o2 = ag.masking(img.clone(), txt.clone(), mask.clone(), None)
     assert 0.05 < float(o2["cov"].float().mean()) < 0.3
+
+
+def test_checkpoint_key_lists_of_targets_teachers_and_downstream_heads():
+    """Checkpoint surface: for every MVM target / task the package's key -> shape list equals the oracle's, which is
+    the list the reference's own state_dict had when the fixtures were generated (gen_goldens asserts oracle keys == reference keys)."""
+    from pytorch_empirical_mvm_amd import teacher as TCH
+    for kw in (dict(mvm_target=["pixel"]), dict(mvm_target=["vq"]), dict(mvm_target=["hog"]), dict(mvm_target=["3d_feature"]),
+               dict(mvm_target=["2d_feature"]), dict(mvm_target=["pixel", "hog"]), dict(task="retrieval", mvm_target=[]),
+               dict(task="qaoe", mvm_target=[], size_vocab=1000)):
+        args = CFG.get_args(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, **kw)
+        mine = CFG.param_shapes(CFG.model_cfg(args))
+        cfg = R.make_cfg("tiny", T=4, mvm_target=list(kw.get("mvm_target", ["pixel"])))
+        if "task" in kw:
+            cfg["task"] = kw["task"]; cfg["size_vocab"] = kw.get("size_vocab", 0)
+        ref = R.param_shapes(cfg)
+        assert {k: tuple(v) for k, v in mine.items()} == {k: tuple(v) for k, v in ref.items()}, kw
+    arch = dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window=(8, 7, 7))
+    for kind, target in (("3d", "3d_feature"), ("2d", "2d_feature")):
+        cfg = R.make_cfg("tiny", T=4, mvm_target=[target])
+        ref = R.teacher_param_shapes(cfg)
+        if kind == "3d":
+            mine = {"feature_model." + k[len("enc_img.swin."):]: v for k, v in CFG.swin_param_shapes(arch, (8, 7, 7)).items()}
+        else:
+            mine = TCH.hf_swin2d_param_shapes(arch, "feature_model.", 7)
+        assert {k: tuple(v) for k, v in mine.items()} == {k: tuple(v) for k, v in ref.items()}, kind
+        assert len(ref) > 300
