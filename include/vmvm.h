@@ -63,7 +63,8 @@ typedef struct {
   int32_t accumulate;     /* C += (f32 output only) */
   float col_scale; int32_t col_scale_n;
   float dropout_p; uint64_t seed, offset;
-  int32_t variant;        /* 0 = auto; 1 = scalar (non-transposing) LDS reads; 2 = register-staged 128^2; 3 = direct 128^2; 4 = 256^2 */
+  int32_t variant;        /* 0 = auto; 1 = scalar (non-transposing) LDS reads; 2 = register-staged 128^2; 3 = direct 128^2; 4 = 256^2 (2-stage);
+                             5 = 256x128 3-stage; 6 = persistent 128^2; 7 = persistent 256^2 ping-pong (k-major x k-major, bf16 out) */
   int32_t splitk;         /* 0 = auto (split the reduction when C is a plain f32 accumulator), 1 = off, >1 = K slices */
   void* workspace; int64_t workspace_bytes;   /* optional caller-owned scratch for split-K slabs (splitk*M*N f32); without it
                                                  the slices combine with f32 atomics */

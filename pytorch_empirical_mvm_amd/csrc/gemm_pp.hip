@@ -1,0 +1,26 @@
+// gemm_pp.hip -- instantiations + dispatch of the 256x256 ping-pong GEMM (gemm_pp.h); its own translation unit so that it
+// compiles beside gemm.hip.  Entered from vmvm_gemm_bf16 (gemm.hip) only: vmvm_gemm_pp() is an internal symbol.
+#include "gemm_pp.h"
+
+namespace {
+
+// epilogue classes of the step's large NT GEMMs (same grouping as launch_pers in gemm.hip; row_map users stay on the 128x128
+// kernel: their K is a Swin channel count, below the range where this kernel pays)
+template <int F>
+int launch_nt(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<true, true, F, 2, 64, 2>(d, st); }
+
+}  // namespace
+
+// need = epilogue feature mask of the descriptor (epi_need in gemm.hip).  Returns VMVM_ENOSUPPORT when no instantiation covers it.
+int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st) {
+  if (!(d.a_kmajor && d.b_kmajor)) return VMVM_ENOSUPPORT;
+#define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_nt<(MASK)>(d, st)
+  TRY_EPI(0);
+  TRY_EPI(EF_BIAS | EF_COLSCALE | EF_RS);
+  TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS);
+  TRY_EPI(EF_ACT3 | EF_RS);
+  TRY_EPI(EF_BIAS | EF_RESID | EF_RS);
+  TRY_EPI(EF_BIAS | EF_RESID | EF_DROP);
+#undef TRY_EPI
+  return VMVM_ENOSUPPORT;
+}

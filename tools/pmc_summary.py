@@ -11,6 +11,6 @@ res = collections.defaultdict(dict)
 for name, grid, cname, val, n in cur.execute(q):
     res[(name.replace("_ZN12_GLOBAL__N_1", "")[:58], grid)][cname] = val
 for k, v in res.items():
-    if not any(x in k[0] for x in ("gemm", "attn", "ln_")): continue
+    if not any(x in k[0] for x in ("gemm", "attn", "ln_", "adamw", "sumsq")): continue
     print(k[0], "grid", k[1])
     print("    " + "  ".join(f"{c}={val:.3g}" for c, val in sorted(v.items())))
