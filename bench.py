@@ -135,6 +135,13 @@ def main():
     from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
     from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
 
+    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        # not under torch.distributed.run: start it as a CHILD (nothing here has touched the GPU yet) and pass its exit code on
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29531")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank, world, local = D.init_from_env("nccl")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)

@@ -83,6 +83,9 @@ typedef struct {
   int32_t in_fp8; float alpha;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
+/* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never
+ * allocates: the caller (PyTorch's caching allocator in the reference loop) owns every buffer, including scratch. */
+int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d);
 /* dst[i] (OCP e4m3, saturating at +-448) = src[i] (bf16) * scale ; n a multiple of 8 */
 int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, float scale, void* stream);
 
@@ -130,6 +133,7 @@ typedef struct {
   void* workspace; uint64_t workspace_bytes;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
+int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d);   /* bytes of `workspace` for the dgamma / dbeta partial rows */
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention (whole K/V of one (sequence, head) resident in LDS up to 448 tokens, streamed in chunks above).
@@ -181,6 +185,7 @@ typedef struct {
   float* delta;                        /* workspace f32 [nseq][heads][L] */
 } vmvm_attn_bwd_desc;
 int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
+int64_t vmvm_attention_bwd_workspace_size(const vmvm_attn_bwd_desc* d); /* bytes of the `delta` scratch */
 
 /* ------------------------------------------------------------------------------------------
  * Small fused kernels
@@ -280,6 +285,7 @@ int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table
  * in a fixed order, so data-parallel ranks holding identical (all-reduced) gradients get bit-identical clip coefficients and their
  * replicas stay bit-identical; workspace NULL: f32 atomics (order-dependent rounding). */
 int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void* workspace, uint64_t workspace_bytes, void* stream);
+int64_t vmvm_sumsq_workspace_size(int64_t n);                            /* bytes of `workspace` for the fixed-order partial sums */
 typedef struct {
   float* param; const float* grad; float* m; float* v; void* param_bf16;
   int64_t n;

@@ -36,6 +36,17 @@ class Agent_Pretrain:
             self.comm = D.GradReducer(self.engine.store, self.engine.device)
             D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
             self.engine.store.refresh_shadow()
+            # DDP also broadcasts the frozen teachers' parameters (they are sub-modules of the wrapped model): without this, ranks
+            # seeded differently would regress onto different random teachers
+            ft = getattr(self.model, "feature_model", None)
+            if ft is not None:
+                D.broadcast_(ft.eng.store.flat)
+                ft.eng.store.refresh_shadow()
+            dl = getattr(self.model, "dalle", None)
+            if dl is not None:
+                for k in sorted(dl.w):
+                    D.broadcast_(dl.w[k])
+                dl._refresh()
 
     def reduce_mean(self, v):
         """agent.py:118-125"""
@@ -59,7 +70,9 @@ class Agent_Pretrain:
         ans_mtm = torch.full_like(txt, -1)
         cov = torch.zeros(B, T, h, w, dtype=torch.uint8)
         Lv = (1 + h * w) * T
-        att_all = None                       # get_att's weights for the whole batch (the reference recomputes them per 'am' sample, :321-324)
+        # `vq` (dataset-supplied token map (B, T*(1+hw)), -1 at the per-frame cls slots): special visual positions and the MVM answers
+        spc_vis = None if vq is None else (vq.cpu() == -1)
+        ans_mvm = torch.full((B, T * (1 + h * w)), -1, dtype=torch.long)
         failed_masking = False               # sticky across the batch, as in the reference (:300, :342-343)
         if p_mask > 0:
             for i in range(B):
@@ -77,10 +90,9 @@ class Agent_Pretrain:
                     # attention mass each position receives; special positions (per-frame cls, [CLS]/[SEP]/pad/[MASK]) excluded.
                     # The weights come from the HIP path (attention kernels with the column-sum output, one pass for the whole
                     # batch), the draw is torch.multinomial on the CPU generator.
-                    if att_all is None:
-                        att_all = self.model.get_att(img, txt, mask)[1].detach().float().cpu()
-                    a = att_all[i].clone()
-                    spc_v = torch.tensor(sum([[True] + [False] * (h * w) for _ in range(T)], []))
+                    # (:321-324: get_att runs on the whole batch as it stands NOW -- text and clips of the earlier samples already masked)
+                    a = self.model.get_att(img, txt, mask, cov=cov)[1][i].detach().float().cpu().clone()
+                    spc_v = torch.tensor(sum([[True] + [False] * (h * w) for _ in range(T)], [])) if spc_vis is None else spc_vis[i]
                     a[torch.cat([spc_v, spc[i].cpu()])] = 0.0
                     try:
                         pos = torch.multinomial(a, int((Lv + X) * p_mask)).numpy()
@@ -97,12 +109,16 @@ class Agent_Pretrain:
                 if mask_type == "rm" or failed_masking:                  # :344-352 (also the fallback of a failed 'am' draw)
                     sel = (~spc[i].cpu()) & (torch.rand(X) < p_mask)
                     r = torch.rand((1 + h * w) * T) < p_mask
+                    if spc_vis is not None:
+                        r = r & ~spc_vis[i]
                     cov_i = r.view(T, 1 + h * w)[:, 1:].reshape(T, h, w).to(torch.uint8)
                 cov[i] = cov_i
+                if vq is not None:                                       # :356-360 curr_ans_mvm[p] = vq[i][p] at covered positions
+                    pos_c = torch.cat([torch.zeros(T, 1, dtype=torch.bool), cov_i.view(T, h * w).bool()], 1).flatten()
+                    ans_mvm[i] = torch.where(pos_c, vq[i].cpu().long(), ans_mvm[i])
                 sel = sel.to(txt.device)
                 ans_mtm[i] = torch.where(sel, txt[i], ans_mtm[i])
                 txt[i] = torch.where(sel, torch.full_like(txt[i], self.mask_token_id), txt[i])
-        ans_mvm = torch.full((B, T * (1 + h * w)), -1, dtype=torch.long)
         out = {"txt": txt, "mask": mask, "ans_mtm": ans_mtm, "ans_mvm": ans_mvm, "cov": cov, "unmask_img": img}
         if "vq" in self.args.mvm_target:
             out.update(self.vq_index(cov))
@@ -206,6 +222,9 @@ class Agent_Pretrain:
                 r["mvm_3d_feature"] = float(losses["mvm_feature"].item())      # the reference reports both under this key (:526,:545)
             if "vq" in self.args.mvm_target:           # accuracy over covered positions (main_pretrain.py:503-506)
                 r["mvm_vq"] = float(outs["vq_acc"].item()) if "vq_acc" in outs else -1
+            if "out_smtm" in outs:                     # main_pretrain.py:581-584: the seq2seq-masked pass is scored against the MLM answers
+                pred_s = outs["out_smtm"].argmax(-1)
+                r["smtm"] = float(((pred_s == ans_m) & (ans_m != -1)).sum().item()) / nm if nm > 0 else -1
             return r
         if not sync:
             return losses
@@ -223,6 +242,22 @@ class Agent_Pretrain:
             for k, v in r.items():
                 ret.setdefault(k, []).append(v)
         return {k: self.reduce_mean(float(np.mean([x for x in v if x == x]))) for k, v in ret.items()}
+
+    def evaluate(self, dl):
+        """main_pretrain_yaml.py:196-214 : eval mode, mask every batch like training, step(is_train=False), NaN-ignoring means
+        averaged over the ranks; back to train mode."""
+        self.model.eval()
+        ret = {}
+        for batch in dl:
+            masked = self.masking(batch["img"], batch["txt"], batch["mask"], batch.get("vq"))
+            if batch.get("hog") is not None:
+                masked["hog"] = batch["hog"]
+            r = self.step(self.prepare_batch(masked), is_train=False)
+            for k, v in r.items():
+                ret.setdefault(k, []).append(v)
+        out = {k: self.reduce_mean(float(np.average([x for x in v if x == x]))) for k, v in ret.items()}
+        self.model.train()
+        return out
 
     def backward_step(self):
         """all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:186-193)"""
@@ -242,6 +277,8 @@ class Agent_Pretrain:
                         beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
                         grad_scale=gscale)
         S.refresh_transposed()
+        if getattr(S, "shadow8", None) is not None:          # fp8 forward (config 5): the e4m3 weight copy follows the updated bf16 copy
+            K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE, out=S.shadow8[:S.total8])
         self.sched_step += 1
         S.grad.zero_()
 

@@ -53,16 +53,20 @@ def get_args(config_path=None, **overrides):
     return a
 
 
-def model_cfg(args):
-    size = args.vis_backbone_size
-    if int(args.size_img) == 384 and size == "large":
+def swin_arch(size, size_img=224, override=None):
+    """video_swin.py:573-599 : the Video-Swin architecture table by (size_img, vis_backbone_size)"""
+    if int(size_img) == 384 and size == "large":
         size = "large384"                 # video_swin.py:574-580
     if size not in ARCH:
         raise ValueError(f"unknown vis_backbone_size {size}")
-    cfg = dict(ARCH[size])
-    for k in ("arch_override",):
-        if k in args and args[k]:
-            cfg.update(args[k])
+    arch = dict(ARCH[size])
+    if override:
+        arch.update(override)
+    return arch, size
+
+
+def model_cfg(args):
+    cfg, size = swin_arch(args.vis_backbone_size, args.size_img, args.get("arch_override"))
     cfg.update(size=size, hidden=BERT["hidden"], vocab=BERT["vocab"], bert_layers=args.get("bert_layers", BERT["layers"]),
                max_size_frame=args.max_size_frame, max_size_patch=args.max_size_patch, size_patch=args.size_patch,
                temp=args.temp, mvm_target=list(args.mvm_target), size_vq=args.get("size_vq", 8192),

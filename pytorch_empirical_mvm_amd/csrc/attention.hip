@@ -2388,3 +2388,10 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   }
   return VMVM_OK;
 }
+
+// `delta` scratch of the backward (f32 [nseq][heads][L])
+extern "C" int64_t vmvm_attention_bwd_workspace_size(const vmvm_attn_bwd_desc* d) {
+  if (!d || d->f.nseq <= 0 || d->f.heads <= 0 || d->f.L <= 0) return VMVM_EINVAL;
+  return (int64_t)d->f.nseq * d->f.heads * d->f.L * (int64_t)sizeof(float);
+}
+

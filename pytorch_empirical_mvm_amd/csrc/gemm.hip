@@ -1160,3 +1160,24 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     return direct ? launch<false, false, true, true>(*d, st) : (tr ? launch<false, false, true, false>(*d, st) : launch<false, false, false, false>(*d, st));
   return direct ? launch<false, true, true, true>(*d, st) : (tr ? launch<false, true, true, false>(*d, st) : launch<false, true, false, false>(*d, st));
 }
+
+// Scratch the split-K slabs of this problem take when `workspace` is supplied (a workspace-size query per op that
+// takes one).  Mirrors the plan of vmvm_gemm_bf16 for variant 0 / splitk 0|>1; 0 = this problem never splits.
+extern "C" int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
+  const bool plain_acc = d->out_fp32 && d->accumulate && !d->bias && !d->row_scale && !d->act && !d->resid && !d->row_map &&
+                         d->dropout_p <= 0.f && d->col_scale_n == 0;
+  if (!plain_acc || d->in_fp8 || d->in_fp16 || d->conv_taps || d->splitk == 1) return 0;
+  const int nk_all = (d->K + BK - 1) / BK;
+  int s = d->splitk;
+  if (s == 0) {
+    const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+    s = ((d->K % BK == 0) ? 512 : 1024) / tiles;
+    if (s > nk_all / 4) s = nk_all / 4;
+  }
+  if (s < 2) return 0;
+  const int per = (nk_all + s - 1) / s;
+  s = (nk_all + per - 1) / per;
+  return s < 2 ? 0 : (int64_t)s * d->M * d->N * (int64_t)sizeof(float);
+}
+

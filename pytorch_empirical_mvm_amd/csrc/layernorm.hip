@@ -483,3 +483,13 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
+
+// scratch of the dgamma / dbeta reduction (one [2][C] f32 partial row per resident workgroup); without it: global atomics
+extern "C" int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d) {
+  if (!d || d->M <= 0 || d->C <= 0) return VMVM_EINVAL;
+  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 3 : 2;
+  int grid = (d->M + 3) / 4;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  return (int64_t)grid * 2 * d->C * (int64_t)sizeof(float);
+}
+

@@ -760,3 +760,12 @@ extern "C" int vmvm_probe_tr16(int32_t* out, void* stream) {
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
+
+// scratch of the fixed-order gradient-norm sum (one f32 partial per workgroup)
+extern "C" int64_t vmvm_sumsq_workspace_size(int64_t n) {
+  if (n <= 0) return VMVM_EINVAL;
+  int64_t grid = (((n + 3) / 4) + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  return grid * (int64_t)sizeof(float);
+}
+

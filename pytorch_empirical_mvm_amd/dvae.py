@@ -110,6 +110,13 @@ class DalleTeacher:
                 self.w[k] = sd[prefix + k].to(self.device, torch.float32).reshape(self.w[k].shape)
         self._refresh()
 
+    def load_pickle(self, path):
+        """`dalle_model_path` (visbackbone/dalle/__init__.py:12-20): the reference torch.load()s a pickled dall_e Encoder module.
+        Accepts that module (anything with .state_dict()) or a plain state_dict saved from it; keys `blocks.*`."""
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+        self.load_state_dict({("dalle.encoder." + k): v for k, v in sd.items()})
+
     def _conv(self, x, k):
         w = self.c[k + ".w"]
         return F.conv2d(x.to(w.dtype), w, self.c[k + ".b"], padding=(w.shape[-1] - 1) // 2)

@@ -509,7 +509,7 @@ class VioletEngine:
         return cur, xv, idx
 
     @torch.no_grad()
-    def get_att(self, img, txt, mask, train=True, dp_all=None):
+    def get_att(self, img, txt, mask, train=True, dp_all=None, cov=None):
         """VIOLET_Pretrain.get_att (main_pretrain.py:211-215): one (img_i, txt_i) fusion pass whose attention kernels also
         accumulate the head-averaged column sums of every layer -> (B, T*(1+hw)+X) f32, the sampling weights of the 'am' masking.
         `train` keeps dropout / DropPath on, as the reference calls it from masking() with the model in train mode."""
@@ -519,7 +519,8 @@ class VioletEngine:
         saved, self.tape = self.tape, []
         if train and dp_all is None:
             dp_all = self.sample_drop_path(B)
-        pool, Lv, hw = self.encode(img.to(dev, F32).contiguous(), None, txt.to(dev).contiguous(), dp_all, train)
+        cov_d = None if cov is None else cov.to(dev, torch.uint8).contiguous()
+        pool, Lv, hw = self.encode(img.to(dev, F32).contiguous(), cov_d, txt.to(dev).contiguous(), dp_all, train)
         Lq = Lv + X
         ar_v, ar_t = np.arange(Lv), np.arange(X)
         idx1 = _dev_i32(np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)]), dev)

@@ -109,6 +109,11 @@ _PROTOS = {
     "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p, c_u64, c_void_p], c_int),
     "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
     "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),
+    # workspace-size queries: the caller owns every buffer, scratch included
+    "vmvm_gemm_workspace_size": ([C.POINTER(GemmDesc)], c_i64),
+    "vmvm_layernorm_bwd_workspace_size": ([C.POINTER(LnBwdDesc)], c_i64),
+    "vmvm_attention_bwd_workspace_size": ([C.POINTER(AttnBwdDesc)], c_i64),
+    "vmvm_sumsq_workspace_size": ([c_i64], c_i64),
 }
 
 _lib = None

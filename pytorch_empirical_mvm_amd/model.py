@@ -66,6 +66,9 @@ class VIOLET_Pretrain(torch.nn.Module):
             self.dalle = DalleTeacher(self.cfg["dvae_hid"], self.cfg["dvae_vocab"], device=self.engine.device, dtype=args.get("dvae_dtype"),
                                       seed=args.get("seed", 88))
             self.engine.teacher = self.dalle
+            pth = args.get("dalle_model_path", "")
+            if pth:                                                 # visbackbone/dalle/__init__.py:12-20,27 : torch.load of the pickled encoder
+                self.dalle.load_pickle(pth)
         # MVM feature targets: frozen Swin-B teacher (main_pretrain.py:153-174); its tensors load from `feature_model.*`
         self.feature_model = None
         for kind in ("3d_feature", "2d_feature"):
@@ -115,9 +118,29 @@ class VIOLET_Pretrain(torch.nn.Module):
         self.engine.store.load_state(sd)
 
     @torch.no_grad()
-    def get_att(self, img, txt, mask, odr=None):
-        """main_pretrain.py:211-215 -> (feat_img placeholder None, att (B, L)); the reference's callers only use `att`"""
-        return None, self.engine.get_att(img, txt, mask, train=self.training)
+    def get_att(self, img, txt, mask, odr=None, cov=None):
+        """main_pretrain.py:211-215 -> (feat_img placeholder None, att (B, L)); the reference's callers only use `att`.
+        `cov` (B,T,h,w) u8: patch cover already applied to the clips (the reference masks `img` in place while it walks the batch)."""
+        return None, self.engine.get_att(img, txt, mask, train=self.training, cov=cov)
+
+    @torch.no_grad()
+    def go_feat(self, img, txt, mask, odr=None, vt_mask=None, attn_mask_type="full"):
+        """VIOLET_Base.go_feat (model.py:174-178): (feat_img (B, T*(1+hw), H), mask_img ones, feat_txt (B, X, H), mask_txt).
+        Inference surface (eval / feature extraction); the training step assembles the same token pool inside the engine."""
+        if odr is not None or vt_mask is not None:
+            raise NotImplementedError("odr / vt_mask are outside the pretraining path (model.py:61-67)")
+        eng, dev = self.engine, self.engine.device
+        B, T = img.shape[0], img.shape[1]
+        X = txt.shape[1]
+        saved, eng.tape = eng.tape, []
+        train = self.training
+        dp_all = eng.sample_drop_path(B) if train else None
+        pool, Lv, hw = eng.encode(img.to(dev, torch.float32).contiguous(), None, txt.to(dev).contiguous(), dp_all, train)
+        eng.tape = saved
+        Hd = self.hidden_size
+        feat_img = pool.t[:B * Lv].view(B, Lv, Hd)
+        feat_txt = pool.t[B * Lv:].view(B, X, Hd)
+        return feat_img, torch.ones(B, Lv, dtype=torch.long, device=dev), feat_txt, mask.to(dev)
 
     def state_dict(self, *a, **k):
         sd = super().state_dict(*a, **k)
@@ -127,6 +150,9 @@ class VIOLET_Pretrain(torch.nn.Module):
             sd[prefix + "fc_mtm.predictions.decoder.bias"] = sd[prefix + key]
         if getattr(self, "feature_model", None) is not None:        # frozen teacher tensors travel with the checkpoint, as in the reference
             for k_, v_ in self.feature_model.state_dict().items():
+                sd[prefix + k_] = v_
+        if getattr(self, "dalle", None) is not None:                # the reference's DalleModel is an nn.Module: `dalle.encoder.blocks.*` are saved
+            for k_, v_ in self.dalle.state_dict().items():
                 sd[prefix + k_] = v_
         return sd
 
@@ -142,6 +168,8 @@ class VIOLET_Pretrain(torch.nn.Module):
         if self.feature_model is not None:
             self.feature_model.load_state_dict(sd)
             unexpected = [k for k in unexpected if not k.startswith("feature_model.")]
+        if self.dalle is not None:
+            unexpected = [k for k in unexpected if not k.startswith("dalle.encoder.")]
         return missing, unexpected
 
     def load_ckpt(self, ckpt):

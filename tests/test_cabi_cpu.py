@@ -16,7 +16,7 @@ def _header():
 def test_library_exports_every_declared_symbol():
     from pytorch_empirical_mvm_amd import build, lib
     build.build(force=False, verbose=False)
-    declared = sorted(set(re.findall(r"^int (vmvm_\w+)\(", _header(), flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|int64_t) (vmvm_\w+)\(", _header(), flags=re.M)))
     assert len(declared) >= 25
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
@@ -53,6 +53,26 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert l.vmvm_sumsq_f32(None, 10, None, None, 0, None) == -1
     a = lib.AttnFwdDesc()
     assert l.vmvm_attention_fwd(ctypes.byref(a), None) == -1
+
+
+def test_workspace_size_queries_without_a_gpu():
+    """every op that takes scratch reports how much (pure host arithmetic)."""
+    from pytorch_empirical_mvm_amd import lib
+    l = lib.load()
+    d = lib.GemmDesc()
+    d.M, d.N, d.K, d.out_fp32, d.accumulate = 3072, 768, 55296, 1, 1          # a weight gradient of the fusion FFN: splits
+    need = l.vmvm_gemm_workspace_size(ctypes.byref(d))
+    assert need > 0 and need % (3072 * 768 * 4) == 0 and need // (3072 * 768 * 4) >= 2
+    d.accumulate = 0
+    assert l.vmvm_gemm_workspace_size(ctypes.byref(d)) == 0                      # not a plain accumulator: never splits
+    assert l.vmvm_gemm_workspace_size(None) < 0
+    ln = lib.LnBwdDesc()
+    ln.M, ln.C = 69120, 768
+    assert l.vmvm_layernorm_bwd_workspace_size(ctypes.byref(ln)) == 256 * 3 * 2 * 768 * 4
+    a = lib.AttnBwdDesc()
+    a.f.nseq, a.f.heads, a.f.L = 160, 12, 432
+    assert l.vmvm_attention_bwd_workspace_size(ctypes.byref(a)) == 160 * 12 * 432 * 4
+    assert l.vmvm_sumsq_workspace_size(225_000_000) == 2048 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

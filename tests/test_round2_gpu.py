@@ -1,0 +1,299 @@
+"""Round-2 parity cases on the BASELINE configurations ("next round" item 1) and the boundary additions:
+
+* full-size C2 (Swin-B, 8 x 224^2, 432-token fusion sequences) PER-TENSOR gradients against the oracle's autograd -- the 18-deep
+  stage 3, 16 / 32 heads, split-K weight gradients at K = 50 176 tokens and the fused bias-gradient column sums end to end;
+* full-width config 5 (Swin-L-384, window (8,12,12), 16 x 384^2) step with and without the fp8 forward GEMMs;
+* several optimizer steps with fp8 forward: the e4m3 weight copy follows the optimizer;
+* the native dVAE tokenizer against the ORACLE's encoder (not against the package's own torch path);
+* RCCL itself: backend nccl at world size 1 with the reducer active (VMVM_FORCE_DIST) == the run without a reducer;
+* evaluate() / step(is_train=False) incl. the smtm accuracy; save_model -> load_ckpt with the max_size_frame 6 -> 8 resize rule;
+  upstream Video-Swin checkpoint loading (load_checkpoint_3d) and the standalone get_vidswin_model / EncVideo / go_feat surface."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _engine(cfg_args):
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
+    args = CFG.get_args(**cfg_args)
+    return VIOLET_Pretrain(args, None, device="cuda"), args
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_c2_gradients_vs_oracle():
+    """Swin-B, T = 8, 224^2, B = 2: every parameter gradient with norm above 1e-3 of the largest against the CPU oracle's autograd
+    at temp = 1.0 (cosine >= 0.99, norm within 5 %; `fc.1` / `fc.3` included), then the global gradient norm at the reference's
+    temp = 0.05 (3 %)."""
+    from oracle import violet_ref as R
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    B = 2
+    for temp in (1.0, 0.05):
+        cfg = R.make_cfg("base", T=8, temp=temp)
+        model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8, temp=temp))
+        sd = R.make_state_dict(cfg)
+        model.load_state_dict(sd)
+        img, txt, mask = R.make_batch(cfg, B)
+        mb = R.default_masking(cfg, img, txt, mask, seed=3)
+        neg = R.vtm_negatives_default(B)
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ls = R.pretrain_losses(params, cfg, mb, negatives=neg)
+        ls["total"].backward()
+        cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+        eng = model.engine
+        eng.store.grad.zero_()
+        losses, _ = eng.forward_backward(dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda()),
+                                         negatives=neg, train=False, backward=True)
+        torch.cuda.synchronize()
+        for k in ("mtm", "mvm"):
+            assert abs(float(losses[k].item()) - float(ls[k].detach())) <= 2e-2 * abs(float(ls[k].detach())) + 1e-3, (temp, k)
+        ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
+        S = eng.store
+        got_norm = float(torch.sqrt((S.grad[:S.n_trainable].double() ** 2).sum()).item())
+        assert abs(got_norm - ref_norm) <= 3e-2 * ref_norm, (temp, got_norm, ref_norm)
+        if temp == 1.0:
+            gmax = max(float(p.grad.norm()) for p in params.values() if p.grad is not None)
+            bad, checked = [], 0
+            for name, p in params.items():
+                if p.grad is None or float(p.grad.norm()) < 1e-3 * gmax:
+                    continue
+                got = eng.store.g(name).detach().cpu().double().flatten()
+                ref = p.grad.double().flatten()
+                cos, ratio = _cos(got, ref), float(got.norm() / ref.norm())
+                checked += 1
+                if cos < 0.99 or abs(ratio - 1.0) > 0.05:
+                    bad.append((name, round(cos, 4), round(ratio, 3)))
+            assert checked > 300 and not bad, (checked, bad[:12])
+        del model, eng, params
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(1200)
+def test_full_width_c5_step_bf16_and_fp8():
+    """BASELINE config 5 at full width (Swin-L, 16 x 384^2 frames, window (8,12,12): 1152-token windows, 2352-token fusion
+    sequences on the streaming attention kernels), B = 2: one training step each with bf16 and with the fp8 (e4m3) forward GEMMs;
+    finite, and the two agree on every loss within 5 %."""
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    import bench
+    res = {}
+    for fp8 in (False, True):
+        model, args = _engine(dict(vis_backbone_size="large", size_frame=16, max_size_frame=16, size_img=384, max_iter=100, fp8_forward=fp8, seed=88))
+        agent = Agent_Pretrain(args, model)
+        agent.sched_step = 10
+        img, txt, mask = bench.synth_batch(args, 2, "cuda", 123)
+        import random
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
+        model.eval()                     # dropout / DropPath off so that the two runs see the same network
+        eng = model.engine
+        b = dict(img=mb["unmask_img"].float().contiguous(), cov=mb["cov"].contiguous(), txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"])
+        losses, _ = eng.forward_backward(b, negatives=np.array([[1], [0]]), train=False, backward=True)
+        agent.backward_step()
+        torch.cuda.synchronize()
+        res[fp8] = {k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}
+        assert all(np.isfinite(v) for v in res[fp8].values()), res
+        assert np.isfinite(agent.grad_norm()) and agent.grad_norm() > 0
+        del model, agent, eng
+        torch.cuda.empty_cache()
+    for k in ("mtm", "mvm"):
+        assert abs(res[True][k] - res[False][k]) <= 5e-2 * abs(res[False][k]), res
+    assert abs(res[True]["vtm"] - res[False]["vtm"]) <= 5e-2 * abs(res[False]["vtm"]) + 5e-2, res
+
+
+def test_fp8_weight_copy_follows_the_optimizer():
+    """with fp8_forward the e4m3 weight copy must be re-cast after every AdamW step; the loss trajectory of
+    three steps tracks the bf16 run."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd import kernels as K
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    traj = {}
+    for fp8 in (False, True):
+        model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, arch_override=arch, bert_layers=2, max_iter=20,
+                                   lr=1e-3, size_img=96, temp=1.0, fp8_forward=fp8))
+        cfg = R.make_cfg("tiny", T=4, img=96, arch=arch, bert_layers=2, temp=1.0)
+        model.load_state_dict(R.make_state_dict(cfg))
+        img, txt, mask = R.make_batch(cfg, 2)
+        mb = R.default_masking(cfg, img, txt, mask, seed=1)
+        cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+        agent = Agent_Pretrain(args, model)
+        agent.sched_step = 5
+        b = dict(img=img.cuda(), cov=cov.cuda().contiguous(), txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+        S = model.engine.store
+        out = []
+        for _ in range(3):
+            losses, _ = model.engine.forward_backward(b, negatives=R.vtm_negatives_default(2), train=False, backward=True)
+            agent.backward_step()
+            out.append(float(losses["mtm"].item()) + float(losses["mvm"].item()))
+            if fp8:
+                want = K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE)
+                assert torch.equal(want, S.shadow8[:S.total8]), "e4m3 weight copy is stale after the optimizer step"
+        traj[fp8] = out
+    assert traj[False][2] < traj[False][0]                      # lr 1e-3: the loss moves
+    for a, b_ in zip(traj[False], traj[True]):
+        assert abs(a - b_) <= 3e-2 * abs(a), traj
+
+
+@pytest.mark.timeout(600)
+def test_dvae_native_tokenizer_vs_oracle_encoder():
+    """the full-width tokenizer (n_hid 256, 8192 codes) on the hand-written implicit-GEMM fp16 convolutions against
+    the ORACLE's fp32 `dvae_encoder` (the restatement pinned to the reference's Encoder by tests/golden/vq.npz) on the same weights."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.dvae import DalleTeacher
+    torch.manual_seed(0)
+    t = DalleTeacher(256, 8192, device="cuda", seed=3)
+    assert t.native
+    sd = {k: v.float().cpu() for k, v in t.state_dict().items()}                 # keys dalle.encoder.blocks.*
+    img = torch.randn(2, 3, 224, 224).clamp_(-2.1, 2.6)
+    x = 0.8 * (img * torch.tensor(R.IMNET_STD).view(1, 3, 1, 1) + torch.tensor(R.IMNET_MEAN).view(1, 3, 1, 1)) + 0.1
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        zr = R.dvae_encoder(sd, dict(dvae_hid=256, dvae_vocab=8192), x).permute(0, 2, 3, 1)          # (N,28,28,V)
+    zl = t.logits_native(x.cuda()).view(2, 28, 28, 8192).float().cpu()
+    assert _cos(zl, zr) >= 0.9995, _cos(zl, zr)
+    assert float((zl - zr).abs().max()) <= 3e-2 * float(zr.abs().max())
+    tok = t.extract_vq_token(img.cuda()).cpu()
+    tok_r = R.vq_tokens(sd, dict(dvae_hid=256, dvae_vocab=8192), img.view(1, 2, 3, 224, 224))
+    assert float((tok == tok_r).float().mean()) >= 0.98, float((tok == tok_r).float().mean())
+
+
+@pytest.mark.timeout(900)
+def test_rccl_world1_reducer_equals_no_reducer():
+    """RCCL (torch.distributed backend "nccl") initialised at world size 1 with the gradient reducer forced on: three optimizer
+    steps at the C2 shapes (B = 4) give bit-identical parameters to the run without a reducer."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VMVM_FORCE_DIST="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "tools/rccl_smoke.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "rccl world-1: identical=True" in p.stdout, p.stdout[-2000:]
+
+
+def test_evaluate_and_eval_step_with_smtm_accuracy(tmp_path):
+    """Agent_Pretrain.evaluate (main_pretrain_yaml.py:196-214) over a small loader; step(is_train=False) returns the reference's
+    accuracy keys incl. `smtm` (main_pretrain.py:574-586) and agrees with the accuracies recomputed from the model's outputs."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    tasks = ["vtm", "mlm", "mvm", "smtm"]
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=2, max_size_frame=6, arch_override=arch, bert_layers=1, size_img=96,
+                               pretrain_tasks=tasks, path_output=str(tmp_path)))
+    cfg = R.make_cfg("tiny", T=2, img=96, arch=arch, bert_layers=1, pretrain_tasks=tasks)
+    model.load_state_dict(R.make_state_dict(cfg))
+    agent = Agent_Pretrain(args, model)
+    img, txt, mask = R.make_batch(cfg, 4)
+    dl = [dict(img=img[:2], txt=txt[:2], mask=mask[:2]), dict(img=img[2:], txt=txt[2:], mask=mask[2:])]
+    import random
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    r = agent.evaluate(dl)
+    assert set(r) >= {"mtm", "vtm", "mvm_pixel", "smtm"}, r
+    assert model.training                                    # evaluate() puts the model back into train mode
+    assert all(np.isfinite(v) for v in r.values()) and 0.0 <= r["vtm"] <= 1.0 and -1 <= r["smtm"] <= 1.0
+    # one batch by hand: accuracies from the returned logits
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    mb = agent.prepare_batch(agent.masking(img[:2], txt[:2], mask[:2], None))
+    model.eval()
+    r1 = agent.step(mb, is_train=False, negatives=R.vtm_negatives_default(2))
+    out = model(dict(img=mb["unmask_img"], cov=mb["cov"], txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"]), negatives=R.vtm_negatives_default(2))
+    ans = mb["ans_mtm"]
+    nm = int((ans != -1).sum())
+    want = float(((out["out_mtm"].argmax(-1) == ans) & (ans != -1)).sum()) / nm if nm else -1
+    assert abs(r1["mtm"] - want) < 1e-6 and abs(r1["vtm"] - float((out["out_vtm"].argmax(-1) == 0).float().mean())) < 1e-6
+    model.train()
+
+
+def test_save_model_load_ckpt_round_trip_with_frame_resize(tmp_path):
+    """save_model -> load_ckpt (main_pretrain.py:612-619, model.py:295-353): same-shape tensors come back bit-identical; a checkpoint
+    saved at max_size_frame = 6 loads into a max_size_frame = 8 model with emb_len[:, :6] taken from the file and the rest kept."""
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    common = dict(vis_backbone_size="tiny", size_frame=2, arch_override=arch, bert_layers=1, size_img=96, path_output=str(tmp_path), dataset="unit")
+    m6, a6 = _engine(dict(common, max_size_frame=6, seed=1))
+    ag = Agent_Pretrain(a6, m6)
+    ag.save_model(3, "unit", 0)
+    path = os.path.join(str(tmp_path), "ckpt_violet_pretrain_unit_0_3.pt")
+    assert os.path.exists(path)
+    saved = torch.load(path, map_location="cpu")
+    assert all(v.device.type == "cpu" for v in saved.values()) and "fc_mtm.predictions.decoder.bias" in saved
+    m6b, _ = _engine(dict(common, max_size_frame=6, seed=2))
+    m6b.load_ckpt(path)
+    for k, v in m6.state_dict().items():
+        assert torch.equal(v.cpu(), m6b.state_dict()[k].cpu()), k
+    m8, _ = _engine(dict(common, max_size_frame=8, seed=2))
+    before = m8.state_dict()["enc_img.emb_len"].cpu().clone()
+    m8.load_ckpt(path)
+    after = m8.state_dict()["enc_img.emb_len"].cpu()
+    assert tuple(after.shape) == (1, 8, 1, 768)
+    assert torch.equal(after[:, :6], saved["enc_img.emb_len"]) and torch.equal(after[:, 6:], before[:, 6:])
+    assert torch.equal(m8.state_dict()["trsfr.layer.0.output.dense.weight"].cpu(), saved["trsfr.layer.0.output.dense.weight"])
+    # the bf16 compute copy follows the loaded parameters
+    S = m8.engine.store
+    assert torch.equal(S.shadow[:S.total].float(), S.flat[:S.total].to(torch.bfloat16).float())
+
+
+def test_vq_checkpoint_carries_the_tokenizer(tmp_path):
+    """`dalle.encoder.*` travels with state_dict() / load_state_dict() and `dalle_model_path` loads a pickle."""
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    common = dict(vis_backbone_size="tiny", size_frame=2, max_size_frame=6, arch_override=arch, bert_layers=1, mvm_target=["vq"], dvae_hid=64, dvae_vocab=512)
+    m1, _ = _engine(dict(common, seed=1))
+    sd = m1.state_dict()
+    keys = [k for k in sd if k.startswith("dalle.encoder.blocks.")]
+    assert len(keys) == len(m1.dalle.w) and "dalle.encoder.blocks.output.conv.w" in keys
+    m2, _ = _engine(dict(common, seed=2))
+    assert not torch.equal(m2.dalle.w["blocks.input.w"].cpu(), m1.dalle.w["blocks.input.w"].cpu())
+    missing, unexpected = m2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    assert not unexpected
+    for k in m1.dalle.w:
+        assert torch.equal(m1.dalle.w[k].cpu(), m2.dalle.w[k].cpu()), k
+    pth = os.path.join(str(tmp_path), "encoder.pkl")
+    torch.save({k[len("dalle.encoder."):]: v.cpu() for k, v in sd.items() if k.startswith("dalle.encoder.")}, pth)
+    m3, _ = _engine(dict(common, seed=3, dalle_model_path=pth))
+    assert torch.equal(m3.dalle.w["blocks.group_2.block_1.id_path.w"].cpu(), m1.dalle.w["blocks.group_2.block_1.id_path.w"].cpu())
+
+
+def test_standalone_vidswin_and_encvideo_surface(tmp_path):
+    """get_vidswin_model / load_checkpoint_3d (video_swin.py:573-659) and EncVideo / go_feat (model.py:8-78,174-178): an upstream-style
+    `.pth` ({'state_dict': {'backbone.*'}}) loads with the prefix stripped; the standalone backbone's output equals the oracle's
+    Swin forward; EncVideo returns (B, T*(1+hw), 768) features + a ones mask."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd import visbackbone as VB
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    cfg = R.make_cfg("tiny", T=2, img=96, arch=arch, bert_layers=1)
+    sd = R.make_state_dict(cfg)
+    swin = {k[len("enc_img.swin."):]: v for k, v in sd.items() if k.startswith("enc_img.swin.")}
+    pth = os.path.join(str(tmp_path), "swin_upstream.pth")
+    torch.save({"state_dict": {"backbone." + k: v for k, v in swin.items()}, "meta": {}}, pth)
+    assert set(VB.load_checkpoint_3d(pth)) == set(swin)
+    args = CFG.get_args(vis_backbone_size="tiny", size_img=96, arch_override=arch, vis_backbone_init="3d", vis_backbone_pretrained_weight=pth)
+    m = VB.get_vidswin_model(args)
+    assert m.norm.normalized_shape[0] == 8 * 32
+    img, txt, mask = R.make_batch(cfg, 2)
+    x = img.transpose(1, 2).contiguous()                          # (B,3,T,H,W) as the reference's backbone takes it
+    y = m(x.cuda())
+    assert tuple(y.shape) == (2, 256, 2, 3, 3)
+    with torch.no_grad():
+        yr = R.swin_forward(sd, cfg, x).permute(0, 4, 1, 2, 3)    # oracle: channels-last (B,T,h,w,8E) -> (B,8E,T,h,w)
+    assert _cos(y.float().cpu(), yr) >= 0.999
+    model, _ = _engine(dict(vis_backbone_size="tiny", size_frame=2, max_size_frame=6, arch_override=arch, bert_layers=1, size_img=96))
+    model.load_state_dict(sd)
+    model.eval()
+    feat, fmask = VB.EncVideo(model)(img.cuda())
+    assert tuple(feat.shape) == (2, 2 * (1 + 9), 768) and tuple(fmask.shape) == (2, 20) and int(fmask.min()) == 1
+    with torch.no_grad():
+        fr = R.enc_video(sd, cfg, img)
+    fr = fr[0] if isinstance(fr, (tuple, list)) else fr
+    assert _cos(feat.float().cpu(), fr.reshape(feat.shape)) >= 0.999

@@ -33,6 +33,8 @@ orig = K.gemm
 
 def timed(A, Bm, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if os.environ.get("VMVM_NO_PP") and not kw.get("variant"):
+        kw["variant"] = 6                      # force the 128x128 persistent kernel where the dispatcher would take the 256x256 ping-pong one
     e0.record()
     out = orig(A, Bm, **kw)
     e1.record()
