@@ -625,6 +625,7 @@ class VioletEngine:
         K.cross_entropy(lg_v.view(B, O), O, tgt_v, losses["vtm"], want_grad=False)
         if want_outputs:
             outs["out_vtm"] = lg_v.view(B, O)
+            outs["vtm_cls"] = r_v                       # the [CLS] states the VTM head reads (tests: head gradients on the same inputs)
 
         # ---- MVM pixel head (main_pretrain.py:178-179,420-432)
         ps = cfg["size_patch"]

@@ -113,7 +113,7 @@ def test_reduced_swin_pad_and_temporal_shift_vs_reference_golden():
 @pytest.mark.parametrize("tasks", [("vtm", "mlm", "mvm"), ("vtm", "mlm", "mvm", "smtm")], ids=["default", "smtm"])
 def test_gradients_per_tensor_vs_oracle(tasks):
     """Every parameter gradient of the full step (Swin + fusion + heads; reduced widths, temp=1.0 so the VTM cancellation
-    noise is not amplified) against the CPU oracle's autograd: cosine >= 0.98 and norm within 10% for every tensor whose
+    noise is not amplified) against the CPU oracle's autograd: cosine >= 0.99 and norm within 5% for every tensor whose
     gradient norm is above 1e-3 of the largest one.  `smtm`: with the third (seq2seq-masked) fusion pass."""
     from oracle import violet_ref as R
     arch = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
@@ -147,7 +147,7 @@ def test_gradients_per_tensor_vs_oracle(tasks):
         cos = _cos(got, ref)
         ratio = float(got.norm() / ref.norm())
         checked += 1
-        if cos < 0.98 or abs(ratio - 1.0) > 0.1:
+        if cos < 0.99 or abs(ratio - 1.0) > 0.05:
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert checked > 100 and not bad, (checked, bad[:12])
 
@@ -306,7 +306,7 @@ def test_c5_window_and_sequence_lengths_vs_oracle():
         cos = _cos(got, ref)
         ratio = float(got.norm() / ref.norm())
         checked += 1
-        if cos < 0.98 or abs(ratio - 1.0) > 0.1:
+        if cos < 0.99 or abs(ratio - 1.0) > 0.05:
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert checked > 80 and not bad, (checked, bad[:12])
 

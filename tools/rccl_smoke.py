@@ -1,6 +1,7 @@
 """RCCL smoke at world size 1 (the driver's GPU box has one GPU): torch.distributed backend "nccl" (= RCCL on ROCm) is
 initialised, the gradient reducer is forced on (VMVM_FORCE_DIST=1) and three optimizer steps at the C2 shapes run with the
-side-stream all-reduces issued next to the persistent GEMMs; the parameters must equal the run without a reducer bit for bit.
+side-stream all-reduces issued next to the persistent GEMMs; the reduced gradient must equal the gradient of the run without a
+reducer (up to the run-to-run floor of the f32 atomics).
 Launch: RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=<p> VMVM_FORCE_DIST=1 python tools/rccl_smoke.py [--batch B]"""
 import argparse
 import os
@@ -18,6 +19,7 @@ from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain  # noqa: E402
 
 
 def run(with_reducer, B, steps):
+    """returns (gradient arena of one forward/backward through the hooks, parameters after `steps` optimizer steps)"""
     args = CFG.get_args(vis_backbone_size="base", size_frame=8, max_size_frame=8, mvm_target=["pixel"], max_iter=1000, seed=88)
     model = VIOLET_Pretrain(args, None, device="cuda:0")
     agent = Agent_Pretrain(args, model)
@@ -29,13 +31,27 @@ def run(with_reducer, B, steps):
     random.seed(3); np.random.seed(3); torch.manual_seed(3)
     mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
     rs = np.random.RandomState(11)
-    for _ in range(steps):
-        neg = model.engine.sample_negatives(B, rs)
-        dp = model.engine.sample_drop_path(B, rs)
-        agent.step(mb, is_train=True, negatives=neg, dp_all=dp, sync=False)
+    eng, S = model.engine, model.engine.store
+    neg, dp = eng.sample_negatives(B, rs), eng.sample_drop_path(B, rs)
+    b = dict(img=mb["unmask_img"].float().contiguous(), cov=mb["cov"].contiguous(), txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"])
+    off0 = eng.rng_offset
+    S.grad.zero_()
+    if with_reducer:
+        eng.on_swin_tail_ready = agent.comm.reduce_swin_tail
+        eng.forward_backward(b, negatives=neg, train=True, dp_all=dp, on_other_grads_ready=agent.comm.reduce_other)
+        agent.comm.reduce_swin_and_wait()
+    else:
+        eng.forward_backward(b, negatives=neg, train=True, dp_all=dp)
     torch.cuda.synchronize()
-    S = model.engine.store
-    return S.flat[:S.total].clone()
+    grad = S.grad[:S.n_trainable].clone()
+    S.grad.zero_()
+    eng.rng_offset = off0
+    last = None
+    for _ in range(steps):
+        last = agent.step(mb, is_train=True, negatives=neg, dp_all=dp, sync=True)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in last.values()), last
+    return grad, S.flat[:S.total].clone()
 
 
 def main():
@@ -50,11 +66,17 @@ def main():
     torch.distributed.all_reduce(t)                     # RCCL communicator creation + one collective
     torch.cuda.synchronize()
     assert float(t.sum().item()) == float(1 << 20)
-    p1 = run(True, a.batch, a.steps)
+    g1, p1 = run(True, a.batch, a.steps)
     os.environ.pop("VMVM_FORCE_DIST")                   # D.is_initialized() -> False at world size 1: no reducer
-    p0 = run(False, a.batch, a.steps)
-    same = bool(torch.equal(p0, p1))
-    print(f"rccl world-1: identical={same} max|diff|={float((p0 - p1).abs().max()):.3e} params={p0.numel()}", flush=True)
+    g0, p0 = run(False, a.batch, a.steps)
+    g0b, _ = run(False, a.batch, 1)                     # run-to-run floor of the gradient (f32 atomics in a few reductions)
+    scale = float(g0.abs().max())
+    err, floor = float((g1 - g0).abs().max()) / scale, float((g0b - g0).abs().max()) / scale
+    same = err <= max(4 * floor, 1e-6)
+    # (parameters after AdamW steps are NOT compared bit for bit: a near-zero gradient entry whose last bit differs between two runs
+    #  flips the sign of its Adam update)
+    print(f"rccl world-1: identical={same} grad rel diff {err:.3e} (run-to-run floor {floor:.3e}) |dparam| {float((p0 - p1).abs().max()):.3e} "
+          f"params={p0.numel()}", flush=True)
     torch.distributed.destroy_process_group()
     sys.exit(0 if same else 1)
 
