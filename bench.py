@@ -24,11 +24,29 @@ sys.path.insert(0, ROOT)
 TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x 3 (C2/C3)
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
-# HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_roofline_gemm.txt):
-# FETCH_SIZE 3.97e5 KiB x2 (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 8.42e5 KiB.
-# Algorithmic bytes: A 106 MB + W 4.7 MB + C 425 MB + pre-activation 425 MB = 0.96 GB; the excess read traffic is the
-# 4.7 MB weight panel re-streamed through the 4 MiB L2 (served by the Infinity Cache), 1.17 GB before the tile rasterisation.
-ROOFLINE_TRAFFIC_BYTES = int((2 * 3.97e5 + 8.42e5) * 1024)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
+
+
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the roofline kernel from the COMMITTED counter passes (tools/pmc_roofline.sh -> profiles/):
+    FETCH_SIZE x 2 (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in
+    KiB.  None when the profile is not in the tree."""
+    try:
+        vals, in_gemm = {}, False
+        for line in open(PMC_FILE):
+            if not line.startswith(" "):
+                in_gemm = "gemm_pp_kernel" in line or "gemm_pers_kernel" in line      # values follow their kernel's header line
+                continue
+            if in_gemm:
+                for tok in line.split():
+                    if tok.startswith("FETCH_SIZE=") or tok.startswith("WRITE_SIZE="):
+                        k, v = tok.split("=")
+                        vals.setdefault(k, float(v))
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    except OSError:
+        pass
+    return None
 
 
 def synth_batch(args, B, device, seed):
@@ -49,34 +67,53 @@ def synth_batch(args, B, device, seed):
     return img, txt, mask
 
 
-def time_kernel_gemm(device, reps=20):
-    """Dominant kernel: the bf16 MFMA GEMM at the fusion-encoder FFN shape (M = B*5*432, N=3072, K=768), timed with HIP
-    events on the launching stream.  Returns (avg seconds, algorithmic flops per launch)."""
-    from pytorch_empirical_mvm_amd import kernels as K
-    M, N, Kd = 32 * 5 * 432, 3072, 768
-    A = torch.randn(M, Kd, device=device).to(torch.bfloat16)
-    Bw = torch.randn(N, Kd, device=device).to(torch.bfloat16)
-    bias = torch.zeros(N, device=device)
-    pre = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    for _ in range(3):
-        K.gemm(A, Bw, bias=bias, act=1, out_preact=pre)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        K.gemm(A, Bw, bias=bias, act=1, out_preact=pre)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps / 1e3, 2.0 * M * N * Kd
+class InStepTimers:
+    """HIP events (on the launching stream) around the roofline kernels INSIDE a real training step: the fusion FFN fc1 GEMM
+    (bias + GELU + saved pre-activation; M = B*4*432 rows of the VTM pass, N = 3072, K = 768) and the AdamW launches."""
+
+    def __init__(self, M):
+        self.M, self.gemm, self.adamw = M, [], []
+
+    def __enter__(self):
+        from pytorch_empirical_mvm_amd import kernels as K
+        self.K, self.og, self.oa = K, K.gemm, K.adamw
+        me = self
+
+        def gemm(A, Bm, **kw):
+            hit = kw.get("act", 0) == 1 and kw.get("out_preact") is not None and A.shape[0] == me.M and Bm.shape[0] == 3072 and A.shape[1] == 768
+            if not hit:
+                return me.og(A, Bm, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = me.og(A, Bm, **kw); e1.record()
+            me.gemm.append((e0, e1))
+            return out
+
+        def adamw(p_, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = me.oa(p_, *a, **kw); e1.record()
+            me.adamw.append((e0, e1, p_.numel()))
+            return r
+        K.gemm, K.adamw = gemm, adamw
+        return self
+
+    def __exit__(self, *exc):
+        self.K.gemm, self.K.adamw = self.og, self.oa
+
+    def results(self):
+        torch.cuda.synchronize()
+        g = [a.elapsed_time(b) * 1e-3 for a, b in self.gemm]
+        ad = sum(a.elapsed_time(b) for a, b, _ in self.adamw) * 1e-3
+        n = sum(c for _, _, c in self.adamw)
+        return (sum(g) / len(g) if g else None), len(g), ad, n
 
 
-def cpu_baseline_worker(size, frames, threads):
-    """CPU oracle ('port' of the reference algorithm, validated against the reference's own outputs) on this host:
-    one full train step (fwd + loss + bwd + clip + AdamW, fp32) on a BOUNDED sample of the same workload (1 clip)."""
+def cpu_baseline_worker(size, frames, threads, B=4, timed=2):
+    """CPU oracle ('port' of the reference algorithm, validated against the reference's own outputs) on this host: full train
+    steps (fwd + loss + bwd + clip + AdamW, fp32) on a BOUNDED sample of the same workload: B = 4 clips (so that every clip runs its
+    1 + O = 5 fusion sequences as at B = 32), one warm-up step + `timed` timed steps, `threads` torch threads."""
     from oracle import violet_ref as R
     torch.set_num_threads(threads)
     cfg = R.make_cfg(size, T=frames, img=224, n_txt=32)
-    B = 1
     torch.manual_seed(0)
     sd = {k: (torch.randn(s) * 0.02 if len(s) > 1 else (torch.ones(s) if "norm" in k.lower() and k.endswith("weight") else torch.zeros(s)))
           for k, s in R.param_shapes(cfg).items()}
@@ -85,20 +122,22 @@ def cpu_baseline_worker(size, frames, threads):
     txt[:, 0] = 101
     mask = torch.ones_like(txt)
     mb = R.default_masking(cfg, img, txt, mask, seed=0)
-    t0 = time.time()
-    R.train_step(sd, cfg, mb, {}, 1, 100, negatives=R.vtm_negatives_default(B))
-    dt = time.time() - t0
-    # B=1 runs (1+O)=2 fusion sequences per clip instead of 5: scale the fusion share so the figure is per C2-clip
-    fusion_fix = (281.3 + 0.62 + 5 * 80.26 + 1.54 + 1.85) / (281.3 + 0.62 + 2 * 80.26 + 1.54 + 1.85)
-    print(json.dumps(dict(value=round(1.0 / (dt * fusion_fix), 5), unit="clips/s", cores=threads, kind="port",
-                          sample=f"1 full fp32 train step of oracle/violet_ref.py (fwd+loss+bwd+clip+AdamW), Swin-{size} T={cfg['T']} 224^2, B=1 "
-                                 f"(2 fusion sequences; scaled x{1 / fusion_fix:.3f} to the 5-sequence C2 clip), {dt:.1f} s wall")), flush=True)
+    st, times = {}, []
+    for i in range(1 + timed):
+        t0 = time.time()
+        R.train_step(sd, cfg, mb, st, i + 1, 100, negatives=R.vtm_negatives_default(B))
+        times.append(time.time() - t0)
+    dt = sum(times[1:]) / timed
+    print(json.dumps(dict(value=round(B / dt, 5), unit="clips/s", cores=threads, kind="port", s_per_step=round(dt, 2),
+                          sample=f"{timed} timed full fp32 train steps (after 1 warm-up of {times[0]:.1f} s) of oracle/violet_ref.py (fwd+loss+bwd+clip+AdamW), "
+                                 f"Swin-{size} T={cfg['T']} 224^2, B={B} (5 fusion sequences per clip as in the GPU run), {threads} torch threads: "
+                                 f"{dt:.1f} s/step")), flush=True)
 
 
-def cpu_baseline(size, frames, timeout_s=150):
+def cpu_baseline(size, frames, timeout_s=420):
     """Runs the worker in a CHILD process (bounded by a timeout so the default bench run stays within minutes)."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 16)
+    threads = min(os.cpu_count() or 1, 32)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--size", size, "--frames", str(frames),
                             "--threads", str(threads)], capture_output=True, text=True, timeout=timeout_s,
@@ -195,7 +234,14 @@ def main():
         return
     clips = B * world * a.steps
     value = clips / dt
-    kt, kflop = time_kernel_gemm(device)
+    # one more step with HIP events around the roofline kernels (outside the timed region: the events themselves cost nothing, the
+    # step is the same work)
+    O = min(B, 4)
+    Lq = a.frames * (1 + (a.img // 32) ** 2) + 32
+    with InStepTimers(B * O * Lq) as tm:
+        one_step(a.steps)
+    kt, kcalls, adamw_s, adamw_n = tm.results()
+    kflop = 2.0 * (B * O * Lq) * 3072 * 768
     headline = a.size == "base" and a.frames == 8 and a.img == 224
     window = "(8,12,12)" if (a.size == "large" and a.img == 384) else "(8,7,7)"
     if headline:
@@ -215,13 +261,23 @@ def main():
                                f"{'device-side rm/bm masking inside the timed step' if mask_in_step else 'masking before the timed region'}",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
-        "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                     "frac": round(kflop / kt / PEAK_BF16, 4), "traffic": ROOFLINE_TRAFFIC_BYTES,
-                     "kernel": "gemm_pers_kernel<k-major,k-major,F=bias|GELU|rowscale> fusion FFN fc1+bias+GELU (M=69120,N=3072,K=768), 2*M*N*K flop per launch"},
+        "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                     "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
+                     "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved pre-activation (M={B * O * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
+                               f"gemm_pp_kernel<k-major,k-major,F=bias|GELU|rowscale> 256x256 ping-pong when M*N >= 1024 tiles else gemm_pers_kernel 128x128; "
+                               f"average of the {kcalls} launches of one real step, HIP events on the launching stream",
+                     "algorithmic_bytes": int((B * O * Lq) * 768 * 2 + 3072 * 768 * 2 + 2 * (B * O * Lq) * 3072 * 2),
+                     # the dominant memory-bound kernel of the step, against HBM: fused clip + AdamW over the flat arena
+                     # (f32 p, g, m, v read + p, m, v written + bf16 copy written = 30 B per parameter)
+                     "hbm": {"bound": "hbm", "kernel": "adamw_kernel (4 launches over the parameter arena: clip coefficient + AdamW + bf16 copy)",
+                             "achieved": round(30.0 * adamw_n / adamw_s / 1e9, 1) if adamw_s else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                             "frac": round(30.0 * adamw_n / adamw_s / PEAK_HBM, 4) if adamw_s else None, "algorithmic_bytes": int(30 * adamw_n)}},
         "losses_last_step": last,
     }
     if world == 1 and not a.no_cpu_baseline and a.img == 224:
         out["cpu_baseline"] = cpu_baseline(a.size, a.frames)
+    if kt is None:
+        out["roofline"]["kernel"] += " (not launched at this configuration)"
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
