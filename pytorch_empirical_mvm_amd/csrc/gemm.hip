@@ -1091,6 +1091,32 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   // persistent kernel got cross-tile prefetch and 16-byte stores it is faster than both on every shape of the step.
   bool p3 = direct && !big && dd.variant == 5;
   const int tiles = big ? tiles_big : (p3 ? tiles_p3 : tiles_small);
+  // weight gradients with a long reduction on the 256x256 ping-pong main loop (gemm_pp.h, m/n-major operands through transposing
+  // LDS reads): one round of (tile, K-slice) items over the 256 CUs, f32 slabs + reduce
+  if (direct && plain_acc && !dd.a_kmajor && !dd.b_kmajor && (dd.variant == 0 || dd.variant == 7) && dd.splitk == 0 && dd.workspace &&
+      dd.K >= 4096 && dd.M >= 256 && dd.N >= 256 && !(dd.M & 7) && !(dd.N & 7) &&
+      ((long)dd.M * dd.N >= (1 << 20) || dd.variant == 7)) {       // measured: +7..25 % from 2048x512 up, a loss below (the slabs of a one-round plan are 67 MB whatever the shape)
+    const int t256 = ((dd.M + 255) / 256) * ((dd.N + 255) / 256);
+    int s = 256 / t256;
+    if (s > nk_all_ / 4) s = nk_all_ / 4;
+    if (s < 1) s = 1;
+    const int per = (nk_all_ + s - 1) / s;
+    s = (nk_all_ + per - 1) / per;
+    const size_t need_ws = (size_t)s * dd.M * dd.N * sizeof(float);
+    if (s == 1 || need_ws <= (size_t)dd.workspace_bytes) {
+      vmvm_gemm_desc dp = dd;
+      dp.splitk = s;
+      if (s == 1) dp.workspace = nullptr;
+      const int rc_ = vmvm_gemm_pp(dp, epi_need(dp) | (s > 1 ? EF_SPLIT : 0), st);
+      if (rc_ == VMVM_OK && s > 1) {
+        const long n = (long)dp.M * (dp.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(dp.workspace),
+                           reinterpret_cast<float*>(dp.C), dp.M, dp.N, dp.ldc, s);
+        VMVM_CHECK_LAUNCH();
+      }
+      if (rc_ != VMVM_ENOSUPPORT) return rc_;
+    }
+  }
   if (dd.splitk == 0) {
     dd.splitk = 1;
     if (plain_acc) {
@@ -1175,9 +1201,23 @@ extern "C" int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d) {
     s = ((d->K % BK == 0) ? 512 : 1024) / tiles;
     if (s > nk_all / 4) s = nk_all / 4;
   }
-  if (s < 2) return 0;
-  const int per = (nk_all + s - 1) / s;
-  s = (nk_all + per - 1) / per;
-  return s < 2 ? 0 : (int64_t)s * d->M * d->N * (int64_t)sizeof(float);
+  int64_t need = 0;
+  if (s >= 2) {
+    const int per = (nk_all + s - 1) / s;
+    s = (nk_all + per - 1) / per;
+    if (s >= 2) need = (int64_t)s * d->M * d->N * (int64_t)sizeof(float);
+  }
+  if (d->splitk == 0 && !d->a_kmajor && !d->b_kmajor && d->K % BK == 0 && d->K >= 4096 && d->M >= 256 && d->N >= 256 &&
+      (long)d->M * d->N >= (1 << 20)) {                                                                                       // 256x256 plan
+    int s2 = 256 / (((d->M + 255) / 256) * ((d->N + 255) / 256));
+    if (s2 > nk_all / 4) s2 = nk_all / 4;
+    if (s2 >= 2) {
+      const int per = (nk_all + s2 - 1) / s2;
+      s2 = (nk_all + per - 1) / per;
+      const int64_t n2 = s2 >= 2 ? (int64_t)s2 * d->M * d->N * (int64_t)sizeof(float) : 0;
+      if (n2 > need) need = n2;
+    }
+  }
+  return need;
 }
 

@@ -33,6 +33,22 @@ constexpr int PP_T = 256;                              // tile edge (M and N)
 template <int BK> __device__ __forceinline__ int pp_fsw(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// transposing LDS reads through inline asm (see gemm.hip: the builtin makes the compiler drain the DMA queue in front of every read);
+// the halves are valid only after pp_tr_wait (s_waitcnt lgkmcnt(0) that also ties the registers)
+__device__ __forceinline__ uint32_t pp_lds_addr(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+  return (uint32_t)(size_t)(lds_u8*)p;
+}
+template <int O1, int O2>
+__device__ __forceinline__ void pp_tr_issue2(s16x4& lo, s16x4& hi, uint32_t a) {      // two reads off one address register (16-bit immediates)
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(O1), "n"(O2) : "memory");
+}
+__device__ __forceinline__ bf16x8 pp_tr_cat(const s16x4& a, const s16x4& b) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8_;
+  const s16x8_ v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 constexpr int pp_smem_bytes(int WM, int BK, int NS) { return NS * (WM * 128 + PP_T) * BK * 2 + WM * 4 * 4096; }   // ring + 4 KiB per wave (epilogue re-tiling)
 
 // WM = wave groups along M: 2 -> 512 threads, tile 256x256, one workgroup per CU, the two groups ping-pong (see above);
@@ -41,7 +57,8 @@ constexpr int pp_smem_bytes(int WM, int BK, int NS) { return NS * (WM * 128 + PP
 // DBG (probe builds only): 1 = no epilogue (accumulators kept live), 2 = s_memtime phase timers of block 0 -> p.workspace
 template <bool AK, bool BKM, int F, int WM, int BK, int NS, bool F16 = false, int DBG = 0>
 __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_desc p) {
-  static_assert(AK && BKM, "k-major operands");
+  static_assert(AK == BKM, "both operands k-major (forward / dgrad) or both m/n-major (weight gradient dW = dY^T X)");
+  constexpr bool TR = !AK;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(WM == 1 || WM == 2, "WM");
   static_assert(NS >= 2, "ring depth");
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
   const int x_start = (xcd < rr2) ? xcd * (q2 + 1) : rr2 * (q2 + 1) + (xcd - rr2) * q2;
   const int x_cnt = q2 + (xcd < rr2 ? 1 : 0);
   if (li >= x_cnt) return;                      // whole workgroup: nothing to do
-  const unsigned bytesA = (unsigned)((size_t)M * p.lda * 2), bytesB = (unsigned)((size_t)N * p.ldb * 2);
+  const unsigned bytesA = (unsigned)((size_t)(TR ? K : M) * p.lda * 2), bytesB = (unsigned)((size_t)(TR ? K : N) * p.ldb * 2);
   const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)bytesB, 0x00020000);
 
@@ -100,15 +117,32 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
       iw += per_xcd;
     }
     if (iw < x_cnt) {
+      if (TR) {
+        // m/n-major operand images: [BK k-rows][TM or 256 columns], 32-byte slots XOR-swizzled by ((krow & 3) << 1) so that the
+        // 2 slots x 4 k-rows a half-wave's transposing read touches fall on 8 different bank octets
 #pragma unroll
-      for (int i = 0; i < PDA; ++i) {
-        const int u = tid + i * NT, row = u / CPR, cs = u % CPR;
-        ivA[i] = (unsigned)(((size_t)(m0 + row) * p.lda + ((cs ^ pp_fsw<BK>(row)) * 8)) * 2);
-      }
+        for (int i = 0; i < PDA; ++i) {
+          const int u = tid + i * NT, krow = u / (TM / 8), x = u % (TM / 8);
+          const int src = (((x >> 1) ^ ((krow & 3) << 1)) * 2 + (x & 1)) * 8;
+          ivA[i] = (unsigned)(((size_t)krow * p.lda + m0 + src) * 2);
+        }
 #pragma unroll
-      for (int i = 0; i < PDB; ++i) {
-        const int u = tid + i * NT, row = u / CPR, cs = u % CPR;
-        ivB[i] = (unsigned)(((size_t)(n0 + row) * p.ldb + ((cs ^ pp_fsw<BK>(row)) * 8)) * 2);
+        for (int i = 0; i < PDB; ++i) {
+          const int u = tid + i * NT, krow = u / (PP_T / 8), x = u % (PP_T / 8);
+          const int src = (((x >> 1) ^ ((krow & 3) << 1)) * 2 + (x & 1)) * 8;
+          ivB[i] = (unsigned)(((size_t)krow * p.ldb + n0 + src) * 2);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PDA; ++i) {
+          const int u = tid + i * NT, row = u / CPR, cs = u % CPR;
+          ivA[i] = (unsigned)(((size_t)(m0 + row) * p.lda + ((cs ^ pp_fsw<BK>(row)) * 8)) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < PDB; ++i) {
+          const int u = tid + i * NT, row = u / CPR, cs = u % CPR;
+          ivB[i] = (unsigned)(((size_t)(n0 + row) * p.ldb + ((cs ^ pp_fsw<BK>(row)) * 8)) * 2);
+        }
       }
     } else {                                    // past the end: phantom stages (out-of-range requests) keep the vmcnt arithmetic uniform
 #pragma unroll
@@ -122,9 +156,9 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
   //  hipcc 7.2 silently drops the HOST stub of the kernel)
   auto issue_piece_ = [&](const unsigned* vA, const unsigned* vB, int j) {      // j in [0, P): A pieces first
     unsigned char* st = smem + islot * STB + wave_base * 16;
-    const unsigned so = (unsigned)ikt * (unsigned)(BK * 2);
-    if (j < PDA) { const unsigned vo = vA[j]; __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + j * (NT * 16)), 16, vo, so, 0, 0); }
-    else { const unsigned vo = vB[j - PDA]; __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + OPA + (j - PDA) * (NT * 16)), 16, vo, so, 0, 0); }
+    const unsigned soA = (unsigned)ikt * (unsigned)(TR ? BK * p.lda * 2 : BK * 2), soB = (unsigned)ikt * (unsigned)(TR ? BK * p.ldb * 2 : BK * 2);
+    if (j < PDA) { const unsigned vo = vA[j]; __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + j * (NT * 16)), 16, vo, soA, 0, 0); }
+    else { const unsigned vo = vB[j - PDA]; __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + OPA + (j - PDA) * (NT * 16)), 16, vo, soB, 0, 0); }
   };
   auto issue_stage = [&]() {
 #pragma unroll
@@ -146,6 +180,18 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
       aoff[kk][ks] = rowA * ROWB + ((c ^ pp_fsw<BK>(rowA)) << 4);
       boff[kk][ks] = OPA + rowB * ROWB + ((c ^ pp_fsw<BK>(rowB)) << 4);
     }
+
+  // transposing reads (m/n-major images): 16-lane group g = (column block g & 1, k block g >> 1) of a 32x16 fragment; lane r of the
+  // group addresses piece r & 3 (4 columns, 8 bytes) of k-row r >> 2 and receives column r of the 4 x 16 block.  The B pieces sit at
+  // columns 8 * (p & 1) + 4 * (p >> 1): the same column permutation as rowB above.
+  const int tg = lane >> 4, tr_ = lane & 15;
+  const int tkrow = (tg >> 1) * 8 + (tr_ >> 2), tf = ((tr_ >> 2) & 3) << 1;
+  int toffA[4], toffB[2];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) toffA[mb] = tkrow * (TM * 2) + (((wr * 8 + mb * 2 + (tg & 1)) ^ tf) << 5) + (tr_ & 3) * 8;
+#pragma unroll
+  for (int nb_ = 0; nb_ < 2; ++nb_)
+    toffB[nb_] = OPA + tkrow * (PP_T * 2) + (((wc * 4 + nb_ * 2 + (tg & 1)) ^ tf) << 5) + (((tr_ & 1) * 8 + ((tr_ >> 1) & 1) * 4) * 2);
 
   EpiCtx ec;
   ec.has_drop = p.dropout_p > 0.f; ec.thr = dropout_threshold(p.dropout_p);
@@ -211,6 +257,8 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
       }
     }
 
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = (F & EF_COLSUM) && p.colsum && n0 == 0 && wc == 0;
     tick(-1);
     for (int kt = kt0; kt < nk; ++kt) {
       const unsigned char* sb = smem + cslot * STB;
@@ -226,12 +274,35 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
         }
         tick(1);
         bf16x8 fa[2][4], fb[2][2];
+        s16x4 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
+        if (TR) {
+          const uint32_t sbase = pp_lds_addr(sb);
+          uint32_t aA[4], aB[2];                 // one address register per fragment column block; k position in the immediates
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+          for (int mb = 0; mb < 4; ++mb) aA[mb] = sbase + toffA[mb];
 #pragma unroll
-          for (int nb_ = 0; nb_ < 2; ++nb_) fb[ks][nb_] = *reinterpret_cast<const bf16x8*>(sb + boff[kk][ks] + nb_ * 32 * ROWB);
+          for (int nb_ = 0; nb_ < 2; ++nb_) aB[nb_] = sbase + toffB[nb_];
+#define PP_TR_SET(KK, KS)                                                                                                          \
+          do {                                                                                                                     \
+            constexpr int koB = ((KK) * 32 + (KS) * 16) * (PP_T * 2), koA = ((KK) * 32 + (KS) * 16) * (TM * 2);                    \
+            pp_tr_issue2<koB, koB + 4 * (PP_T * 2)>(blo[KS][0], bhi[KS][0], aB[0]);                                               \
+            pp_tr_issue2<koB, koB + 4 * (PP_T * 2)>(blo[KS][1], bhi[KS][1], aB[1]);                                               \
+            pp_tr_issue2<koA, koA + 4 * (TM * 2)>(alo[KS][0], ahi[KS][0], aA[0]);                                                 \
+            pp_tr_issue2<koA, koA + 4 * (TM * 2)>(alo[KS][1], ahi[KS][1], aA[1]);                                                 \
+            pp_tr_issue2<koA, koA + 4 * (TM * 2)>(alo[KS][2], ahi[KS][2], aA[2]);                                                 \
+            pp_tr_issue2<koA, koA + 4 * (TM * 2)>(alo[KS][3], ahi[KS][3], aA[3]);                                                 \
+          } while (0)
+          if (kk == 0) { PP_TR_SET(0, 0); PP_TR_SET(0, 1); }
+          else { PP_TR_SET(1, 0); PP_TR_SET(1, 1); }
+#undef PP_TR_SET
+        } else {
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) fa[ks][mb] = *reinterpret_cast<const bf16x8*>(sb + aoff[kk][ks] + mb * 32 * ROWB);
+          for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nb_ = 0; nb_ < 2; ++nb_) fb[ks][nb_] = *reinterpret_cast<const bf16x8*>(sb + boff[kk][ks] + nb_ * 32 * ROWB);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) fa[ks][mb] = *reinterpret_cast<const bf16x8*>(sb + aoff[kk][ks] + mb * 32 * ROWB);
+          }
         }
         if (kk == 0) issue_stage();                                    // stage it+NS-1 -> the slot of stage it-1
         if (WM == 2) {
@@ -246,6 +317,34 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           tick(3);
         }
         // ----------------------------- MULTIPLY -----------------------------
+        if (TR) {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(alo[0][0]), "+v"(alo[0][1]), "+v"(alo[0][2]), "+v"(alo[0][3]), "+v"(ahi[0][0]), "+v"(ahi[0][1]), "+v"(ahi[0][2]), "+v"(ahi[0][3]),
+                         "+v"(alo[1][0]), "+v"(alo[1][1]), "+v"(alo[1][2]), "+v"(alo[1][3]), "+v"(ahi[1][0]), "+v"(ahi[1][1]), "+v"(ahi[1][2]), "+v"(ahi[1][3]),
+                         "+v"(blo[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][0]), "+v"(bhi[0][1]), "+v"(blo[1][0]), "+v"(blo[1][1]), "+v"(bhi[1][0]), "+v"(bhi[1][1]));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) fa[ks][mb] = pp_tr_cat(alo[ks][mb], ahi[ks][mb]);
+#pragma unroll
+            for (int nb_ = 0; nb_ < 2; ++nb_) fb[ks][nb_] = pp_tr_cat(blo[ks][nb_], bhi[ks][nb_]);
+          }
+          if ((F & EF_COLSUM) && do_cs) {        // bias gradient: column sums of the m-major A operand (dY), two k per v_dot2c
+            const bf16x2 one2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int mb = 0; mb < 4; ++mb) {
+                // (pairs through shufflevector: with bit_cast(u32x4)[e] -> bit_cast(bf16x2) hipcc 7.2 feeds the FIRST dword to all four)
+                const bf16x8 f8 = fa[ks][mb];
+                csum[mb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f8, f8, 0, 1), one2, csum[mb], false);
+                csum[mb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f8, f8, 2, 3), one2, csum[mb], false);
+                csum[mb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f8, f8, 4, 5), one2, csum[mb], false);
+                csum[mb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f8, f8, 6, 7), one2, csum[mb], false);
+              }
+          }
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -271,6 +370,14 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
       continue;
     }
     ec.slice = slice;
+    if ((F & EF_COLSUM) && do_cs) {              // lanes l and l + 32 hold the two k-halves of column m = ... + (l & 31)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const float t = csum[mb] + __shfl_xor(csum[mb], 32, 64);
+        const int m = m0 + wr * 128 + mb * 32 + l31;
+        if (hh == 0 && m < M) atomicAdd(p.colsum + m, t);
+      }
+    }
     bool rvalid[4]; long rdst[4]; float rrs[4];
 #pragma clang loop unroll(full)
     for (int mb = 0; mb < 4; ++mb) {

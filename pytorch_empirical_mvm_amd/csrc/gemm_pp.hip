@@ -9,10 +9,17 @@ namespace {
 template <int F>
 int launch_nt(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<true, true, F, 2, 64, 2>(d, st); }
 
+template <int F>
+int launch_tn(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<false, false, F, 2, 64, 2>(d, st); }
+
 }  // namespace
 
 // need = epilogue feature mask of the descriptor (epi_need in gemm.hip).  Returns VMVM_ENOSUPPORT when no instantiation covers it.
 int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st) {
+  if (!d.a_kmajor && !d.b_kmajor) {             // weight gradient dW (+)= dY^T X: f32 slabs / accumulate, optional fused bias gradient
+    if ((need & ~(EF_SPLIT | EF_F32)) != 0) return VMVM_ENOSUPPORT;
+    return d.colsum ? launch_tn<(EF_SPLIT | EF_F32 | EF_COLSUM)>(d, st) : launch_tn<(EF_SPLIT | EF_F32)>(d, st);
+  }
   if (!(d.a_kmajor && d.b_kmajor)) return VMVM_ENOSUPPORT;
 #define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_nt<(MASK)>(d, st)
   TRY_EPI(0);

@@ -42,6 +42,135 @@ __global__ void ref_rows_kernel(const u16* A, const u16* B, const int* rows, flo
   R[(size_t)r * N + n] = s;
 }
 
+// weight-gradient form: R[r][n] = sum_k A[k][rows[r]] * B[k][n]   (A [K][M], B [K][N])
+__global__ void ref_rows_tn_kernel(const u16* A, const u16* B, const int* rows, float* R, int M, int N, int K) {
+  const int r = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int m = rows[r];
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(bf2f(A[(size_t)k * M + m]), bf2f(B[(size_t)k * N + n]), s);
+  R[(size_t)r * N + n] = s;
+}
+
+// main loop of the TN build alone: square problems, no split, (a) full, (b) no epilogue, (c) phase timers
+static int run_tn_mainloop(hipStream_t st, int reps) {
+  const int M = 4096, N = 4096, K = 8192;
+  u16 *A, *B; float* C; unsigned* dbg;
+  CK(hipMalloc(&A, (size_t)K * M * 2)); CK(hipMalloc(&B, (size_t)K * N * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&dbg, 256));
+  fill_kernel<<<2048, 256, 0, st>>>(A, (size_t)K * M, 0x1234u);
+  fill_kernel<<<2048, 256, 0, st>>>(B, (size_t)K * N, 0x9876u);
+  vmvm_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = M; d.ldb = N; d.ldc = N; d.col_scale = 1.f; d.out_fp32 = 1; d.splitk = 1;
+  struct V { const char* name; int (*fn)(const vmvm_gemm_desc&, hipStream_t); };
+  const V vs[] = {{"tn64x2", launch_pp_f<false, false, (EF_SPLIT | EF_F32), 2, 64, 2>}, {"tn32x4", launch_pp_f<false, false, (EF_SPLIT | EF_F32), 2, 32, 4>},
+                  {"tn64x2_ne", launch_pp_f<false, false, (EF_SPLIT | EF_F32), 2, 64, 2, 1>}, {"tn32x4_ne", launch_pp_f<false, false, (EF_SPLIT | EF_F32), 2, 32, 4, 1>},
+                  {"tn64x2_t", launch_pp_f<false, false, (EF_SPLIT | EF_F32), 2, 64, 2, 2>},
+                  {"nt64x2_ne(ref)", launch_pp_f<true, true, 0, 2, 64, 2, 1>}};
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  printf("TN main loop M=%d N=%d K=%d\n", M, N, K);
+  for (const V& v : vs) {
+    vmvm_gemm_desc dv = d;
+    if (strstr(v.name, "nt")) { dv.a_kmajor = dv.b_kmajor = 1; dv.lda = dv.ldb = K; dv.out_fp32 = 0; }
+    if (strstr(v.name, "_t")) { CK(hipMemsetAsync(dbg, 0, 256, st)); dv.workspace = dbg; dv.workspace_bytes = 256; }
+    if (v.fn(dv, st)) { printf("  %s rc!=0\n", v.name); continue; }
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) v.fn(dv, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  %-16s %8.1f us  %7.1f TF/s\n", v.name, ms / reps * 1e3, 2.0 * M * N * K / (ms / reps) / 1e9);
+    if (strstr(v.name, "_t")) {
+      unsigned h[64];
+      CK(hipMemcpy(h, dbg, 256, hipMemcpyDeviceToHost));
+      for (int wv = 0; wv < 8; wv += 4) {
+        double tot = 0; for (int i = 0; i < 5; ++i) tot += h[wv * 8 + i];
+        printf("    [wave %d] %%: vmwait %.1f barrier1 %.1f load %.1f barrier2 %.1f multiply %.1f\n", wv, 100 * h[wv * 8] / tot, 100 * h[wv * 8 + 1] / tot,
+               100 * h[wv * 8 + 2] / tot, 100 * h[wv * 8 + 3] / tot, 100 * h[wv * 8 + 4] / tot);
+      }
+    }
+  }
+  return 0;
+}
+
+static int run_tn_suite(hipStream_t st, int reps) {
+  struct Shape { int M, N, K; };
+  const Shape shapes[] = {{3072, 768, 55296}, {768, 3072, 55296}, {2304, 768, 55296}, {768, 768, 55296}, {2048, 512, 50176}, {512, 2048, 50176}, {1536, 512, 50176},
+                          {512, 512, 50176}, {768, 3072, 13824}, {1024, 4096, 12544}, {1000, 520, 8192}};
+  void* ws; const size_t wsb = (size_t)192 << 20;
+  CK(hipMalloc(&ws, wsb));
+  for (const Shape& s : shapes) {
+    const int M = s.M, N = s.N, K = s.K;
+    const int Mp = (M + 7) & ~7, Np = (N + 7) & ~7;
+    u16 *A, *B; float *C, *cs;
+    CK(hipMalloc(&A, (size_t)K * Mp * 2)); CK(hipMalloc(&B, (size_t)K * Np * 2)); CK(hipMalloc(&C, (size_t)M * Np * 4)); CK(hipMalloc(&cs, (size_t)Mp * 4));
+    fill_kernel<<<2048, 256, 0, st>>>(A, (size_t)K * Mp, 0x1234u);
+    fill_kernel<<<2048, 256, 0, st>>>(B, (size_t)K * Np, 0x9876u);
+    const int NR = 32;
+    std::vector<int> rows(NR);
+    for (int i = 0; i < NR; ++i) rows[i] = (int)(((long)i * 7919 * 13) % M);
+    rows[0] = 0; rows[1] = M - 1; rows[2] = std::min(M - 1, 255); rows[3] = std::min(M - 1, 256); rows[4] = std::min(M - 1, 127); rows[5] = std::min(M - 1, 128);
+    int* drows; float* R;
+    CK(hipMalloc(&drows, NR * 4)); CK(hipMalloc(&R, (size_t)NR * N * 4));
+    CK(hipMemcpyAsync(drows, rows.data(), NR * 4, hipMemcpyHostToDevice, st));
+    ref_rows_tn_kernel<<<dim3((N + 255) / 256, NR), 256, 0, st>>>(A, B, drows, R, Mp, Np, K);
+    std::vector<float> hR((size_t)NR * N);
+    CK(hipMemcpyAsync(hR.data(), R, hR.size() * 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    vmvm_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = Mp; d.ldb = Np; d.ldc = Np; d.a_kmajor = 0; d.b_kmajor = 0;
+    d.col_scale = 1.f; d.out_fp32 = 1; d.accumulate = 1; d.workspace = ws; d.workspace_bytes = (int64_t)wsb; d.colsum = cs;
+    printf("TN M=%d N=%d K=%d (f32 accumulate, split-K slabs + reduce, fused column sums)\n", M, N, K);
+    const char* names[2] = {"old128", "auto"};
+    for (int v = 0; v < 2; ++v) {
+      d.variant = v == 0 ? 6 : 0;
+      CK(hipMemsetAsync(C, 0, (size_t)M * Np * 4, st)); CK(hipMemsetAsync(cs, 0, (size_t)Mp * 4, st));
+      int rc = vmvm_gemm_bf16(&d, st);
+      if (rc) { printf("  %-8s rc=%d\n", names[v], rc); continue; }
+      CK(hipStreamSynchronize(st));
+      std::vector<float> hC((size_t)NR * N), hcs(M);
+      for (int r = 0; r < NR; ++r) CK(hipMemcpyAsync(hC.data() + (size_t)r * N, C + (size_t)rows[r] * Np, N * 4, hipMemcpyDeviceToHost, st));
+      CK(hipMemcpyAsync(hcs.data(), cs, M * 4, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      double me = 0;
+      for (size_t i = 0; i < hC.size(); ++i) {
+        const double err = fabs((double)hC[i] - hR[i]) / (fabs((double)hR[i]) * 1e-3 + 1e-3 * sqrt((double)K));
+        if (!(err <= me)) me = err;
+      }
+      // column sums: |sum_k A[k][m]| -- checked against a host sum of the sampled columns
+      std::vector<u16> col(K);
+      double mcs = 0;
+      for (int r = 0; r < 4; ++r) {
+        CK(hipMemcpy2D(col.data(), 2, A + rows[r], (size_t)Mp * 2, 2, K, hipMemcpyDeviceToHost));
+        double sref = 0;
+        for (int k = 0; k < K; ++k) { uint32_t b = (uint32_t)col[k] << 16; float f; memcpy(&f, &b, 4); sref += f; }
+        mcs = std::max(mcs, fabs(sref - hcs[rows[r]]) / (1e-3 * sqrt((double)K) + 1e-3 * fabs(sref)));
+        if (getenv("PROBE_VERBOSE")) printf("    colsum m=%d ref %.4f got %.4f\n", rows[r], sref, hcs[rows[r]]);
+      }
+      std::vector<float> tms;
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int rd = 0; rd < 3; ++rd) {
+        vmvm_gemm_bf16(&d, st);
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) vmvm_gemm_bf16(&d, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        tms.push_back(ms / reps);
+      }
+      std::sort(tms.begin(), tms.end());
+      printf("  %-8s med %8.1f us  %7.1f TF/s  relerr %.3f %s  colsum err %.3f %s\n", names[v], tms[1] * 1e3, 2.0 * M * N * K / tms[1] / 1e9, me, me <= 1.0 ? "ok" : "MISMATCH",
+             mcs, mcs <= 1.0 ? "ok" : "MISMATCH");
+      fflush(stdout);
+    }
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(cs)); CK(hipFree(drows)); CK(hipFree(R));
+  }
+  return 0;
+}
+
 struct Variant { const char* name; int (*fn)(const vmvm_gemm_desc&, hipStream_t); };
 
 static int run_old(const vmvm_gemm_desc& d, hipStream_t st) { vmvm_gemm_desc e = d; e.variant = 6; return vmvm_gemm_bf16(&e, st); }
@@ -75,6 +204,8 @@ int main(int argc, char** argv) {
                  {12544, 4096, 1024}, {8192, 8192, 8192}};
   hipStream_t st;
   CK(hipStreamCreate(&st));
+  if (!strcmp(set, "tn")) return run_tn_suite(st, reps);
+  if (!strcmp(set, "tnloop")) return run_tn_mainloop(st, reps);
   for (const Shape& s : shapes) {
     const int M = s.M, N = s.N, K = s.K;
     u16 *A, *B, *C, *C2;
