@@ -1154,7 +1154,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   // 256x256 tile is not hidden by a second workgroup) and when M*N gives fewer than ~3 rounds of 256 tiles at K < 2048.
   if (pers && pp_shape && (dd.variant == 7 || dd.variant == 0)) {
     const long tiles = (long)((dd.M + 255) / 256) * ((dd.N + 255) / 256);
-    const bool pays = dd.K >= 768 && dd.N >= 512 && (dd.K >= 2048 ? tiles >= 256 : tiles >= 1024);
+    const bool pays = dd.K >= 768 && dd.N >= 512 && (dd.K >= 2048 ? tiles >= 128 : tiles >= 1024);
     if (pays || dd.variant == 7) {
       const int rc_ = vmvm_gemm_pp(dd, epi_need(dd), st);
       if (rc_ != VMVM_ENOSUPPORT) return rc_;

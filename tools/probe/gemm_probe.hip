@@ -200,6 +200,8 @@ int main(int argc, char** argv) {
   else if (!strcmp(set, "big")) shapes = {{8192, 8192, 8192}, {4096, 4096, 4096}};
   else if (!strcmp(set, "k8")) shapes = {{8192, 8192, 8192}};
   else if (!strcmp(set, "fc1")) shapes = {{69120, 3072, 768}};
+  else if (!strcmp(set, "step2")) shapes = {{55296, 3072, 768}, {55296, 768, 3072}, {55296, 2304, 768}, {55296, 768, 2304}, {55296, 768, 768}, {13824, 3072, 768},
+                                            {13824, 768, 3072}, {13824, 2304, 768}, {13824, 768, 768}, {50176, 512, 512}, {12544, 1024, 4096}, {12544, 3072, 1024}};
   else shapes = {{69120, 3072, 768}, {69120, 768, 3072}, {69120, 2304, 768}, {69120, 768, 768}, {50176, 2048, 512}, {50176, 512, 2048}, {50176, 1536, 512},
                  {12544, 4096, 1024}, {8192, 8192, 8192}};
   hipStream_t st;
