@@ -230,7 +230,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     }
     for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
   } else {
-    for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
+    // key mask as an ADDITIVE bias (0 / -inf; also -inf beyond L) in the unused rc slot: score = fma(acc, scale * log2e, kbias[key])
+    // in the log2 domain is one packed FMA per two elements instead of byte compares and selects
+    float* kb = reinterpret_cast<float*>(rc);
+    for (int i = tid; i < sm.lp32; i += NW * 64) {
+      const bool on = (i < L) && (p.keymask ? p.keymask[(size_t)seq * L + i] != 0 : true);
+      reg[i] = on ? 1 : 0;
+      kb[i] = on ? 0.f : NEG_INF;
+    }
   }
   __syncthreads();
 
@@ -239,6 +246,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
   const uint32_t thr8 = drop_thr8(p.dropout_p);
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
+  constexpr bool FAST1 = (MODE == 1) && !CAUSAL;          // fusion encoder: log2-domain packed softmax math
+  const float sc2 = p.scale * 1.4426950408889634f;
 
   for (int qt = wave; qt < nt; qt += NW) {
     const int q = qt * 16 + r;
@@ -282,6 +291,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
             s = KEY_OK(t, key0 + j) ? s : NEG_INF;
             acc[t][j] = s; mx = fmaxf(mx, s);
           }
+        } else if (FAST1) {
+          const float4 k4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rc) + key0);
+          const f32x2 s01 = __builtin_elementwise_fma(f32x2{acc[t][0], acc[t][1]}, f32x2{sc2, sc2}, f32x2{k4.x, k4.y});
+          const f32x2 s23 = __builtin_elementwise_fma(f32x2{acc[t][2], acc[t][3]}, f32x2{sc2, sc2}, f32x2{k4.z, k4.w});
+          acc[t] = f32x4{s01[0], s01[1], s23[0], s23[1]};
+          mx = fmaxf(fmaxf(mx, s01[0]), s01[1]);
+          mx = fmaxf(fmaxf(mx, s23[0]), s23[1]);
         } else {
           const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
           const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -301,14 +317,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
+    if (FAST1) {
+      f32x2 sum2 = f32x2{0.f, 0.f};
+      const f32x2 nmx = f32x2{-mx, -mx};
 #pragma unroll
-    for (int t = 0; t < NT_MAX; ++t) {
+      for (int t = 0; t < NT_MAX; ++t) {
+        const f32x2 d01 = f32x2{acc[t][0], acc[t][1]} + nmx, d23 = f32x2{acc[t][2], acc[t][3]} + nmx;
+        const f32x2 e01 = f32x2{__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+        const f32x2 e23 = f32x2{__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+        acc[t] = f32x4{e01[0], e01[1], e23[0], e23[1]};
+        sum2 += e01; sum2 += e23;
+      }
+      sum = sum2[0] + sum2[1];
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float e = __expf(acc[t][j] - mx); acc[t][j] = e; sum += e; }
+      for (int t = 0; t < NT_MAX; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float e = __expf(acc[t][j] - mx); acc[t][j] = e; sum += e; }
+      }
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = mx + __logf(sum);
+    // saved log-sum-exp stays in natural-log units of the scaled scores (the backward kernels convert)
+    if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = FAST1 ? (mx + __log2f(sum)) * 0.6931471805599453f : mx + __logf(sum);
     if (has_drop) {
       uint4 own = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -319,12 +350,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           const uint4 blk = quad_bcast_i(own, t & 3);
           const uint32_t w = u4_get(blk, q & 3);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
+          for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j];      // the 1/(1-p) keep scale rides on 1/sum below
         }
       }
     }
     if (COLSUM) {                                       // 16 queries of the tile live in one 16-lane row: xor-shuffles 1..8 stay inside it
-      const float wq = qv ? p.att_scale / sum : 0.f;
+      const float wq = qv ? p.att_scale * keep / sum : 0.f;
       float* cs = p.att_colsum + (size_t)seq * L;
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
       }
     }
     if (qv) {
-      const float inv = seq_scale / sum;
+      const float inv = seq_scale * keep / sum;
       u16* op = reinterpret_cast<u16*>(p.out) + ((size_t)seq * L + q) * p.ld_out + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt)
@@ -408,11 +439,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
   if (MODE == 0) {
     for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (p.region && i < L) ? p.region[(size_t)(seq % p.n_win) * L + i] : 0;
   } else {
-    for (int i = tid; i < sm.lp32; i += NW * 64) reg[i] = (i < L) ? (p.keymask ? p.keymask[(size_t)seq * L + i] : 1) : 0;
+    float* kb = reinterpret_cast<float*>(rc);          // additive key mask (0 / -inf), see attn_fwd_kernel
+    for (int i = tid; i < sm.lp32; i += NW * 64) {
+      const bool on = (i < L) && (p.keymask ? p.keymask[(size_t)seq * L + i] != 0 : true);
+      reg[i] = on ? 1 : 0;
+      kb[i] = on ? 0.f : NEG_INF;
+    }
   }
   __syncthreads();
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  constexpr bool FAST1 = (MODE == 1) && !CAUSAL;
+  const float sc2 = p.scale * 1.4426950408889634f, cdk = seq_scale * keep;
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
 
@@ -433,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
     dl += __shfl_xor(dl, 32, 64);             // delta_q = sum_d dO'[q,d] * out'[q,d]
     if (g == 0 && qv) delta_g[q] = dl;
     const float lse = qv ? lse_g[q] : 0.f;
+    const float lse2 = qv ? lse * 1.4426950408889634f : __builtin_huge_valf();
     const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
     const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
 
@@ -481,6 +520,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
               ds[u][j] = d;
               if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], d);
             }
+          } else if (FAST1) {
+            // log2 domain, two elements per instruction: P = exp2(fma(S, scale*log2e, kbias[key]) - lse*log2e) (lse2 = +inf on padded
+            // rows), dS = P * (keep-scaled dP under the dropout mask - delta)
+            const float4 k4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rc) + key0);
+            const f32x2 nl = f32x2{-lse2, -lse2}, ndl = f32x2{-dl, -dl}, c2 = f32x2{cdk, cdk};
+            const f32x2 x01 = __builtin_elementwise_fma(f32x2{s4[0], s4[1]}, f32x2{sc2, sc2}, f32x2{k4.x, k4.y}) + nl;
+            const f32x2 x23 = __builtin_elementwise_fma(f32x2{s4[2], s4[3]}, f32x2{sc2, sc2}, f32x2{k4.z, k4.w}) + nl;
+            const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+            const f32x2 d01 = f32x2{dp4[0], dp4[1]} * c2, d23 = f32x2{dp4[2], dp4[3]} * c2;
+            float dp[4] = {d01[0], d01[1], d23[0], d23[1]};
+            if (has_drop) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dp[j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dp[j];
+            }
+            const f32x2 o01 = f32x2{pr[0], pr[1]} * (f32x2{dp[0], dp[1]} + ndl), o23 = f32x2{pr[2], pr[3]} * (f32x2{dp[2], dp[3]} + ndl);
+            ds[u][0] = o01[0]; ds[u][1] = o01[1]; ds[u][2] = o23[0]; ds[u][3] = o23[1];
           } else {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
             const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -1132,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   const float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
   for (int i = tid; i < sm.lp32; i += NW * 64) {
-    lse_s[i] = i < L ? lse_g[i] : __builtin_huge_valf();       // +inf -> p = 0 for padded queries
+    lse_s[i] = i < L ? lse_g[i] * ((MODE == 1 && !CAUSAL) ? 1.4426950408889634f : 1.0f) : __builtin_huge_valf();       // +inf -> p = 0 for padded queries (fusion build: log2 units)
     delta_s[i] = i < L ? delta_g[i] : 0.f;
     if (MODE == 0) {
       rc[i] = i < L ? p.rc[i] : 0;
@@ -1150,6 +1205,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   const uint32_t thr8 = drop_thr8(p.dropout_p);
   const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
+  constexpr bool FAST1 = (MODE == 1) && !CAUSAL;
+  const float sc2 = p.scale * 1.4426950408889634f, cdk = seq_scale * keep;
 
   // each wave owns TWO key tiles at a time: the Q / dO fragments (k = hd) and the transposed Q^T / dO^T fragments
   // (k = tokens) are read from LDS once and feed both tiles -> half the LDS traffic per MFMA.
@@ -1230,6 +1287,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 if ((qt & 3) == 0) own[t] = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)((qt + (lane & 3)) * 4 + g), (uint32_t)(key[t] >> 2));
                 blk = (c & 1) ? (u ? quad_bcast<3>(own[t]) : quad_bcast<2>(own[t])) : (u ? quad_bcast<1>(own[t]) : quad_bcast<0>(own[t]));
               }
+              if (FAST1) {
+                // log2 domain, packed: the key's additive mask and the queries' lse fold into one offset per query; the keep scale
+                // of P rides on the final dV scale
+                const float kbk = (kv[t] && regk[t]) ? 0.f : NEG_INF;
+                const f32x2 off01 = f32x2{kbk, kbk} - f32x2{ls[0], ls[1]}, off23 = f32x2{kbk, kbk} - f32x2{ls[2], ls[3]};
+                const f32x2 x01 = __builtin_elementwise_fma(f32x2{s4[t][0], s4[t][1]}, f32x2{sc2, sc2}, off01);
+                const f32x2 x23 = __builtin_elementwise_fma(f32x2{s4[t][2], s4[t][3]}, f32x2{sc2, sc2}, off23);
+                const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+                const f32x2 c2 = f32x2{cdk, cdk};
+                const f32x2 d01 = f32x2{dp4[t][0], dp4[t][1]} * c2, d23 = f32x2{dp4[t][2], dp4[t][3]} * c2;
+                float dp[4] = {d01[0], d01[1], d23[0], d23[1]}, pj[4] = {pr[0], pr[1], pr[2], pr[3]};
+                if (has_drop) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                    dp[j] = dropped ? 0.f : dp[j];
+                    pj[j] = dropped ? 0.f : pj[j];
+                  }
+                }
+                const f32x2 o01 = f32x2{pr[0], pr[1]} * (f32x2{dp[0], dp[1]} - f32x2{dls[0], dls[1]});
+                const f32x2 o23 = f32x2{pr[2], pr[3]} * (f32x2{dp[2], dp[3]} - f32x2{dls[2], dls[3]});
+                pt[t][u][0] = pj[0]; pt[t][u][1] = pj[1]; pt[t][u][2] = pj[2]; pt[t][u][3] = pj[3];
+                ds[t][u][0] = o01[0]; ds[t][u][1] = o01[1]; ds[t][u][2] = o23[0]; ds[t][u][3] = o23[1];
+              } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 bool ok = kv[t] && regk[t];
@@ -1243,6 +1324,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 }
                 pt[t][u][j] = pj;
                 ds[t][u][j] = pr * (dpj - dls[j]);
+              }
               }
             }
           }
@@ -1268,12 +1350,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
       if (kv[t]) {
         u16* base = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + key[t]) * pb.ld_dqkv + h * HD + g * 4;
         const float ksc = (MODE == 1) ? p.scale : 1.0f;
+        const float vsc = FAST1 ? cdk : seq_scale;           // fusion build: P carries no keep scale, dV does
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
           *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
               make_uint2(pack_bf2(dk[t][dt][0] * ksc, dk[t][dt][1] * ksc), pack_bf2(dk[t][dt][2] * ksc, dk[t][dt][3] * ksc));
           *reinterpret_cast<uint2*>(base + p.v_off + dt * 16) =
-              make_uint2(pack_bf2(dv[t][dt][0] * seq_scale, dv[t][dt][1] * seq_scale), pack_bf2(dv[t][dt][2] * seq_scale, dv[t][dt][3] * seq_scale));
+              make_uint2(pack_bf2(dv[t][dt][0] * vsc, dv[t][dt][1] * vsc), pack_bf2(dv[t][dt][2] * vsc, dv[t][dt][3] * vsc));
         }
       }
     }

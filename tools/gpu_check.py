@@ -853,6 +853,8 @@ if __name__ == "__main__":
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
+        elif w == "benchattn":
+            run(bench_attn)
         elif w == "benchln":
             run(bench_ln)
         else:
