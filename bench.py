@@ -227,6 +227,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     last = {k: float(v.item()) for k, v in losses.items()}
+    # one more step with HIP events around the roofline kernels (outside the timed region: the events themselves cost nothing, the
+    # step is the same work).  EVERY rank runs it: the step holds the gradient collectives.
+    O = min(B, 4)
+    Lq = a.frames * (1 + (a.img // 32) ** 2) + 32
+    with InStepTimers(B * O * Lq) as tm:
+        one_step(a.steps)
+    torch.cuda.synchronize()
     if rank != 0:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.barrier()
@@ -234,12 +241,6 @@ def main():
         return
     clips = B * world * a.steps
     value = clips / dt
-    # one more step with HIP events around the roofline kernels (outside the timed region: the events themselves cost nothing, the
-    # step is the same work)
-    O = min(B, 4)
-    Lq = a.frames * (1 + (a.img // 32) ** 2) + 32
-    with InStepTimers(B * O * Lq) as tm:
-        one_step(a.steps)
     kt, kcalls, adamw_s, adamw_n = tm.results()
     kflop = 2.0 * (B * O * Lq) * 3072 * 768
     headline = a.size == "base" and a.frames == 8 and a.img == 224

@@ -72,10 +72,14 @@ def main():
     g0b, _ = run(False, a.batch, 1)                     # run-to-run floor of the gradient (f32 atomics in a few reductions)
     scale = float(g0.abs().max())
     err, floor = float((g1 - g0).abs().max()) / scale, float((g0b - g0).abs().max()) / scale
-    same = err <= max(4 * floor, 1e-6)
+    n0 = float(g0.double().norm())
+    err2, floor2 = float((g1 - g0).double().norm()) / n0, float((g0b - g0).double().norm()) / n0
+    # a segment reduced twice / not at all is an O(1) relative error of its entries; the atomics' reordering noise is ~1e-6 and its
+    # maximum over 2e8 entries varies a few-fold from run to run, hence the generous multiple of the floor
+    same = err <= max(20 * floor, 1e-4) and err2 <= max(20 * floor2, 1e-5)
     # (parameters after AdamW steps are NOT compared bit for bit: a near-zero gradient entry whose last bit differs between two runs
     #  flips the sign of its Adam update)
-    print(f"rccl world-1: identical={same} grad rel diff {err:.3e} (run-to-run floor {floor:.3e}) |dparam| {float((p0 - p1).abs().max()):.3e} "
+    print(f"rccl world-1: identical={same} grad rel diff max {err:.3e} l2 {err2:.3e} (run-to-run floor {floor:.3e} / {floor2:.3e}) |dparam| {float((p0 - p1).abs().max()):.3e} "
           f"params={p0.numel()}", flush=True)
     torch.distributed.destroy_process_group()
     sys.exit(0 if same else 1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Microbenchmark of the epilogue-heavy GEMM forms of the step (fc1 + bias + GELU + pre-activation; fc2 dgrad x GELU')."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pytorch_empirical_mvm_amd import kernels as K
 dev = "cuda:0"
 def rnd(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)

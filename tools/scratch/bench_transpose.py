@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from pytorch_empirical_mvm_amd import config as CFG, kernels as K  # noqa: E402
 from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain  # noqa: E402
 

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import violet_ref as R
 from pytorch_empirical_mvm_amd import config as CFG, kernels as K
 from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain

@@ -2,7 +2,7 @@
 """Diagnostic: stage-by-stage comparison of the HIP pretraining forward against the CPU oracle + optimizer trajectory."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import violet_ref as R
 from pytorch_empirical_mvm_amd import config as CFG, kernels as K
 from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain

@@ -2,7 +2,7 @@
 """Diagnostic: per-block comparison of the HIP Swin forward against the CPU oracle (fp32) on the reduced config."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import violet_ref as R
 from pytorch_empirical_mvm_amd import config as CFG, kernels as K, swin_index as SI
 from pytorch_empirical_mvm_amd.engine import VioletEngine, V

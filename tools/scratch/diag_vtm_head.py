@@ -1,7 +1,7 @@
 """diagnostic: VTM head gradients of the HIP path vs the oracle's head on the same [CLS] rows"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from oracle import violet_ref as R
 from pytorch_empirical_mvm_amd import config as CFG
 from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
