@@ -26,6 +26,23 @@ def _trunc_normal_(t, std, gen):
     return t
 
 
+def swinbert_renames(loaded):
+    """model.py:355-386 (`load_SwinBERT_weight`): key renames of a SwinBERT checkpoint (file name contains "SwinBERT") onto this
+    model's names; keys without a counterpart are dropped, the MLM decoder bias is the shared `predictions.bias`."""
+    rules = (("swin.backbone", "enc_img.swin", False), ("trans_encoder.bert.encoder", "trsfr", False),
+             ("trans_encoder.bert.embeddings", "enc_txt.emb_txt", False), ("fc.", "enc_img.fc.", True),
+             ("trans_encoder.bert.img_embedding", "enc_img.img_embedding", False), ("trans_encoder.cls.", "fc_mtm.", True))
+    out = {}
+    for k, v in loaded.items():
+        for old, new, prefix in rules:
+            if (k.startswith(old) if prefix else old in k):
+                out[k.replace(old, new)] = v
+                break
+    if "fc_mtm.predictions.bias" in out:
+        out["fc_mtm.predictions.decoder.bias"] = out["fc_mtm.predictions.bias"]
+    return out
+
+
 class VIOLET_Pretrain(torch.nn.Module):
     def __init__(self, args, tokzr=None, device="cuda"):
         super().__init__()
@@ -177,6 +194,8 @@ class VIOLET_Pretrain(torch.nn.Module):
         if ckpt == "" or not os.path.exists(ckpt):
             return
         loaded = torch.load(ckpt, map_location="cpu")
+        if "SwinBERT" in os.path.splitext(os.path.basename(ckpt))[0]:
+            loaded = swinbert_renames(loaded)
         own = super().state_dict()
         toload = {k: v for k, v in loaded.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
         for k, dim in (("enc_img.emb_len", 1), ("enc_img.emb_pos", 2)):

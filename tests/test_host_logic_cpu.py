@@ -208,3 +208,25 @@ def test_checkpoint_key_lists_of_targets_teachers_and_downstream_heads():
             mine = TCH.hf_swin2d_param_shapes(arch, "feature_model.", 7)
         assert {k: tuple(v) for k, v in mine.items()} == {k: tuple(v) for k, v in ref.items()}, kind
         assert len(ref) > 300
+
+
+def test_swinbert_checkpoint_key_renames():
+    """model.py:355-386 (`load_SwinBERT_weight`): the rename table of a SwinBERT checkpoint, rule priority included (a key holding
+    `swin.backbone` is a backbone key even when it starts with `fc.`-like text), dropped keys, the duplicated MLM decoder bias."""
+    from pytorch_empirical_mvm_amd.model import swinbert_renames
+    t = lambda i: torch.full((1,), float(i))
+    src = {"swin.backbone.layers.0.blocks.0.attn.qkv.weight": t(0), "trans_encoder.bert.encoder.layer.3.output.dense.bias": t(1),
+           "trans_encoder.bert.embeddings.word_embeddings.weight": t(2), "fc.weight": t(3), "trans_encoder.bert.img_embedding.weight": t(4),
+           "trans_encoder.cls.predictions.bias": t(5), "trans_encoder.cls.predictions.transform.dense.weight": t(6),
+           "learn_mask_enabled": t(7), "module.fc.weight": t(8)}
+    out = swinbert_renames(src)
+    want = {"enc_img.swin.layers.0.blocks.0.attn.qkv.weight": 0, "trsfr.layer.3.output.dense.bias": 1, "enc_txt.emb_txt.word_embeddings.weight": 2,
+            "enc_img.fc.weight": 3, "enc_img.img_embedding.weight": 4, "fc_mtm.predictions.bias": 5, "fc_mtm.predictions.decoder.bias": 5,
+            "fc_mtm.predictions.transform.dense.weight": 6}
+    assert set(out) == set(want), sorted(out)
+    for k, v in want.items():
+        assert float(out[k]) == v, k
+    # the renamed names are this model's names
+    inv = set(R.param_shapes(R.make_cfg("base", T=8)))
+    assert {"enc_img.swin.layers.0.blocks.0.attn.qkv.weight", "trsfr.layer.3.output.dense.bias", "enc_txt.emb_txt.word_embeddings.weight",
+            "fc_mtm.predictions.bias", "fc_mtm.predictions.transform.dense.weight"} <= inv
