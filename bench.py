@@ -200,9 +200,9 @@ def main():
         mb = agent.masking(img, txt, mask, None)
         batches.append(agent.prepare_batch(mb))
     torch.cuda.synchronize()
-    # masking INSIDE the timed step (device-side, vmvm_masking; fresh rm/bm draws every step) for the pixel target; the vq
-    # target needs host-built index lists of the covered patches, so its batches are masked before the timed region
-    mask_in_step = (a.mvm_target != "vq") and not a.host_masking
+    # masking INSIDE the timed step (device-side, vmvm_masking; fresh rm/bm draws every step); for the vq target that includes the
+    # device-built index lists of the covered patches and their one count read-back
+    mask_in_step = not a.host_masking
     gen = torch.Generator(device=device).manual_seed(88 + rank)
 
     def one_step(i):

@@ -43,7 +43,7 @@ int vmvm_last_hip_error(void);
  * a chunk straddling the logical extent must still lie inside the row); N%4==0.
  * Epilogue order: v = acc; v += bias[n]; v *= col_scale (n < col_scale_n);
  *   act (0 none, 1 GELU-erf [C2 receives the pre-activation], 2 ReLU, 3 multiply by GELU'(aux[m,n]),
- *        4 multiply by (aux[m,n] > 0));
+ *        4 multiply by (aux[m,n] > 0), 5 fused arg-max [fp16 builds, see a_relu below]);
  *   v *= row_scale[m/rows_per_scale] ; dropout(p, Philox(seed, offset + m*N+n)) ; + resid[dst,n] ; store at row dst where
  *   dst = row_map ? row_map[m % map_len] + (m / map_len) * map_stride : m   (dst < 0 -> row skipped).
  * ------------------------------------------------------------------------------------------ */
@@ -81,6 +81,12 @@ typedef struct {
    * A(m,k) B(n,k)) with alpha = 1 / (scale_A * scale_B) of the per-tensor quantisation (vmvm_cast_bf16_to_fp8); bias, act 1 (GELU,
    * + C2 pre-activation) / 2 (ReLU), resid, bf16 or f32 output.  MFMA: v_mfma_scale_f32_16x16x128_f8f6f4, block scales 1.0. */
   int32_t in_fp8; float alpha;
+  /* fp16 builds only.  a_relu = 1: the A operand is read through max(., 0) (the ReLU in front of conv_1 / the output conv of the
+   * dVAE encoder, visbackbone/dalle/encoder.py:27,70, applied to the fragments instead of in a pass over the activation).
+   * act = 5 (1x1 only, out_fp32 = 1, N % 64 == 0): fused arg-max -- nothing is stored but, per row m and 64-column group q, the
+   * pair C[m*ldc + 2q] = max_n (acc + bias)[m, 64q .. 64q+63], C[m*ldc + 2q + 1] = that column's index (int32 bit pattern; ties:
+   * the smaller column); ldc >= 2 * N / 64.  vmvm_argmax_pairs() reduces the pairs to token ids (visbackbone/dalle/__init__.py:53). */
+  int32_t a_relu;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 /* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never
@@ -88,6 +94,19 @@ int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d);
 /* dst[i] (OCP e4m3, saturating at +-448) = src[i] (bf16) * scale ; n a multiple of 8 */
 int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frozen DALL-E dVAE tokenizer (MVM 'vq' target): the passes around its convolution GEMMs.
+ *   vmvm_dvae_stem_im2col: DalleModel.preprocess (visbackbone/dalle/__init__.py:38-42: un-normalise, map_pixels utils.py:46-52) fused
+ *     with the im2col of the 7x7 stem (encoder.py:59).  img [n][3][H][W] f32 ImageNet-normalised -> cols fp16 [n*H*W][192] with
+ *     k = ky*24 + kx*3 + c (kx < 7; the other columns zero); the stem is then vmvm_gemm_bf16(in_fp16) against a [n_hid][192] weight.
+ *   vmvm_maxpool2x2_nhwc_f16: nn.MaxPool2d(2) (encoder.py:62,66,70) on an NHWC fp16 activation [n][H][W][C] -> [n][H/2][W/2][C]; C % 8 == 0.
+ *   vmvm_argmax_pairs: torch.argmax(z_logits, 1) (__init__.py:53) from the (maximum, column) pairs the act = 5 GEMM epilogue leaves
+ *     per 64-column group: pairs f32 [M][ld], `groups` pairs per row -> out int64 [M].
+ * ------------------------------------------------------------------------------------------ */
+int vmvm_dvae_stem_im2col(const float* img, void* cols, int32_t n_img, int32_t H, int32_t W, void* stream);
+int vmvm_maxpool2x2_nhwc_f16(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, void* stream);
+int vmvm_argmax_pairs(const float* pairs, int32_t ld, int32_t M, int32_t groups, int64_t* out, void* stream);
 
 /* column sums  out[n] (+)= sum_m scale[m/rows_per_scale] * X[m,n]   (bias gradients)  X bf16 [M][ldx], out f32 */
 int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale,

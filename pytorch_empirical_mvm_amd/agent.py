@@ -160,17 +160,27 @@ class Agent_Pretrain:
         out = {"img": img, "unmask_img": img, "txt": txt, "mask": mask, "ans_mtm": ans_mtm, "cov": cov,
                "ans_mvm": torch.full((B, T * (1 + h * w)), -1, dtype=torch.long, device=dev)}
         if "vq" in self.args.mvm_target:
-            out.update(self.vq_index(cov))              # index lists are built on the host (one sync)
+            out.update(self.vq_index(cov))              # index lists built on the device (one count read-back)
         return out
 
     def vq_index(self, cov):
-        """Host-side index lists for the vq head (main_pretrain.py:485-488): a vq position is a target iff its 32x32 patch is
-        covered, so the head only runs on covered patches.  patch_rows: rows of the MVM output (B*(T*(1+hw)+X) layout of the
-        fusion output) ; tok_index: for each covered patch its 16 token positions (i-major, j-minor) in the (B*T, 28, 28) map."""
+        """Index lists for the vq head (main_pretrain.py:485-488): a vq position is a target iff its 32x32 patch is covered, so the
+        head only runs on covered patches.  patch_rows: rows of the MVM output (B*(T*(1+hw)+X) layout of the fusion output);
+        tok_index: for each covered patch its 16 token positions (i-major, j-minor) in the (B*T, 28, 28) map.  Built where `cov`
+        lives: on the device for masking_device (torch.nonzero reads the count back -- the one host sync of that path; the step's
+        GEMM sizes depend on it), in numpy for the host masking path."""
         B, T, h, w = cov.shape
         up = self.patch_size // 8
         vs_h, vs_w = h * up, w * up
         Lq = T * (1 + h * w) + int(self.args.size_txt)
+        if cov.is_cuda:
+            nz = torch.nonzero(cov)                                       # row-major order = numpy's
+            b, t, hh, ww = nz[:, 0], nz[:, 1], nz[:, 2], nz[:, 3]
+            rows = (b * Lq + t * (1 + h * w) + 1 + hh * w + ww).to(torch.int32)
+            ar = torch.arange(up, device=cov.device)
+            ii, jj = ar.repeat_interleave(up).view(1, -1), ar.repeat(up).view(1, -1)
+            tok = ((b * T + t)[:, None] * vs_h + (hh[:, None] * up + ii)) * vs_w + ww[:, None] * up + jj
+            return {"vq_patch_rows": rows.contiguous(), "vq_tok_index": tok.reshape(-1).contiguous()}
         b, t, hh, ww = np.nonzero(cov.cpu().numpy())
         rows = b * Lq + t * (1 + h * w) + 1 + hh * w + ww
         ii, jj = np.meshgrid(np.arange(up), np.arange(up), indexing="ij")

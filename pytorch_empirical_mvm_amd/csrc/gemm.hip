@@ -664,11 +664,21 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // FP8: A and B are OCP e4m3 bytes (k-major both); the descriptor reaches the kernel with K / lda / ldb counted in 2-byte units, so
 // the staging is unchanged: a 64-"element" K tile is 128 fp8 = one v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair (a lane's
 // operand = the two 16-byte chunks 2g, 2g+1 of its row; block scales fixed at 1.0, the per-tensor scale product is `alpha`).
-template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false, bool FP8 = false>
+// TM = 2: tile 256 (M) x 64 (N), the four waves stacked along M (64 x 64 each as in the square tile) -- the dVAE's group-1
+// convolutions have 64 output channels, on a 128-wide tile half of every MFMA multiplies zero padding.  ARELU: max(A, 0) on the A
+// fragments after the LDS read (fp16 builds: the block-input ReLU of the dVAE's residual path, encoder.py:27-28, without a pass
+// over the activation); one v_pk_max_f16 per MFMA, in its shadow.  F & EF_ARGMAX: instead of storing, each 64-column group of a
+// row leaves its (maximum, column) pair in C (f32 [M][ldc], pairs at 2 * (n / 64)) -- the 8192-wide logits are never written.
+template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false, bool FP8 = false, int TM = 1, bool ARELU = false>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
+  static_assert(TM == 1 || (TM == 2 && AK && BKM && !FP8 && !(F & EF_COLSUM)), "the 256x64 tile serves k-major x k-major operands");
+  static_assert(!ARELU || (F16 && AK), "A-operand ReLU: fp16 k-major build");
+  constexpr int BM = TM == 2 ? 256 : 128, BN = TM == 2 ? 64 : 128;        // (shadow the file-scope square tile)
+  constexpr int NA = BM / 32, NB = BN / 32;                                 // 16-byte DMA requests per thread per operand tile
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TM == 2 ? wave : (wave >> 1), wn = TM == 2 ? 0 : (wave & 1);
   const int M = p.M, N = p.N, K = p.K;
   const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM;
   const int nb = nbm * nbn;
@@ -711,9 +721,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   // vector address arithmetic was ~30 of the ~100 non-MFMA issue slots of a K step.)
   const int wave_base_s = __builtin_amdgcn_readfirstlane(tid & ~63);
   const unsigned kstepA = (unsigned)((AK ? BK : BK * p.lda) * 2), kstepB = (unsigned)((BKM ? BK : BK * p.ldb) * 2);
-  auto tile_offsets = [&](int m0, int n0, unsigned (&vA)[4], unsigned (&vB)[4], int (&py)[4], int (&px)[4]) {
+  auto tile_offsets = [&](int m0, int n0, unsigned (&vA)[NA], unsigned (&vB)[NB], int (&py)[NA], int (&px)[NA]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int u = tid + i * 256;
       py[i] = 0; px[i] = 0;
       if (CONV) {                                           // pixel (y, x) of this request's row; rows >= M are parked outside the image
@@ -724,6 +734,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       if (AK) { const int row = u >> 3, cs = u & 7; vA[i] = (unsigned)(((size_t)(m0 + row) * p.lda + (cs ^ kswz<false>(row)) * 8) * 2); }
       else { const int krow = u >> 4, unit = u & 15; const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
              vA[i] = (unsigned)(((size_t)krow * p.lda + m0 + (slot * 2 + (unit & 1)) * 8) * 2); }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int u = tid + i * 256;
       if (BKM) { const int row = u >> 3, cs = u & 7; vB[i] = (unsigned)(((size_t)(n0 + row) * p.ldb + (cs ^ kswz<true>(row)) * 8) * 2); }
       else { const int krow = u >> 4, unit = u & 15; const int slot = ((unit >> 1) ^ swz_m(krow)) & 7;
              vB[i] = (unsigned)(((size_t)krow * p.ldb + n0 + (slot * 2 + (unit & 1)) * 8) * 2); }
@@ -731,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   };
   auto issue = [&](const unsigned* vA, const unsigned* vB, const int* py, const int* px, int kt, int buf) {
     typedef __attribute__((address_space(3))) void lds_void;
-    unsigned char* st = smem + buf * 2 * TILE_BYTES + wave_base_s * 16;
+    unsigned char* st = smem + buf * STAGE_BYTES + wave_base_s * 16;
     unsigned sa = (unsigned)kt * kstepA;
     const unsigned sb = (unsigned)kt * kstepB;
     int dy = 0, dx = 0;
@@ -741,13 +755,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       sa = (unsigned)(((dy + 1) * p.conv_w + (dx + 1)) * cC + cb * 64) * 2u;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       unsigned vo = vA[i];
       if (CONV) vo = ((unsigned)(py[i] + dy) < (unsigned)p.conv_h && (unsigned)(px[i] + dx) < (unsigned)p.conv_w) ? vo : a_records;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(st + i * 4096), 16, vo, sa, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + TILE_BYTES + i * 4096), 16, vB[i], sb, 0, 0);
+    for (int i = 0; i < NB; ++i) {
+      const unsigned vo = vB[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(st + A_BYTES + i * 4096), 16, vo, sb, 0, 0);
+    }
   };
 
   int w = li;
@@ -755,8 +772,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
   unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
-  unsigned voA[4], voB[4], nvoA[4], nvoB[4];
-  int pyA[4], pxA[4], npyA[4], npxA[4];
+  unsigned voA[NA], voB[NB], nvoA[NA], nvoB[NB];
+  int pyA[NA], pxA[NA], npyA[NA], npxA[NA];
   tile_offsets(m0, n0, voA, voB, pyA, pxA);
   issue(voA, voB, pyA, pxA, kt0, it & 1);
   while (true) {
@@ -779,8 +796,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
       const int cur = it & 1;
-      const unsigned char* la = smem + cur * 2 * TILE_BYTES;
-      const unsigned char* lb = la + TILE_BYTES;
+      const unsigned char* la = smem + cur * STAGE_BYTES;
+      const unsigned char* lb = la + A_BYTES;
       if (FP8) {
         typedef __attribute__((ext_vector_type(8))) int i32x8;
         i32x8 fa8[4], fb8[4];
@@ -815,7 +832,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       auto load_set = [&](int s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (AK) fa[s][i] = read_frag<true, true>(la, wm * 4 + i, s, lane);
+          if (AK) {
+            fa[s][i] = read_frag<true, true>(la, wm * 4 + i, s, lane);
+            if (ARELU) fa[s][i] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(f16x8, fa[s][i]), f16x8{0, 0, 0, 0, 0, 0, 0, 0}));
+          }
           else tr_issue_frag(la, wm * 4 + i, s, lane, alo[s][i], ahi[s][i]);
         }
 #pragma unroll
@@ -870,6 +890,40 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         if (m < M) atomicAdd(p.colsum + m, cs[i][0]);
       }
     }
+    if constexpr ((F & EF_ARGMAX) != 0) {
+      // (maximum, column) of every row over this wave's 64 columns; ties keep the smaller column (torch.argmax's answer)
+      float bzm[2][8];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int n = n0 + wn * 64 + jb * 32 + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bzm[jb][e] = (p.bias && n + 8 <= N) ? p.bias[n + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int n = n0 + wn * 64 + jb * 32 + g * 8 + e;
+            const float v = acc[i][2 * jb + (e >> 2)][e & 3] + bzm[jb][e];
+            if (n < N && v > best) { best = v; bi = n; }
+          }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const float ov = __shfl_xor(best, off, 64);
+          const int oi = __shfl_xor(bi, off, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (g == 0 && m < M) {
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + 2 * ((n0 + wn * 64) >> 6);
+          *reinterpret_cast<float2*>(c) = make_float2(best, __int_as_float(bi));
+        }
+      }
+    } else {
     // epilogue in three passes: row bookkeeping, ALL loads of the tile (bias, saved activation, residual), then math + stores
     bool rvalid[4]; long rdst[4]; float rrs[4];
 #pragma clang loop unroll(full)
@@ -922,10 +976,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         if (rvalid[i] && n < N) epi_store8<F, F16>(p, ec, v, m, rdst[i], n, rrs[i], N - n, bz[jb], auxv[i][jb], resv[i][jb]);
       }
     }
+    }
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { voA[i] = nvoA[i]; voB[i] = nvoB[i]; pyA[i] = npyA[i]; pxA[i] = npxA[i]; }
+    for (int i = 0; i < NA; ++i) { voA[i] = nvoA[i]; pyA[i] = npyA[i]; pxA[i] = npxA[i]; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) voB[i] = nvoB[i];
   }
 }
 
@@ -972,18 +1029,23 @@ static int epi_need(const vmvm_gemm_desc& d) {
 // pre-activation; fc2 dgrad = GELU' x saved; proj / fc2 = bias + dropout + residual (+ window un-gather); wgrad = f32 split-K)
 // and fall back to the all-features build for anything else.
 // fp16 / implicit-convolution builds (frozen dVAE tokenizer): one epilogue mask covers its four GEMM forms
+// (3x3: bias + ReLU;  1x1: bias, post_gain column scale, residual, bf16 / f32 output;  last 1x1: bias + fused arg-max)
 constexpr int EF_TEACHER = EF_BIAS | EF_COLSCALE | EF_ACT24 | EF_RESID | EF_F32;
-template <bool CONV>
+constexpr int EF_TEACHER_CONV = EF_BIAS | EF_ACT24;
+constexpr int EF_TEACHER_ARGMAX = EF_BIAS | EF_ARGMAX;
+template <bool CONV, int F, int TM, bool ARELU>
 int launch_pers_teacher(const vmvm_gemm_desc& d, hipStream_t st) {
-  const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  constexpr int BM_ = TM == 2 ? 256 : 128, BN_ = TM == 2 ? 64 : 128;
+  constexpr int SMEM_ = 2 * (BM_ + BN_) * BK * 2;
+  const int items = ((d.M + BM_ - 1) / BM_) * ((d.N + BN_ - 1) / BN_);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, EF_TEACHER, true, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, F, true, CONV, false, TM, ARELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_);
     attr_done = true;
   }
   int grid = 512;
   if (items < grid) grid = ((items + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_pers_kernel<true, true, EF_TEACHER, true, CONV>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  hipLaunchKernelGGL((gemm_pers_kernel<true, true, F, true, CONV, false, TM, ARELU>), dim3(grid), dim3(256), SMEM_, st, d);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -1028,6 +1090,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
   if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
+  if (d->a_relu && !d->in_fp16) return VMVM_ENOSUPPORT;
   if (d->in_fp8) {
     // fp8 (OCP e4m3) operands: k-major both, whole 128-element K tiles, epilogue features within EF_FP8
     if (!d->a_kmajor || !d->b_kmajor || d->in_fp16 || d->conv_taps) return VMVM_ENOSUPPORT;
@@ -1046,7 +1109,9 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     const int taps = d->conv_taps;
     if (!d->in_fp16 || !d->a_kmajor || !d->b_kmajor || (taps != 0 && taps != 9)) return VMVM_ENOSUPPORT;
     if ((d->K % BK) || (d->N & 7) || d->row_scale || d->dropout_p > 0.f || d->row_map || d->C2 || d->accumulate || d->colsum ||
-        (d->act != 0 && d->act != 2) || d->splitk > 1) return VMVM_ENOSUPPORT;
+        (d->act != 0 && d->act != 2 && d->act != 5) || d->splitk > 1) return VMVM_ENOSUPPORT;
+    if (d->act == 5 && (taps || !d->out_fp32 || (d->N & 63) || d->ldc < 2 * (d->N >> 6) || d->resid || d->col_scale_n)) return VMVM_EINVAL;
+    if (taps && (d->resid || d->col_scale_n || d->out_fp32)) return VMVM_ENOSUPPORT;
     const int Cin = taps ? d->K / taps : d->K;
     if (taps && ((d->K % taps) || (Cin % BK) || d->conv_h <= 0 || d->conv_w <= 0 || (d->M % (d->conv_h * d->conv_w)))) return VMVM_EINVAL;
     if (d->lda < Cin || d->ldb < d->K) return VMVM_EINVAL;
@@ -1055,7 +1120,13 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     vmvm_gemm_desc dt = *d;
     dt.splitk = 1;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
-    return taps ? launch_pers_teacher<true>(dt, st_) : launch_pers_teacher<false>(dt, st_);
+    const bool ar = dt.a_relu != 0;
+    if (taps) {
+      if (dt.N <= 64) return ar ? launch_pers_teacher<true, EF_TEACHER_CONV, 2, true>(dt, st_) : launch_pers_teacher<true, EF_TEACHER_CONV, 2, false>(dt, st_);
+      return ar ? launch_pers_teacher<true, EF_TEACHER_CONV, 1, true>(dt, st_) : launch_pers_teacher<true, EF_TEACHER_CONV, 1, false>(dt, st_);
+    }
+    if (dt.act == 5) return ar ? launch_pers_teacher<false, EF_TEACHER_ARGMAX, 1, true>(dt, st_) : launch_pers_teacher<false, EF_TEACHER_ARGMAX, 1, false>(dt, st_);
+    return ar ? launch_pers_teacher<false, EF_TEACHER, 1, true>(dt, st_) : launch_pers_teacher<false, EF_TEACHER, 1, false>(dt, st_);
   }
   // 16-byte chunks may straddle the logical extent as long as the row stride covers the round-up
   const int K8 = (d->K + 7) & ~7, M8 = (d->M + 7) & ~7, N8 = (d->N + 7) & ~7;

@@ -97,7 +97,8 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
 // instruction cache every tile cost 10-25% on the short-K shapes of this model.)  EF_ALL = everything, any descriptor.
 enum : int { EF_BIAS = 1, EF_COLSCALE = 2, EF_ACT1 = 4, EF_ACT24 = 8, EF_ACT3 = 16, EF_RS = 32, EF_DROP = 64, EF_RESID = 128,
              EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095,
-             EF_COLSUM = 4096 /* fused column sum of the m-major A operand (not part of EF_ALL: only the wgrad build carries it) */ };
+             EF_COLSUM = 4096 /* fused column sum of the m-major A operand (not part of EF_ALL: only the wgrad build carries it) */,
+             EF_ARGMAX = 8192 /* act 5: (row maximum, column) pairs per 64-column group instead of the outputs (dVAE tokenizer's last conv) */ };
 template <int F, bool F16 = false>
 __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid,
                                            const float (&bz)[8], const uint4& auxv, const uint4& resv) {

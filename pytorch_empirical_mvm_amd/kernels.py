@@ -27,7 +27,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0):
+         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0, a_relu=False):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -64,6 +64,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.in_fp16 = int(fp16)
     d.conv_taps, d.conv_h, d.conv_w = conv if conv is not None else (0, 0, 0)
     d.in_fp8, d.alpha = int(fp8), float(alpha)
+    d.a_relu = int(a_relu)
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
 
@@ -73,6 +74,30 @@ def cast_fp8(x, scale=1.0, out=None):
     y = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
     L.check(L.load().vmvm_cast_bf16_to_fp8(x.data_ptr(), y.data_ptr(), x.numel(), float(scale), L.stream()), "cast_fp8")
     return y
+
+
+def dvae_stem_im2col(img):
+    """img (n,3,H,W) f32 ImageNet-normalised -> fp16 [n*H*W, 192] rows of the pre-processed 7x7 stem (include/vmvm.h)"""
+    n, _, H, W = img.shape
+    cols = torch.empty((n * H * W, 192), device=img.device, dtype=torch.float16)
+    L.check(L.load().vmvm_dvae_stem_im2col(img.data_ptr(), cols.data_ptr(), n, H, W, L.stream()), "dvae_stem_im2col")
+    return cols
+
+
+def maxpool2x2_nhwc(x, n, H, W):
+    """x fp16 [n*H*W, C] (NHWC rows) -> [n*(H/2)*(W/2), C]"""
+    Cc = x.shape[1]
+    y = torch.empty((n * (H // 2) * (W // 2), Cc), device=x.device, dtype=x.dtype)
+    L.check(L.load().vmvm_maxpool2x2_nhwc_f16(x.data_ptr(), y.data_ptr(), n, H, W, Cc, L.stream()), "maxpool2x2_nhwc")
+    return y
+
+
+def argmax_pairs(pairs, groups):
+    """pairs f32 [M, ld] (max, column-bits) per 64-column group (gemm act=5) -> int64 [M]"""
+    M = pairs.shape[0]
+    out = torch.empty(M, device=pairs.device, dtype=torch.int64)
+    L.check(L.load().vmvm_argmax_pairs(pairs.data_ptr(), _ld(pairs), M, groups, out.data_ptr(), L.stream()), "argmax_pairs")
+    return out
 
 
 def colsum(X, out, row_scale=None, rows_per_scale=0, accumulate=True, M=None, N=None):

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
                 ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
                 ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p),
-                ("in_fp8", c_int), ("alpha", c_float)]
+                ("in_fp8", c_int), ("alpha", c_float), ("a_relu", c_int)]
 
 
 class LnFwdDesc(C.Structure):
@@ -99,6 +99,9 @@ _PROTOS = {
     "vmvm_rowdot": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "vmvm_rowdot_bwd": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "vmvm_cast_bf16_to_fp8": ([c_void_p, c_void_p, c_i64, c_float, c_void_p], c_int),
+    "vmvm_dvae_stem_im2col": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_maxpool2x2_nhwc_f16": ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_argmax_pairs": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),

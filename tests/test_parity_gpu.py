@@ -355,12 +355,14 @@ def test_dvae_teacher_native_convs_vs_pytorch_fp32():
     ref = DalleTeacher(256, 8192, device=dev, dtype=torch.float32)
     ref.w = t.w; ref._refresh(); ref.native = False
     x = 0.8 * (img * torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1) + torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)) + 0.1
-    zl = t.logits_native(x).view(4, 28, 28, 8192)
+    zl = t.logits_native(img).view(4, 28, 28, 8192)            # (pre-processing fused into the stem's im2col kernel)
     zr = ref.logits(x).permute(0, 2, 3, 1)
     assert _cos(zl.float(), zr.float()) >= 0.9995
     assert float((zl - zr).abs().max()) <= 3e-2 * float(zr.abs().max())
     tok, tokr = t.extract_vq_token(img), ref.extract_vq_token(img)
     assert float((tok == tokr).float().mean()) >= 0.99
+    # the fused arg-max epilogue (no logits in memory) against the arg-max of the native logits: same arithmetic, same tie rule
+    assert torch.equal(tok.reshape(-1), torch.argmax(zl.reshape(-1, 8192), dim=1))
 
 
 def test_device_masking_matches_oracle_on_the_same_draws():

@@ -178,7 +178,7 @@ def test_dvae_native_tokenizer_vs_oracle_encoder():
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     with torch.no_grad():
         zr = R.dvae_encoder(sd, dict(dvae_hid=256, dvae_vocab=8192), x).permute(0, 2, 3, 1)          # (N,28,28,V)
-    zl = t.logits_native(x.cuda()).view(2, 28, 28, 8192).float().cpu()
+    zl = t.logits_native(img.cuda()).view(2, 28, 28, 8192).float().cpu()      # native path: pre-processing fused into the stem kernel
     assert _cos(zl, zr) >= 0.9995, _cos(zl, zr)
     assert float((zl - zr).abs().max()) <= 3e-2 * float(zr.abs().max())
     tok = t.extract_vq_token(img.cuda()).cpu()

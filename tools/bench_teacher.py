@@ -6,7 +6,8 @@ from pytorch_empirical_mvm_amd.dvae import DalleTeacher
 dev = "cuda"
 img = torch.randn(256, 3, 224, 224, device=dev)
 def _torch_path(t): t.native = False
-for name, setup in (("native implicit-GEMM", lambda t: None), ("torch conv2d NHWC", _torch_path)):
+ONLY = os.environ.get("TEACHER_NATIVE_ONLY") == "1"
+for name, setup in ((("native implicit-GEMM", lambda t: None),) if ONLY else (("native implicit-GEMM", lambda t: None), ("torch conv2d NHWC", _torch_path))):
     t = DalleTeacher(256, 8192, device=dev)
     setup(t)
     for _ in range(2): t.extract_vq_token(img)
@@ -15,6 +16,8 @@ for name, setup in (("native implicit-GEMM", lambda t: None), ("torch conv2d NHW
     torch.cuda.synchronize(); dt = (time.time() - t0) / 3
     print(f"{name:26s}: {dt * 1e3:.1f} ms  {256 * 208.5e9 / dt / 1e12:.0f} TFLOP/s")
 
+if ONLY:
+    sys.exit(0)
 # agreement of the native fp16 path with the PyTorch fp32 path on 8 frames (same weights)
 t = DalleTeacher(256, 8192, device=dev)
 tok_n = t.extract_vq_token(img[:8])
