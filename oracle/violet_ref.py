@@ -137,12 +137,18 @@ def param_shapes(cfg):
         s["fc.3.weight"] = (int(cfg["size_vocab"]), 2 * H)
         s["fc.3.bias"] = (int(cfg["size_vocab"]),)
         return s
+    if cfg.get("task", "pretrain") == "qamc_mlm":        # VIOLET_QAMC_MLM_Head main_qamc_tsv_mlm_head.py:61-71: `del self.fc`, + fc_mtm + emb_task
+        for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
+            del s[k]
+        s["emb_task"] = (10, H)
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
     s["fc_mtm.predictions.transform.dense.bias"] = (H,)
     s["fc_mtm.predictions.transform.LayerNorm.weight"] = (H,)
     s["fc_mtm.predictions.transform.LayerNorm.bias"] = (H,)
     s["fc_mtm.predictions.decoder.weight"] = (V, H)
+    if cfg.get("task", "pretrain") == "qamc_mlm":
+        return s
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)
@@ -873,6 +879,37 @@ def qaoe_forward(sd, cfg, img, txt, mask):
     out = go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask)
     x = F.relu(F.linear(out[:, (1 + h * w) * T, :], sd["fc.1.weight"], sd["fc.1.bias"]))
     return F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"])
+
+
+def qamc_mlm_forward(sd, cfg, img, txt, mask):
+    """VIOLET_QAMC_MLM_Head.forward main_qamc_tsv_mlm_head.py:76-94 (eval mode, no task token / prompt: `prepro_txt_inputs` is the
+    identity then, model.py:252-258): txt / mask (B, O, X) = one tokenised "question + option + [MASK]" per option; the video
+    tokens are shared by a clip's O sequences; MLM-head logits (B*O, X, vocab) of the text positions."""
+    B, T, _, H, W = img.shape
+    O, X = txt.shape[1], txt.shape[2]
+    h, w = H // 32, W // 32
+    feat_img, mask_img = enc_video(sd, cfg, img)
+    feat_txt = enc_txt(sd, txt.reshape(B * O, X))
+    ii = [i for i in range(B) for _ in range(O)]
+    out = go_cross(sd, cfg, feat_img[ii], mask_img[ii], feat_txt, mask.reshape(B * O, X))
+    return mlm_head(sd, out[:, (1 + h * w) * T:])
+
+
+def qamc_mlm_loss(logits, mask_ans):
+    """Agent_QAMC_MLM_Head.step, train branch (:104-109): CrossEntropyLoss(ignore_index=-1) over every text position"""
+    return cross_entropy_ignore(logits.reshape(-1, logits.shape[-1]), mask_ans.reshape(-1))
+
+
+def qamc_mlm_predict(logits, mask_ans, true_id, false_id):
+    """eval branch (:111-123): at each option's [MASK] position p_true / (p_true + p_false) of the RAW logits, arg-max over the options;
+    returns (predicted option (B,), answer option (B,))"""
+    B, O, L = mask_ans.shape
+    pt, pf = logits[:, :, true_id], logits[:, :, false_id]
+    sc = pt / (pt + pf)
+    m = mask_ans.reshape(B * O, L)
+    sc = sc[m != -1].view(B, O)
+    am = m[m != -1].view(B, O)
+    return torch.argmax(sc, dim=-1), (am == true_id).nonzero()[:, 1]
 
 
 def norm_softmax_loss(x, temperature):

@@ -155,12 +155,18 @@ def param_shapes(cfg):
         s["fc.3.weight"] = (int(cfg["size_vocab"]), 2 * H)
         s["fc.3.bias"] = (int(cfg["size_vocab"]),)
         return s
+    if cfg.get("task", "pretrain") == "qamc_mlm":        # VIOLET_QAMC_MLM_Head (main_qamc_tsv_mlm_head.py:61-71): no fc; fc_mtm + emb_task
+        for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
+            del s[k]
+        s["emb_task"] = (10, H)
     s["fc_mtm.predictions.bias"] = (V,)
     s["fc_mtm.predictions.transform.dense.weight"] = (H, H)
     s["fc_mtm.predictions.transform.dense.bias"] = (H,)
     s["fc_mtm.predictions.transform.LayerNorm.weight"] = (H,)
     s["fc_mtm.predictions.transform.LayerNorm.bias"] = (H,)
     s["fc_mtm.predictions.decoder.weight"] = (V, H)
+    if cfg.get("task", "pretrain") == "qamc_mlm":
+        return s
     if "pixel" in cfg["mvm_target"]:
         s["decoder_pixel.0.weight"] = (cfg["size_patch"] ** 2 * 3, H, 1, 1)
         s["decoder_pixel.0.bias"] = (cfg["size_patch"] ** 2 * 3,)

@@ -3,6 +3,9 @@
   batch's B x B (video, text) pairs are B*B gathered sequences of one fusion pass.
 * Open-ended video QA: `VIOLET_QAOE` / `Agent_QAOE` (main_qaoe.py:42-90) -- one (video, question) pass, classification over the
   answer vocabulary on the text [CLS] state.
+* Multiple-choice video QA, MLM-head form: `VIOLET_QAMC_MLM_Head` / `Agent_QAMC_MLM_Head` (main_qamc_tsv_mlm_head.py:61-123) -- one
+  "question + option + [MASK]" sequence per option, the clip's video tokens shared by its options, the pre-training MLM head
+  predicts the true / false token at [MASK].
 Same encoders, token pool and fusion kernels as pre-training; checkpoints interchange through the shared key names."""
 import torch
 
@@ -80,3 +83,61 @@ class Agent_QAOE(Agent_Pretrain):
             return float(loss.item())
         _, logits = eng.qaoe_forward_backward(img, txt, mask, ans, train=False, backward=False)
         return (logits.argmax(1) == ans.to(dev)).float().tolist()
+
+
+class VIOLET_QAMC_MLM_Head(VIOLET_Pretrain):
+    """VIOLET_Base + the pre-training MLM head `fc_mtm` (+ `emb_task`, unused while the task token is off); no `fc`
+    (main_qamc_tsv_mlm_head.py:61-71).  A pre-training checkpoint loads through `load_ckpt` (shared key names)."""
+
+    def __init__(self, args, tokzr=None, device="cuda"):
+        args = CFG.Args(dict(args))
+        args.update(task="qamc_mlm", mvm_target=[])
+        if args.get("enable_task_token") or args.get("enable_prompt"):
+            raise NotImplementedError("task token / prompt prefixes (model.py:219-293) are outside the accelerated path")
+        super().__init__(args, tokzr, device=device)
+
+    @torch.no_grad()
+    def forward(self, batch):
+        """batch: img (B,T,3,H,W), txt / mask / mask_ans (B,O,X) -> (out (B*O, X, vocab) f32, ans (B,O,X))   (:76-94)"""
+        dev = self.engine.device
+        txt = batch["txt"]
+        B, O, X = txt.shape
+        _, lg = self.engine.qamc_mlm_forward_backward(batch["img"].to(dev, torch.float32).contiguous(), txt.to(dev), batch["mask"].to(dev),
+                                                      batch["mask_ans"].to(dev), train=self.training, backward=False)
+        return lg.view(B * O, X, -1), batch["mask_ans"].to(dev)
+
+
+class Agent_QAMC_MLM_Head(Agent_Pretrain):
+    """Agent_QAMC_MLM_Head.step (main_qamc_tsv_mlm_head.py:100-123): train -> cross entropy over the text positions (ignore -1) + the
+    shared backward_step; eval -> per-clip accuracy of arg-max over the options of p_true / (p_true + p_false) at [MASK]."""
+
+    def __init__(self, args, model, true_token_id=2995, false_token_id=6270):       # bert-base-uncased ids of "true" / "false"
+        super().__init__(args, model)
+        self.true_token_id, self.false_token_id = int(true_token_id), int(false_token_id)
+
+    def current_lrs(self):
+        """Agent_QAMC.build_optimizer (main_qamc.py:111-140): the `vis_backbone_lr_mul` group is the parameters whose name starts with
+        `fc.` -- none in the MLM-head model -- so every group runs at the base rate."""
+        lr = max(1e-8, self.args.lr * CFG.lr_factor(self.sched_step, self.args.max_iter))
+        return [lr, lr, lr, lr]
+
+    def step(self, batch, is_train=True):
+        eng = self.engine
+        dev = eng.device
+        img = batch["img"].to(dev, torch.float32).contiguous()
+        txt, mask, ans = batch["txt"].to(dev), batch["mask"].to(dev), batch["mask_ans"].to(dev)
+        if is_train:
+            loss, _ = eng.qamc_mlm_forward_backward(img, txt, mask, ans, train=True, backward=True)
+            if self.comm is not None:
+                self.comm.reduce_other()
+            self.backward_step()
+            self.global_step += 1
+            return float(loss.item())
+        B, O, X = txt.shape
+        _, lg = eng.qamc_mlm_forward_backward(img, txt, mask, ans, train=False, backward=False)
+        lg = lg.view(B * O, X, -1)
+        pt, pf = lg[:, :, self.true_token_id], lg[:, :, self.false_token_id]
+        sc = pt / (pt + pf)
+        m = ans.reshape(B * O, X)
+        sc, am = sc[m != -1].view(B, O), m[m != -1].view(B, O)
+        return (sc.argmax(-1) == (am == self.true_token_id).nonzero()[:, 1]).float().tolist()

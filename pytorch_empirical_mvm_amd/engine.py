@@ -27,7 +27,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 class ParamStore:
     """All parameters in ONE flat f32 buffer (+ grad, Adam m/v, bf16 compute copy), laid out by optimizer
     group (agent.py:84-113) so clip / AdamW / all-reduce are a handful of launches over contiguous memory."""
-    FROZEN = ("enc_img.emb_odr",)          # never receives a gradient in pretraining (SURVEY section 9)
+    FROZEN = ("enc_img.emb_odr", "emb_task")   # never receive a gradient on the built paths (SURVEY section 9; emb_task: task token off)
     PAD = 16                 # elements: bf16 views 32-byte, fp8 views 16-byte aligned (DMA chunks)
     TAIL = 1 << 16
 
@@ -393,7 +393,8 @@ class VioletEngine:
 
     # -------------------------------------------------------------- EncVideo / EncTxt  -> one token pool
     def encode(self, img, cov, txt, dp_all, train):
-        """returns pool V([B*Lv + B*X, 768]) : rows [0, B*Lv) = feat_img (model.py:71), rest = feat_txt (model.py:107)."""
+        """returns pool V([B*Lv + NT*X, 768]) : rows [0, B*Lv) = feat_img (model.py:71), rest = feat_txt (model.py:107) of the NT =
+        txt.shape[0] text sequences (NT = B in pre-training; B*O option sequences in multiple-choice QA)."""
         cfg, S, dev = self.cfg, self.store, self.device
         B, T, _, H, W = img.shape
         X = txt.shape[1]
@@ -409,7 +410,7 @@ class VioletEngine:
         if T > cfg["max_size_frame"]:
             raise RuntimeError(f"max_size_frame ({cfg['max_size_frame']}) must be >= T ({T})  (model.py:69)")
         pre = K.encvideo_assemble(f, S.p("enc_img.emb_cls", (Hd,)), pos, ln_, B, T, hw, Hd)
-        pool = torch.empty((B * Lv + B * X, Hd), device=dev, dtype=BF16)
+        pool = torch.empty((B * Lv + txt.shape[0] * X, Hd), device=dev, dtype=BF16)
         gi, bi = S.p("enc_img.norm.weight"), S.p("enc_img.norm.bias")
         fi, mean_i, rstd_i = K.layernorm_fwd(pre, gi, bi, 1e-5)
         pool[:B * Lv].copy_(fi)
@@ -890,6 +891,63 @@ class VioletEngine:
         while self.tape:
             self.tape.pop()()
         return loss, logits[:, :NV]
+
+    # -------------------------------------------------------------- downstream: multiple-choice video QA, MLM-head form
+    def qamc_mlm_forward_backward(self, img, txt, mask, mask_ans, train=True, backward=True, dp_all=None):
+        """VIOLET_QAMC_MLM_Head.forward + Agent_QAMC_MLM_Head.step (main_qamc_tsv_mlm_head.py:76-109): txt / mask / mask_ans are
+        (B, O, X) -- one "question + option_o + [MASK]" sequence per option, labelled true / false token id at the [MASK] position
+        and -1 elsewhere.  The clip's video tokens are shared by its O sequences (B*O sequences gathered from one token pool, as the
+        retrieval head's pairs), the shared MLM head (`fc_mtm`) reads every text position, cross entropy with ignore_index -1.
+        Returns (loss f32[1], logits (B*O*X, vocab) f32 view).  Task token / prompt (`enable_task_token`, `enable_prompt`) are off."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        B, T, _, H, W = img.shape
+        O, X = int(txt.shape[1]), int(txt.shape[2])
+        Hd, Vv = cfg["hidden"], cfg["vocab"]
+        self.tape = []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(B)
+        txt2, mask2 = txt.reshape(B * O, X).contiguous(), mask.reshape(B * O, X).contiguous()
+        pool, Lv, hw = self.encode(img, None, txt2, dp_all, train)            # pool rows: B*Lv visual, then (B*O)*X text
+        Lq = Lv + X
+        n_seq = B * O
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx_d = self._cached(("qamc_idx", B, O, Lv, X), lambda: _dev_i32(
+            np.concatenate([np.concatenate([(s_ // O) * Lv + ar_v, B * Lv + s_ * X + ar_t]) for s_ in range(n_seq)]), dev))
+        km = torch.cat([torch.ones(n_seq, Lv, dtype=torch.uint8, device=dev), (mask2 != 0).to(torch.uint8)], 1).contiguous()
+        out, inn, _ = self.go_cross(pool, idx_d, km, n_seq, Lq, train)
+        pm = "fc_mtm.predictions."
+        Vpad, Nlog = -(-Vv // 8) * 8, -(-Vv // 4) * 4
+        txt_rows = self._cached(("qamc_txt_rows", n_seq, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(n_seq)]), dev))
+        gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
+        Wdec = S.b(pm + "decoder.weight")
+        nr = n_seq * X
+        r_ = K.gather_rows(out.t, txt_rows, nr)
+        u_ = torch.empty((nr, Hd), device=dev, dtype=BF16)
+        t_ = K.gemm(r_, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
+        tn_, mean_, rstd_ = K.layernorm_fwd(t_, gm, bm, CFG.BERT["eps"])
+        lg_ = torch.empty((nr, Vpad), device=dev, dtype=F32)
+        K.gemm(tn_, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=lg_)
+        loss = torch.zeros(1, device=dev, dtype=F32)
+        dlog = K.cross_entropy(lg_, Vv, mask_ans.to(dev).reshape(-1).contiguous(), loss, want_grad=backward, ld_d=Vpad)
+        if not backward:
+            self.tape = []
+            return loss, lg_[:, :Vv]
+        K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=nr, N=Vpad)
+        K.gemm(dlog, tn_, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=nr, out=S.g(pm + "decoder.weight"), accumulate=True)
+        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=nr, N=Hd, K=Vv)
+        dt_, _ = K.layernorm_bwd(dtn, t_, gm, mean_, rstd_, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
+        du_ = K.gelu_bwd(dt_, u_)
+        dtxt = self._linear_bwd(du_, r_, pm + "transform.dense.weight", pm + "transform.dense.bias")
+        inv = self._cached(("qamc_inv", n_seq, Lq, Lv, X), lambda: self._inverse_rows(n_seq * Lq, [txt_rows]))
+        out.g = K.gather_rows(dtxt, inv, n_seq * Lq)
+        for _ in range(cfg["bert_layers"]):
+            self.tape.pop()()
+        dpool = torch.zeros((B * Lv + n_seq * X, Hd), device=dev, dtype=F32)
+        K.scatter_add_rows(inn.g, idx_d, dpool)
+        pool.g = K.cast_bf16(dpool)
+        while self.tape:
+            self.tape.pop()()
+        return loss, lg_[:, :Vv]
 
     def _inverse_rows(self, n_rows, row_lists):
         inv = np.full(n_rows, -1, dtype=np.int32)

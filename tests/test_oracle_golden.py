@@ -308,3 +308,29 @@ def test_qaoe_forward_and_loss():
     np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
     for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-6)
+
+
+def test_qamc_mlm_head_forward_loss_and_eval():
+    """VIOLET_QAMC_MLM_Head.forward + the train / eval arithmetic of Agent_QAMC_MLM_Head.step against the reference's own
+    classes (qamc.npz): MLM-head logits of the B*O option sequences, CE(ignore_index=-1), option scores p_true / (p_true + p_false)."""
+    d = load("qamc.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"] = "qamc_mlm"
+    sd = R.make_state_dict(cfg)
+    assert "emb_task" in sd and "fc.1.weight" not in sd
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    B, O = 2, 3
+    img, _, _ = R.make_batch(cfg, B)
+    txt, mask, mask_ans = torch.from_numpy(d["txt"]), torch.from_numpy(d["mask"]), torch.from_numpy(d["mask_ans"])
+    out = R.qamc_mlm_forward(params, cfg, img, txt, mask)
+    check_samp(d, "out", out, rtol=2e-4, atol=2e-5)
+    ls = R.qamc_mlm_loss(out, mask_ans)
+    np.testing.assert_allclose(float(ls.detach()), float(d["loss"]), rtol=1e-5)
+    pred, ans = R.qamc_mlm_predict(out.detach(), mask_ans, 2995, 6270)
+    assert pred.tolist() == d["pred"].tolist() and ans.tolist() == d["ans_idx"].tolist()
+    ls.backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None)
+    np.testing.assert_allclose(gsq ** 0.5, float(d["grad_norm"]), rtol=1e-3)
+    assert sorted(k for k, p in params.items() if p.grad is None) == sorted(d["no_grad"].tolist())
+    for k in ("fc_mtm.predictions.transform.dense.weight", "fc_mtm.predictions.decoder.weight", "fc_mtm.predictions.bias"):
+        check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-6)

@@ -682,6 +682,60 @@ def test_qaoe_logits_loss_grads_and_step():
     assert len(acc) == 3 and all(a in (0.0, 1.0) for a in acc)
 
 
+def test_qamc_mlm_head_logits_loss_grads_and_step():
+    """multiple-choice video QA, MLM-head form, on the HIP path (VIOLET_QAMC_MLM_Head / Agent_QAMC_MLM_Head) against the
+    fixture from the reference's classes (qamc.npz): logits of the B*O option sequences, CE(ignore_index=-1), MLM-head gradients,
+    global gradient norm, the eval arithmetic; then a train step (optimizer groups: no backbone multiplier, as Agent_QAMC)."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd.downstream import Agent_QAMC_MLM_Head, VIOLET_QAMC_MLM_Head
+    d = np.load(os.path.join(G, "qamc.npz"))
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"] = "qamc_mlm"
+    args = CFG.get_args(vis_backbone_size="tiny", size_frame=4, max_size_frame=6)
+    model = VIOLET_QAMC_MLM_Head(args, None, device="cuda")
+    missing, unexpected = model.load_state_dict(R.make_state_dict(cfg))
+    missing = [k for k in missing if "relative_position_index" not in k]      # (buffers the oracle's state dict does not carry)
+    assert not unexpected and not missing, (missing[:5], unexpected[:5])
+    img, _, _ = R.make_batch(cfg, 2)
+    txt, mask, mask_ans = torch.from_numpy(d["txt"]), torch.from_numpy(d["mask"]), torch.from_numpy(d["mask_ans"])
+    eng = model.engine
+    eng.store.grad.zero_()
+    loss, logits = eng.qamc_mlm_forward_backward(img.cuda(), txt.cuda(), mask.cuda(), mask_ans.cuda(), train=False, backward=True)
+    torch.cuda.synchronize()
+    _check_samples(d, "out", logits.reshape(6, txt.shape[2], -1), tol=5e-2)
+    assert abs(float(loss.item()) - float(d["loss"])) <= 2e-2 * float(d["loss"]), (float(loss.item()), float(d["loss"]))
+    gn = float(eng.store.grad[:eng.store.n_trainable].double().pow(2).sum().sqrt().item())
+    assert abs(gn - float(d["grad_norm"])) <= 5e-2 * float(d["grad_norm"]), (gn, float(d["grad_norm"]))
+    for k in ("fc_mtm.predictions.transform.dense.weight", "fc_mtm.predictions.decoder.weight", "fc_mtm.predictions.bias"):
+        _check_samples(d, "g." + k, eng.store.g(k).reshape(tuple(d[f"g.{k}.shape"])), tol=5e-2)
+    batch = dict(img=img, txt=txt, mask=mask, mask_ans=mask_ans)
+    agent = Agent_QAMC_MLM_Head(args, model)
+    model.eval()
+    out, ans = model(batch)
+    pred, want = R.qamc_mlm_predict(out.float().cpu(), mask_ans, 2995, 6270)
+    # the reference's option score p_true / (p_true + p_false) divides RAW logits (:113-115) and is ill-conditioned wherever they nearly
+    # cancel, so the two logits themselves are compared with the oracle's at the [MASK] positions, and the fixture's scores only where
+    # the denominator is not small
+    with torch.no_grad():
+        o_ref = R.qamc_mlm_forward(R.make_state_dict(cfg), cfg, img, txt, mask)
+    sel = mask_ans.view(6, -1) != -1
+    o = out.float().cpu()
+    for tid in (2995, 6270):
+        a, b_ = o[:, :, tid][sel], o_ref[:, :, tid][sel]
+        assert float((a - b_).abs().max()) <= 5e-2 * float(o_ref.abs().max()), (tid, a, b_)
+    den_ref = (o_ref[:, :, 2995] + o_ref[:, :, 6270])[sel].view(2, 3).abs().numpy()
+    sc = (o[:, :, 2995] / (o[:, :, 2995] + o[:, :, 6270]))[sel].view(2, 3).numpy()
+    ok = den_ref > 0.25 * float(o_ref.abs().max())
+    assert np.abs(sc - d["scores"])[ok].max(initial=0.0) <= 0.1, (sc, d["scores"], den_ref)
+    acc = agent.step(batch, is_train=False)
+    assert acc == (pred == want).float().tolist()
+    assert agent.current_lrs()[0] == agent.current_lrs()[1]           # Agent_QAMC.build_optimizer: the multiplier group is `fc.*`, absent here
+    model.train()
+    v = agent.step(batch, is_train=True)
+    assert np.isfinite(v) and v > 0
+
+
 def test_fp8_forward_gemms_stay_close_to_the_oracle():
     """BASELINE config 5's fp8 path (opt-in `fp8_forward`): the fusion encoder's qkv / FFN-in forward GEMMs on e4m3 operands with
     per-tensor static scales.  fp8 has 3 mantissa bits, so this is a closeness check (losses within 5 %, outputs cosine >= 0.995

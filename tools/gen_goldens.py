@@ -736,12 +736,81 @@ def gold_optimizer():
     print("optimizer ok")
 
 
+def qamc_batch(cfg, B, O):
+    """deterministic (B, O, X) multiple-choice batch: the text / mask rows of make_batch(B*O) with one [MASK] (id 103) per sequence,
+    labelled `true` (2995) for the answer option and `false` (6270) for the others (main_qamc_tsv_mlm_head.py:26-37)"""
+    img, _, _ = R.make_batch(cfg, B)
+    _, txt, mask = R.make_batch(cfg, B * O)
+    X = txt.shape[1]
+    txt, mask = txt.clone().view(B, O, X), mask.clone().view(B, O, X)
+    mask_ans = torch.full((B, O, X), -1, dtype=torch.long)
+    ans_idx = torch.tensor([(2 * i + 1) % O for i in range(B)])
+    for i in range(B):
+        for o in range(O):
+            n = int(mask[i, o].sum())
+            pos = max(1, n - 2)                                   # the appended [MASK] sits before [SEP]
+            txt[i, o, pos] = 103
+            mask_ans[i, o, pos] = 2995 if o == int(ans_idx[i]) else 6270
+    return img, txt, mask, mask_ans, ans_idx
+
+
+def gold_qamc(size="tiny", T=4, B=2, O=3):
+    """VIOLET_QAMC_MLM_Head.forward + Agent_QAMC_MLM_Head.step's loss / eval arithmetic through the reference's classes
+    (main_qamc_tsv_mlm_head.py:61-123)."""
+    import main_qamc_tsv_mlm_head as mq
+    cfg = R.make_cfg(size, T=T)
+    cfg["task"] = "qamc_mlm"
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    args.update(num_video_tokens=-1, size_option=O)
+    model = mq.VIOLET_QAMC_MLM_Head(args, None).eval()
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": ()}
+    model.trsfr.forward = trsfr_forward
+    own = model.state_dict()
+    miss = [k for k in sd if k not in own]
+    assert not miss, miss[:8]
+    extra = [k for k in own if k not in sd and "position_ids" not in k and "decoder.bias" not in k and "relative_position_index" not in k]
+    assert not extra, extra[:8]
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask, mask_ans, ans_idx = qamc_batch(cfg, B, O)
+    out, ans = model(dict(img=img, txt=txt, mask=mask, mask_ans=mask_ans))
+    ls = torch.nn.CrossEntropyLoss(ignore_index=-1)(out.flatten(0, len(out.shape) - 2), ans.flatten())
+    ls.backward()
+    # eval arithmetic of Agent_QAMC_MLM_Head.step (:111-123)
+    p_true, p_false = out[:, :, 2995], out[:, :, 6270]
+    sc = (p_true / (p_true + p_false))[ans.view(B * O, -1) != -1].view(B, O)
+    d = dict(loss=np.array(float(ls.detach())), txt=txt.numpy(), mask=mask.numpy(), mask_ans=mask_ans.numpy(), ans_idx=ans_idx.numpy(),
+             scores=sc.detach().numpy().astype(np.float64), pred=torch.argmax(sc, -1).numpy())
+    put(d, "out", out, 512)
+    gsq = 0.0
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        gsq += float((p_.grad.double() ** 2).sum())
+        if k.startswith("fc_mtm.") or k == "enc_txt.emb_txt.LayerNorm.weight":
+            put(d, "g." + k, p_.grad, 32)
+    d["grad_norm"] = np.array(gsq ** 0.5)
+    d["no_grad"] = np.array([k for k, p_ in model.named_parameters() if p_.grad is None])
+    np.savez_compressed(os.path.join(OUT, "qamc.npz"), **d)
+    print("qamc ok loss", float(ls), "gn", gsq ** 0.5, "pred", d["pred"].tolist(), "ans", ans_idx.tolist(), "no_grad", d["no_grad"].tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--qamc-only" in sys.argv:
+        gold_qamc()
+        sys.exit(0)
     if "--qaoe-only" in sys.argv:
         gold_qaoe()
         sys.exit(0)
@@ -777,3 +846,4 @@ if __name__ == "__main__":
     gold_am()
     gold_retrieval()
     gold_qaoe()
+    gold_qamc()
