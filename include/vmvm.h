@@ -286,6 +286,13 @@ int vmvm_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stre
 /* dst_f32[idx[m],:] += src[m,:] (atomics; idx < 0 skipped) -- gradient of a row gather with repeated sources */
 int vmvm_scatter_add_rows_bf16(const void* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst,
                                int32_t M, int32_t C, void* stream);
+/* Gradient of the token pool = backward of the sequence assembly of VIOLET_Pretrain.forward (main_pretrain.py:243-259).  g1: gradient of
+ * the B pass-1 sequences [video i ; text i] (bf16 [B*(Lv+X)][Hd]); g2: of the B*O pass-2 sequences p = i*O + o = [video i ; text tj(p)];
+ * g3: optional third pass laid out as g1 (smtm).  out (bf16 [B*Lv + B*X][Hd]): video row (i, t) = g1 + g3 + sum_o g2[(i*O+o)], text row
+ * (j, x) = g1 + g3 + the pass-2 sequences txt_list[txt_off[j] .. txt_off[j+1]) (CSR over the text index of each pair, int32 on the
+ * device).  f32 sums in registers, no atomics. */
+int vmvm_pool_grad_bf16(const void* g1, const void* g2, const void* g3, void* out, int32_t B, int32_t O, int32_t Lv, int32_t X, int32_t Hd,
+                        const int32_t* txt_off, const int32_t* txt_list, void* stream);
 /* out = dy * GELU'(u)  (backward of the MLM head transform activation) */
 int vmvm_gelu_bwd_bf16(const void* dy, const void* u, void* out, int64_t n, void* stream);
 /* elementwise dropout y = keep(seed, offset+i) ? x/(1-p) : 0  (HF embedding dropout; main_pretrain.py:146 fc[0]).

@@ -333,6 +333,49 @@ __global__ void scatter_add_rows_kernel(const u16* __restrict__ src, int ld_src,
 #pragma unroll
   for (int e = 0; e < 8; ++e) atomicAdd(o + e, v[e]);
 }
+// Gradient of the token pool (backward of the sequence assembly main_pretrain.py:243-259): pass 1 holds sequence i = [video i ; text i],
+// pass 2 holds the B*O sequences p = i*O + o = [video i ; text tj(p)].  A pool row's gradient is the sum of its copies: video rows have
+// the fixed fan-in 1 + O, text row j the sequences of pass 2 listed in txt_list[txt_off[j] .. txt_off[j+1]).  One thread sums 8
+// channels in f32 and writes bf16 -- no f32 scatter buffer, no atomics, no cast pass.
+__global__ void pool_grad_kernel(const u16* __restrict__ g1, const u16* __restrict__ g2, const u16* __restrict__ g3, u16* __restrict__ out,
+                                 int B, int O, int Lv, int X, int Hd, const int32_t* __restrict__ txt_off, const int32_t* __restrict__ txt_list) {
+  const int c8 = Hd >> 3, Lq = Lv + X;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long rows = (long)B * (Lv + X);
+  if (i >= rows * c8) return;
+  const int ch = (int)(i % c8);
+  const long row = i / c8;
+  float acc[8], v[8];
+  if (row < (long)B * Lv) {
+    const int b = (int)(row / Lv), t = (int)(row - (long)b * Lv);
+    unpack_bf8(*reinterpret_cast<const uint4*>(g1 + ((size_t)b * Lq + t) * Hd + ch * 8), acc);
+    if (g3) {
+      unpack_bf8(*reinterpret_cast<const uint4*>(g3 + ((size_t)b * Lq + t) * Hd + ch * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    for (int o = 0; o < O; ++o) {
+      unpack_bf8(*reinterpret_cast<const uint4*>(g2 + (((size_t)b * O + o) * Lq + t) * Hd + ch * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  } else {
+    const long tr = row - (long)B * Lv;
+    const int j = (int)(tr / X), x = (int)(tr - (long)j * X);
+    unpack_bf8(*reinterpret_cast<const uint4*>(g1 + ((size_t)j * Lq + Lv + x) * Hd + ch * 8), acc);
+    if (g3) {
+      unpack_bf8(*reinterpret_cast<const uint4*>(g3 + ((size_t)j * Lq + Lv + x) * Hd + ch * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    for (int e_ = txt_off[j]; e_ < txt_off[j + 1]; ++e_) {
+      unpack_bf8(*reinterpret_cast<const uint4*>(g2 + ((size_t)txt_list[e_] * Lq + Lv + x) * Hd + ch * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+  *reinterpret_cast<uint4*>(out + (size_t)row * Hd + ch * 8) = pack_bf8(acc);
+}
 __global__ void gelu_bwd_kernel(const u16* __restrict__ dy, const u16* __restrict__ u, u16* __restrict__ out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = f2bf(bf2f(dy[i]) * gelu_grad_f(bf2f(u[i])));
@@ -698,6 +741,15 @@ extern "C" int vmvm_scatter_add_rows_bf16(const void* src, int32_t ld_src, const
   if (!src || !idx || !dst || M <= 0 || (C & 7) || (ld_src & 7)) return VMVM_EINVAL;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblk((long)M * (C / 8), 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), ld_src, idx,
                      dst, ld_dst, (long)M, C);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_pool_grad_bf16(const void* g1, const void* g2, const void* g3, void* out, int32_t B, int32_t O, int32_t Lv, int32_t X, int32_t Hd,
+                                   const int32_t* txt_off, const int32_t* txt_list, void* stream) {
+  if (!g1 || !g2 || !out || !txt_off || !txt_list || B <= 0 || O <= 0 || Lv <= 0 || X <= 0 || Hd <= 0 || (Hd & 7)) return VMVM_EINVAL;
+  const long n = (long)B * (Lv + X) * (Hd / 8);
+  hipLaunchKernelGGL(pool_grad_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(g1), reinterpret_cast<const u16*>(g2),
+                     reinterpret_cast<const u16*>(g3), reinterpret_cast<u16*>(out), B, O, Lv, X, Hd, txt_off, txt_list);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

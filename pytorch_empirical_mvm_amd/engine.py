@@ -565,8 +565,14 @@ class VioletEngine:
         idx1_d, idx2_d = _dev_i32(idx1, dev), _dev_i32(idx2, dev)
         km_txt = (mask != 0).to(torch.uint8)
         km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
-        tj = _h2d(torch.tensor([j for _, j in pairs]), dev)
+        tj_h = np.array([j for _, j in pairs], dtype=np.int64)
+        tj = _h2d(torch.from_numpy(tj_h), dev)
         km2 = torch.cat([torch.ones(B * O, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
+        if backward:                            # CSR of the pass-2 sequences by their text index (the pool gradient gathers through it)
+            order = np.argsort(tj_h, kind="stable")
+            csr = np.concatenate([np.concatenate([[0], np.cumsum(np.bincount(tj_h, minlength=B))]), order]).astype(np.int32)
+            csr_d = _dev_i32(csr, dev)
+            txt_off_d, txt_list_d = csr_d[:B + 1], csr_d[B + 1:]
 
         out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
         out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
@@ -767,12 +773,7 @@ class VioletEngine:
         n_layers = cfg["bert_layers"]
         for _ in range((3 if use_smtm else 2) * n_layers):
             self.tape.pop()()
-        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
-        K.scatter_add_rows(in1.g, idx1_d, dpool)
-        K.scatter_add_rows(in2.g, idx2_d, dpool)
-        if use_smtm:
-            K.scatter_add_rows(in3.g, idx1_d, dpool)
-        pool.g = K.cast_bf16(dpool)
+        pool.g = K.pool_grad(in1.g, in2.g, in3.g if use_smtm else None, B, O, Lv, X, txt_off_d, txt_list_d)
         self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
         if on_other_grads_ready is not None:
             on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward

@@ -308,6 +308,15 @@ def gather_rows(src, idx, M, rows_out_per_batch=0, rows_in_per_batch=0):
     return dst
 
 
+def pool_grad(g1, g2, g3, B, O, Lv, X, txt_off, txt_list):
+    """gradient of the token pool from the gradients of the gathered pass-1 / pass-2 (/ smtm) sequences (include/vmvm.h)"""
+    Hd = g1.shape[1]
+    out = torch.empty((B * (Lv + X), Hd), device=g1.device, dtype=BF16)
+    L.check(L.load().vmvm_pool_grad_bf16(g1.data_ptr(), g2.data_ptr(), L.ptr(g3), out.data_ptr(), B, O, Lv, X, Hd, txt_off.data_ptr(),
+                                         txt_list.data_ptr(), L.stream()), "pool_grad")
+    return out
+
+
 def scatter_add_rows(src, idx, dst_f32):
     M, Cc = src.shape
     L.check(L.load().vmvm_scatter_add_rows_bf16(src.data_ptr(), _ld(src), idx.data_ptr(), dst_f32.data_ptr(), _ld(dst_f32), M, Cc,

@@ -105,6 +105,7 @@ _PROTOS = {
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_pool_grad_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_scatter_add_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_gelu_bwd_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_dropout_bf16": ([c_void_p, c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),

@@ -113,6 +113,72 @@ def check_gemm_fp16_conv():
         rep(f"conv3x3 fp16 n={n} {Hh}x{Ww} {Ci}->{Co} relu", y.float(), torch.relu(ref))
 
 
+def check_dvae_passes():
+    """round-2 passes of the dVAE tokenizer: A-operand ReLU, the 256x64 tile (64 output channels), fused arg-max, NHWC max-pool, stem
+    im2col with the pixel pre-processing, against torch in fp32"""
+    H16 = torch.float16
+    def r16(*sh): return (torch.randn(*sh, device=dev) * 0.5).to(H16)
+    for (n, Hh, Ww, Ci, Co) in [(3, 14, 10, 64, 64), (2, 28, 28, 256, 64), (1, 9, 7, 128, 48), (2, 12, 12, 64, 128)]:
+        x = r16(n, Hh, Ww, Ci)
+        w = (torch.randn(Co, Ci, 3, 3, device=dev) / (3 * Ci ** 0.5)).to(H16)
+        bias = torch.randn(Co, device=dev) * 0.1
+        w2 = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+        for ar in (False, True):
+            xin = torch.relu(x) if ar else x
+            ref = torch.relu(torch.nn.functional.conv2d(xin.permute(0, 3, 1, 2).float(), w.float(), bias, padding=1)).permute(0, 2, 3, 1).reshape(-1, Co)
+            y = K.gemm(x.view(-1, Ci), w2, bias=bias, act=2, fp16=True, conv=(9, Hh, Ww), a_relu=ar)
+            rep(f"conv3x3 fp16 n={n} {Hh}x{Ww} {Ci}->{Co} relu a_relu={int(ar)}", y.float(), ref)
+    for (M, N, K_) in [(1000, 512, 256), (3000, 8192, 512), (777, 128, 128)]:
+        A, Bw, bias = r16(M, K_), r16(N, K_), torch.randn(N, device=dev)
+        ref = torch.relu(A).float() @ Bw.float().t() + bias
+        rep(f"gemm fp16 a_relu {M}x{N}x{K_} f32 out", K.gemm(A, Bw, bias=bias, out_dtype=torch.float32, fp16=True, a_relu=True), ref, tol=2e-3)
+        groups = N // 64
+        pairs = torch.empty((M, 2 * groups), device=dev, dtype=torch.float32)
+        K.gemm(A, Bw, bias=bias, out=pairs, N=N, act=5, fp16=True, a_relu=True)
+        tok = K.argmax_pairs(pairs, groups)
+        lg = K.gemm(A, Bw, bias=bias, out_dtype=torch.float32, fp16=True, a_relu=True)
+        rep(f"fused arg-max {M}x{N}x{K_} == argmax(logits)", tok.float(), torch.argmax(lg, 1).float(), tol=0.0)
+        rep(f"fused arg-max {M}x{N}x{K_} pair maxima", pairs.view(M, groups, 2)[:, :, 0].max(1).values, lg.max(1).values, tol=1e-6)
+    for (n, Hh, Ww, C_) in [(3, 8, 12, 64), (2, 56, 56, 256), (1, 2, 2, 8)]:
+        x = r16(n * Hh * Ww, C_)
+        ref = torch.nn.functional.max_pool2d(x.view(n, Hh, Ww, C_).permute(0, 3, 1, 2).float(), 2).permute(0, 2, 3, 1).reshape(-1, C_)
+        rep(f"maxpool2x2 nhwc n={n} {Hh}x{Ww}x{C_}", K.maxpool2x2_nhwc(x, n, Hh, Ww).float(), ref, tol=0.0)
+    for (n, Hh, Ww) in [(2, 16, 24), (1, 9, 5)]:
+        img = torch.randn(n, 3, Hh, Ww, device=dev)
+        w = torch.randn(32, 3, 7, 7, device=dev) / 12.0
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+        xp = 0.8 * (img * std + mean) + 0.1
+        ref = torch.nn.functional.conv2d(xp.half().float(), w.half().float(), None, padding=3).permute(0, 2, 3, 1).reshape(-1, 32)
+        wk = torch.zeros((32, 7, 8, 3), device=dev)
+        wk[:, :, :7, :] = w.permute(0, 2, 3, 1)
+        wk = torch.nn.functional.pad(wk.reshape(32, 168), (0, 24)).half()
+        cols = K.dvae_stem_im2col(img)
+        rep(f"stem im2col n={n} {Hh}x{Ww} (via the 7x7 conv)", cols.float() @ wk.float().t(), ref, tol=1e-3)
+
+
+def check_pool_grad():
+    """gradient of the token pool (gather-sum through the static video fan-in and the text CSR) against index_add in fp32"""
+    import numpy as np
+    for (B, O, Lv, X, Hd, third) in [(4, 4, 20, 8, 64, False), (5, 3, 7, 4, 128, True), (2, 2, 3, 2, 8, False)]:
+        Lq = Lv + X
+        g1, g2 = rnd(B * Lq, Hd), rnd(B * O * Lq, Hd)
+        g3 = rnd(B * Lq, Hd) if third else None
+        tj = np.concatenate([[i] + list(np.random.permutation([j for j in range(B) if j != i])[:O - 1]) for i in range(B)]).astype(np.int64)
+        order = np.argsort(tj, kind="stable")
+        csr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(tj, minlength=B)), order]).astype(np.int32)).to(dev)
+        out = K.pool_grad(g1, g2, g3, B, O, Lv, X, csr[:B + 1], csr[B + 1:])
+        ref = torch.zeros(B * Lv + B * X, Hd, device=dev)
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx1 = torch.from_numpy(np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)])).to(dev)
+        idx2 = torch.from_numpy(np.concatenate([np.concatenate([(p_ // O) * Lv + ar_v, B * Lv + int(tj[p_]) * X + ar_t]) for p_ in range(B * O)])).to(dev)
+        ref.index_add_(0, idx1, g1.float())
+        ref.index_add_(0, idx2, g2.float())
+        if third:
+            ref.index_add_(0, idx1, g3.float())
+        rep(f"pool_grad B={B} O={O} Lv={Lv} X={X} Hd={Hd} third={int(third)}", out.float(), ref, tol=8e-3)
+
+
 def check_gemm_big(variant=4, tag="big"):
     """256^2-tile kernel (variant 4) / 3-stage 256x128 kernel (variant 5) on every layout + epilogue paths + split-K."""
     for (M, N, K_) in [(392 * 3, 768, 128), (1000, 1024, 768), (4096, 512, 2048), (777 * 8, 256, 64)]:
@@ -849,7 +915,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "attna", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc)
+                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc, dvae=check_dvae_passes, pool=check_pool_grad)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
