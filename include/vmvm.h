@@ -215,6 +215,14 @@ int64_t vmvm_attention_bwd_workspace_size(const vmvm_attn_bwd_desc* d); /* bytes
 /* cov (optional, u8 (B,T,H/32,W/32)): covered 32x32 pixel blocks read as zeros == `img *= 1-cov` of
  * Agent_Pretrain.masking (main_pretrain.py:362-364) without writing a masked copy of the clip. */
 int vmvm_patch_im2col(const float* img, const uint8_t* cov, void* cols, int32_t B, int32_t T, int32_t H, int32_t W, void* stream);
+/* PatchEmbed3D forward in one kernel (visbackbone/video_swin.py:390-407): zero frame appended (:398), Conv3d(3 -> E, (2,4,4), stride
+ * (1,4,4)) on MFMA with the pixels as a bf16 hi + lo pair, bias, LayerNorm(eps) as the epilogue.  img f32 (B,T,3,H,W); cov as above;
+ * weight_bf16 [E][96] with k = c*32 + dt*16 + dy*4 + dx (the Conv3d weight flattened); x_out bf16 [B*T*(H/4)*(W/4)][E] = the normalised
+ * tokens, z_out f32 (same shape) = the conv output the LayerNorm backward reads, mean / rstd f32 per token.  E in {32, 64, 96, 128, 192}.
+ * No im2col buffer exists in the forward; the weight gradient re-derives its operand with vmvm_patch_im2col in the backward. */
+int vmvm_patch_embed_fwd(const float* img, const uint8_t* cov, const void* weight_bf16, const float* bias, const float* gamma,
+                         const float* beta, float eps, void* x_out, float* z_out, float* mean, float* rstd, int32_t B, int32_t T,
+                         int32_t H, int32_t W, int32_t E, void* stream);
 
 /* Device-side masking (Agent_Pretrain.masking main_pretrain.py:276-372, mask types 'rm' and 'bm'; 'am' is not built) from
  * EXPLICIT uniform draws in [0,1) (f32, e.g. torch.rand on the device), so the same draws give the same batch on the CPU oracle:

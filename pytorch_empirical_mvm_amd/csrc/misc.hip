@@ -33,8 +33,8 @@ __global__ void im2col_kernel(const float* __restrict__ img, const uint8_t* __re
   const long ntok = (long)B * T * Hp * Wp;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntok * 6) return;
-  const int cd = (int)(i / ntok);
-  const long tok = i - (long)cd * ntok;
+  const long tok = i / 6;                               // (colour, frame) fastest: six adjacent threads write one token's 192 contiguous bytes
+  const int cd = (int)(i - tok * 6);
   const int c = cd >> 1, dt = cd & 1;
   const int x = (int)(tok % Wp);
   const int y = (int)((tok / Wp) % Hp);

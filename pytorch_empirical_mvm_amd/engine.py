@@ -266,21 +266,21 @@ class VioletEngine:
 
     # -------------------------------------------------------------- Video-Swin
     def _patch_embed(self, img, cov):
-        """PatchEmbed3D (video_swin.py:390-407) as im2col + MFMA GEMM + LayerNorm.  The layer is 0.1% of the FLOPs but sets
-        the precision of everything downstream, so the pixels enter as a bf16 hi/lo pair (K = 2x96) and the conv output
-        stays f32 into the LayerNorm (the reference runs this conv in fp16 = 3 more mantissa bits than bf16)."""
+        """PatchEmbed3D (video_swin.py:390-407) in one kernel (`vmvm_patch_embed_fwd`: clip read once, cover + zero frame applied on
+        the way into the MFMA operands, LayerNorm as the epilogue).  The layer is 0.1% of the FLOPs but sets the precision of
+        everything downstream, so the pixels enter as a bf16 hi/lo pair and the conv output stays f32 into the LayerNorm (the
+        reference runs this conv in fp16 = 3 more mantissa bits than bf16).  No im2col buffer is kept: the weight gradient
+        re-derives its [M,192] = [hi | lo] operand in the backward, where it lives for one GEMM."""
         S, pre = self.store, "enc_img.swin.patch_embed."
-        cols = K.patch_im2col(img, cov)                                   # [M,192] = [hi | lo]
         E = self.cfg["embed_dim"]
         wb = S.b(pre + "proj.weight", (E, 96))
-        w2 = torch.cat([wb, wb], dim=1).contiguous()                     # [E,192] (tiny; plumbing)
-        z = K.gemm(cols, w2, bias=S.p(pre + "proj.bias"), out_dtype=F32)
-        x, mean, rstd = K.layernorm_fwd(z, S.p(pre + "norm.weight"), S.p(pre + "norm.bias"), 1e-5)
+        x, z, mean, rstd = K.patch_embed_fwd(img, cov, wb, S.p(pre + "proj.bias"), S.p(pre + "norm.weight"), S.p(pre + "norm.bias"), 1e-5)
         out = V(x)
 
         def bwd():
             dz, _ = K.layernorm_bwd(out.g, z, S.p(pre + "norm.weight"), mean, rstd, S.g(pre + "norm.weight"), S.g(pre + "norm.bias"))
             K.colsum(dz, S.g(pre + "proj.bias"), accumulate=True)
+            cols = K.patch_im2col(img, cov)                                   # [M,192] = [hi | lo]
             K.gemm(dz, cols, a_kmajor=False, b_kmajor=False, M=E, N=96, K=dz.shape[0], out=S.g(pre + "proj.weight", (E, 96)), accumulate=True)
         self.tape.append(bwd)
         return out

@@ -215,6 +215,20 @@ def patch_im2col(img, cov=None):
     return cols
 
 
+def patch_embed_fwd(img, cov, w_bf16, bias, gamma, beta, eps):
+    """PatchEmbed3D forward in one launch -> (x bf16 [M,E], z f32 [M,E], mean, rstd)   (include/vmvm.h)"""
+    B, T, _, H, W = img.shape
+    E = w_bf16.shape[0]
+    M = B * T * (H // 4) * (W // 4)
+    x = torch.empty((M, E), device=img.device, dtype=BF16)
+    z = torch.empty((M, E), device=img.device, dtype=F32)
+    mean = torch.empty(M, device=img.device, dtype=F32)
+    rstd = torch.empty(M, device=img.device, dtype=F32)
+    L.check(L.load().vmvm_patch_embed_fwd(img.data_ptr(), L.ptr(cov), w_bf16.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                          x.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, T, H, W, E, L.stream()), "patch_embed_fwd")
+    return x, z, mean, rstd
+
+
 def encvideo_assemble(fc_out, cls, pos, len_, B, T, hw, Hd):
     out = torch.empty((B * T * (1 + hw), Hd), device=fc_out.device, dtype=BF16)
     L.check(L.load().vmvm_encvideo_assemble(fc_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), len_.data_ptr(), out.data_ptr(),

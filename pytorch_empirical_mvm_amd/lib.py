@@ -86,6 +86,7 @@ _PROTOS = {
     "vmvm_layernorm_bwd": ([C.POINTER(LnBwdDesc), c_void_p], c_int),
     "vmvm_attention_fwd": ([C.POINTER(AttnFwdDesc), c_void_p], c_int),
     "vmvm_attention_bwd": ([C.POINTER(AttnBwdDesc), c_void_p], c_int),
+    "vmvm_patch_embed_fwd": ([c_void_p] * 6 + [c_float] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p], c_int),
     "vmvm_patch_im2col": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_masking": ([c_void_p] * 8 + [c_int] * 7 + [c_float] + [c_int] * 4 + [c_void_p], c_int),
     "vmvm_encvideo_assemble": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p], c_int),

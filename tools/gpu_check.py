@@ -687,6 +687,23 @@ def check_misc():
     w = torch.randn(32, 3, 2, 4, 4, device=dev)
     ref = torch.nn.functional.conv3d(x.to(BF).float(), w, stride=(1, 4, 4)).permute(0, 2, 3, 4, 1).reshape(-1, 32)
     rep("im2col hi+lo (via conv3d)", (cols[:, :96].float() + cols[:, 96:].float()) @ w.view(32, 96).t(), torch.nn.functional.conv3d(x, w, stride=(1, 4, 4)).permute(0, 2, 3, 4, 1).reshape(-1, 32), tol=1e-4)
+    # fused PatchEmbed3D forward (conv + bias + LayerNorm, cover + zero frame applied while reading) against conv3d + layer_norm in fp32
+    for (B_, T_, H_, W_, E_) in [(2, 4, 64, 96, 128), (1, 3, 32, 32, 96), (2, 2, 64, 32, 192)]:
+        im = torch.randn(B_, T_, 3, H_, W_, device=dev)
+        cv = (torch.rand(B_, T_, H_ // 32, W_ // 32, device=dev) < 0.3).to(torch.uint8)
+        wq = (torch.randn(E_, 3, 2, 4, 4, device=dev) * 0.1).to(BF)
+        bq, gq, beq = torch.randn(E_, device=dev) * 0.1, 1 + 0.1 * torch.randn(E_, device=dev), 0.1 * torch.randn(E_, device=dev)
+        for cov_ in (None, cv):
+            xm = im if cov_ is None else im * (1 - cov_.float().repeat_interleave(32, 2).repeat_interleave(32, 3)).unsqueeze(2)
+            xin = torch.nn.functional.pad(xm.transpose(1, 2), (0, 0, 0, 0, 0, 1))
+            zr = torch.nn.functional.conv3d(xin, wq.float(), bq, stride=(1, 4, 4)).permute(0, 2, 3, 4, 1).reshape(-1, E_)
+            xr = torch.nn.functional.layer_norm(zr, (E_,), gq, beq, 1e-5)
+            xo, zo, mo, ro = K.patch_embed_fwd(im, cov_, wq.view(E_, 96).contiguous(), bq, gq, beq, 1e-5)
+            tag = f"patch_embed_fwd B={B_} T={T_} {H_}x{W_} E={E_} cov={int(cov_ is not None)}"
+            rep(tag + " z", zo, zr, tol=2e-4)
+            rep(tag + " x", xo, xr, tol=8e-3)
+            rep(tag + " mean", mo, zr.mean(1), tol=2e-4)
+            rep(tag + " rstd", ro, (zr.var(1, unbiased=False) + 1e-5).rsqrt(), tol=2e-4)
     # encvideo assemble
     hw, Hd = 6, 64
     fc = rnd(B * T * hw, Hd)
