@@ -590,6 +590,7 @@ class VioletEngine:
         gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
         Wdec = S.b(pm + "decoder.weight")
         Nlog = -(-Vv // 4) * 4
+        Kdec = Vpad if (Vpad % 64 == 0 and (Vpad - Vv) * Hd <= S.TAIL) else Vv
         tgt_m = ans_mtm.reshape(-1).contiguous()
 
         def mlm_head(outv, loss):
@@ -606,7 +607,10 @@ class VioletEngine:
             """head gradients (accumulated into the shared fc_mtm.* tensors) ; d(text rows of the encoder output) -> dx_out"""
             K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
             K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
-            dtn = K.gemm(hd["dlog"], Wdec, b_kmajor=False, M=B * X, N=Hd, K=Vv)
+            # K = the padded vocabulary when that is a whole number of 64-wide K tiles (30522 -> 30528): the extra columns of dlog are
+            # zeros and the extra rows of the weight view lie inside the arena (other parameters / its zero tail), so they add
+            # nothing -- and the GEMM takes the direct-to-LDS kernel instead of the K % 64 != 0 fallback (497 -> 60 us)
+            dtn = K.gemm(hd["dlog"], Wdec, b_kmajor=False, M=B * X, N=Hd, K=Kdec)
             dt_, _ = K.layernorm_bwd(dtn, hd["t"], gm, hd["mean"], hd["rstd"], S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
             du_ = K.gelu_bwd(dt_, hd["u"])
             self._linear_bwd(du_, hd["r"], pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dx_out))
@@ -935,7 +939,7 @@ class VioletEngine:
             return loss, lg_[:, :Vv]
         K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=nr, N=Vpad)
         K.gemm(dlog, tn_, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=nr, out=S.g(pm + "decoder.weight"), accumulate=True)
-        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=nr, N=Hd, K=Vv)
+        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=nr, N=Hd, K=Vpad if (Vpad % 64 == 0 and (Vpad - Vv) * Hd <= S.TAIL) else Vv)   # (see forward_backward)
         dt_, _ = K.layernorm_bwd(dtn, t_, gm, mean_, rstd_, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
         du_ = K.gelu_bwd(dt_, u_)
         dtxt = self._linear_bwd(du_, r_, pm + "transform.dense.weight", pm + "transform.dense.bias")

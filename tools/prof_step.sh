@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace -d /tmp/prof_step -- python3 $GRAFT_REPO_ROOT/bench.py 
 tail -1 /tmp/prof_step.log | cut -c1-200
 DB=$(find /tmp/prof_step -name "*.db" | head -1)
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
-python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $DB 80 > $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_shapes.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_shapes.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_gaps.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_gaps.txt 2>&1
 head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
