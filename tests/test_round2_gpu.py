@@ -314,3 +314,51 @@ def test_standalone_vidswin_and_encvideo_surface(tmp_path):
         fr = R.enc_video(sd, cfg, img)
     fr = fr[0] if isinstance(fr, (tuple, list)) else fr
     assert _cos(feat.float().cpu(), fr.reshape(feat.shape)) >= 0.999
+
+
+def test_edge_cases_single_clip_empty_cover_padded_text_single_frame():
+    """Edge cases of the step against the oracle on the same inputs: B = 1 (O = min(B, 4) = 1: the VTM logits are (1, 1), its loss 0 --
+    main_pretrain.py:243-262), a batch whose patch cover is EMPTY (pixel loss = 0 / (0 + 1e-5), main_pretrain.py:429-430), text rows
+    padded down to [CLS] [SEP], a single-frame clip (T = 1: D is padded 1 -> 8 inside the window partition) at 96^2 pixels, and a batch
+    without any MLM target (the one place the two differ by design: reference NaN, here 0)."""
+    from oracle import violet_ref as R
+    arch = dict(embed_dim=32, depths=(1, 1, 2, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    for (T, img_sz, B, empty_cov, short_txt) in [(2, 96, 1, False, False), (1, 96, 2, False, True), (2, 96, 2, True, False)]:
+        model, args = _engine(dict(vis_backbone_size="tiny", size_frame=T, max_size_frame=6, arch_override=arch, bert_layers=1, size_img=img_sz))
+        cfg = R.make_cfg("tiny", T=T, img=img_sz, arch=arch, bert_layers=1)
+        sd = R.make_state_dict(cfg)
+        model.load_state_dict(sd)
+        img, txt, mask = R.make_batch(cfg, B)
+        if short_txt:                                               # row 0: only [CLS] [SEP] are real tokens
+            txt[0, 2:] = 0; mask[0, 2:] = 0; txt[0, 1] = 102
+        mb = R.default_masking(cfg, img, txt, mask, seed=5)
+        if empty_cov:
+            mb["mvm_mask"].zero_(); mb["img"] = mb["unmask_img"].clone()
+        neg = R.vtm_negatives_default(B)
+        with torch.no_grad():
+            ref = R.pretrain_losses(sd, cfg, mb, negatives=neg)
+        cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+        batch = dict(img=mb["unmask_img"].cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+        eng = model.engine
+        eng.store.grad.zero_()
+        losses, _ = eng.forward_backward(batch, negatives=neg, train=False, want_outputs=True, backward=True)
+        torch.cuda.synchronize()
+        tag = (T, img_sz, B, empty_cov, short_txt)
+        for k in ("mtm", "vtm", "mvm"):
+            got, want = float(losses[k].item()), float(ref[k])
+            assert np.isfinite(got), (tag, k, got)
+            if k == "mtm" and int((mb["ans_mtm"] != -1).sum()) == 0:
+                # a batch without a single MLM target: the reference's CrossEntropyLoss(ignore_index=-1) averages over an empty set
+                # (NaN, and the step's update is lost); vmvm_cross_entropy divides by max(n_valid, 1): loss 0, zero gradient
+                assert not np.isfinite(want) and got == 0.0, (tag, got, want)
+                continue
+            tol = 8e-2 if k == "vtm" else 3e-2 * abs(want) + 2e-3
+            assert abs(got - want) <= tol, (tag, k, got, want)
+        if B == 1:
+            assert abs(float(losses["vtm"].item())) <= 1e-6
+        if empty_cov:
+            assert float(losses["mvm"].item()) == 0.0
+        g = eng.store.grad[:eng.store.n_trainable]
+        assert bool(torch.isfinite(g).all()), tag
+        if empty_cov:                                               # no covered patch: the pixel head receives no gradient at all
+            assert float(eng.store.g("decoder_pixel.0.weight").abs().max()) == 0.0
