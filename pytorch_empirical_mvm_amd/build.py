@@ -13,17 +13,40 @@ SOURCES = ["gemm.hip", "gemm_pp.hip", "layernorm.hip", "attention.hip", "misc.hi
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 
+INFO = os.path.join(HERE, "libvmvm.build.json")       # next to the .so (git-ignored like it): what the library was built from
+
+
+def _source_hash():
+    """sha256 over every file the library is compiled from (csrc/*.hip, csrc/*.h, include/vmvm.h) + the flags"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
+    for f in files:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "vmvm.h"), "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    """content-based: the recorded source hash must match (mtimes say nothing after a checkout / snapshot copy)"""
+    import json
+    if not os.path.exists(LIB) or not os.path.exists(INFO):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vmvm.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return json.load(open(INFO)).get("source_sha256") != _source_hash()
+    except Exception:
+        return True
 
 
 def build(force=False, verbose=True):
+    import json
+    import time
+    force = force or os.environ.get("VMVM_FORCE_BUILD") == "1"
     if not force and not _stale():
+        if verbose:
+            print(f"libvmvm: up to date (source hash {_source_hash()[:16]} matches {os.path.basename(INFO)}); VMVM_FORCE_BUILD=1 rebuilds", flush=True)
         return LIB
+    t0 = time.time()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -41,6 +64,14 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()[0]
+    except Exception:
+        ver = "?"
+    json.dump(dict(source_sha256=_source_hash(), sources=SOURCES, flags=FLAGS, hipcc=ver, seconds=round(time.time() - t0, 1),
+                   built_at=time.strftime("%Y-%m-%dT%H:%M:%S")), open(INFO, "w"), indent=1)
+    if verbose:
+        print(f"libvmvm: rebuilt {len(SOURCES)} sources in {time.time() - t0:.0f} s ({ver})", flush=True)
     return LIB
 
 
