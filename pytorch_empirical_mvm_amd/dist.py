@@ -28,7 +28,17 @@ def init_from_env(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, init_method="env://")
+        kw = {}
+        if backend == "nccl":
+            # RCCL's kernels run on the process group's own stream; high priority lets their workgroups take the first CUs that a
+            # retiring GEMM workgroup frees (the persistent GEMM grids otherwise re-occupy every CU launch after launch)
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:
+                kw = {}
+        dist.init_process_group(backend=backend, init_method="env://", **kw)
     return rank, world, local
 
 
