@@ -736,6 +736,61 @@ def gold_optimizer():
     print("optimizer ok")
 
 
+def write_tsv_fixture_files(root):
+    """the deterministic TSV files both the generator and the test write: two image files (key, caption, base64 payload columns of
+    varying length, one line with surrounding blanks) + list / sequence files of the composite view"""
+    import base64
+    os.makedirs(root, exist_ok=True)
+    names = ["img_a.tsv", "img_b.tsv"]
+    for fi, name in enumerate(names):
+        with open(os.path.join(root, name), "w") as f:
+            for r in range(5 + 2 * fi):
+                payload = [base64.b64encode(bytes((7 * r + 3 * c + fi + k) % 251 for k in range(40 + 17 * r + c))).decode() for c in range(1 + (r % 3))]
+                key = f"vid{fi}_{r:03d}" + ("x" * (30 * (r % 2)))
+                f.write("\t".join([key, f" caption {r} of file {fi} "] + payload) + "\n")
+    with open(os.path.join(root, "files.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    with open(os.path.join(root, "seq.tsv"), "w") as f:
+        for src, row in [(0, 2), (1, 6), (1, 0), (0, 4), (0, 0), (1, 3)]:
+            f.write(f"{src}\t{row}\n")
+    return names
+
+
+def gold_tsv():
+    """the reference's TSVFile / CompositeTSVFile / create_lineidx (utils/tsv_file.py) run on the fixture files; the
+    locking helper of utils/qd_common.py (it imports cv2 / matplotlib / progressbar, absent here) is replaced by plain open()."""
+    import importlib
+    import tempfile
+    import types
+    qd = types.ModuleType("utils.qd_common")
+    qd.exclusive_open_to_read = lambda fname, mode="r": open(fname, mode)
+    sys.modules["utils.qd_common"] = qd
+    tf = importlib.import_module("utils.tsv_file")
+    root = tempfile.mkdtemp()
+    names = write_tsv_fixture_files(root)
+    out = {}
+    for name in names:
+        t = tf.TSVFile(os.path.join(root, name), generate_lineidx=True)
+        out[name] = dict(lineidx=[int(x) for x in open(os.path.splitext(os.path.join(root, name))[0] + ".lineidx").read().split()],
+                         num_rows=t.num_rows(), rows=[t.seek(i) for i in range(t.num_rows())], keys=[t.seek_first_column(i) for i in range(t.num_rows())],
+                         getitem_last=t[t.num_rows() - 1], length=len(t))
+    c = tf.CompositeTSVFile(os.path.join(root, "files.txt"), os.path.join(root, "seq.tsv"), root=root)
+    out["composite"] = dict(num_rows=c.num_rows(), rows=[c[i] for i in range(len(c))], keys=[c.get_key(i) for i in range(len(c))],
+                            source_idx=c.get_composite_source_idx(), file_list=tf.load_list_file(os.path.join(root, "files.txt")))
+    # Dataset_Base.sampling (dataset.py:142-146): dataset.py itself is stubbed out (cv2 / torchvision video transforms), so the one method
+    # is compiled from the reference's source text at generation time
+    import ast
+    import textwrap
+    src = open(os.path.join(REF, "dataset.py")).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "sampling"][0]
+    ns = {}
+    exec(textwrap.dedent(ast.get_source_segment(src, fn)), ns)
+    smp = ns["sampling"]
+    out["sampling"] = {f"{a},{b},{n}": smp(None, a, b, n) for (a, b, n) in [(0, 31, 8), (0, 5, 6), (3, 40, 4), (0, 9, 1), (2, 2, 3), (0, 100, 16)]}
+    json.dump(out, open(os.path.join(OUT, "tsv.json"), "w"))
+    print("tsv ok", {k: (v["num_rows"] if isinstance(v, dict) and "num_rows" in v else len(v)) for k, v in out.items()})
+
+
 def qamc_batch(cfg, B, O):
     """deterministic (B, O, X) multiple-choice batch: the text / mask rows of make_batch(B*O) with one [MASK] (id 103) per sequence,
     labelled `true` (2995) for the answer option and `false` (6270) for the others (main_qamc_tsv_mlm_head.py:26-37)"""
@@ -808,6 +863,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
     from visbackbone import video_swin as vs
+    if "--tsv-only" in sys.argv:
+        gold_tsv()
+        sys.exit(0)
     if "--qamc-only" in sys.argv:
         gold_qamc()
         sys.exit(0)
@@ -847,3 +905,4 @@ if __name__ == "__main__":
     gold_retrieval()
     gold_qaoe()
     gold_qamc()
+    gold_tsv()
