@@ -25,6 +25,36 @@
 namespace {
 
 constexpr float NEG_INF = -__builtin_huge_valf();
+// Bias blocks that enter the score through an MFMA (bias_block_mfma): out-of-range keys carry a large FINITE negative value -- the
+// identity product multiplies every entry by 0 or 1, and 0 * -inf would be NaN.  exp2 of it is exactly 0 all the same.
+constexpr float PAD_BIAS = -1.0e30f;
+// One (16 x 16) bias + mask block, kept as packed bf16 in two registers per lane, added to a score accumulator by the matrix core:
+// D = I(16x16) * Bias + C on v_mfma_f32_16x16x16_bf16.  The two registers ARE the B operand of that instruction (lane (col r, group g)
+// holds rows 4g..4g+3 of column r -- the accumulator layout of the score MFMA), the A operand is the identity (1.0 where the lane's
+// row equals one of its four k slots).  It replaces four VALU unpack instructions per block in kernels whose VALU pipe is the bound
+// while the matrix pipe idles; exact (1.0 * b accumulates in f32).
+// HAZARD (measured, tools/probe/bias_mfma_probe.hip): hipcc 7.2 emits NO wait states between v_mfma_f32_16x16x16_bf16 and a
+// v_mfma_f32_16x16x32_bf16 that reads its result as SrcC (or the reverse), and the hardware does not forward between the two
+// instruction types -- the consumer reads two stale registers.  With one independent MFMA between producer and consumer the result
+// is correct.  Every use below therefore issues the bias products EARLY (a whole pass / tile pair ahead of their consumers) and pins
+// that order with sched_barrier.
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+__device__ __forceinline__ s16x4_ bias_ident_frag(int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  s16x4_ a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = (4 * g + j == r) ? (short)0x3f80 : (short)0;      // bf16 1.0
+  return a;
+}
+__device__ __forceinline__ f32x4 bias_block_mfma(const s16x4_& ident, uint32_t w0, uint32_t w1, const f32x4& c) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ident, __builtin_bit_cast(s16x4_, u32x2_{w0, w1}), c, 0, 0, 0);
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {        // v_max3_f32 without fmaxf's canonicalisation of each input
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 struct Smem {
   int nt, nt2, lp16, lp32;
@@ -102,6 +132,14 @@ __device__ __forceinline__ void fill_one(unsigned char* dst, int kv_bytes, const
   typedef __attribute__((address_space(3))) void lds_void;
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(ksrc), 0, (int)bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vsrc), 0, (int)bytes, 0x00020000);
+  if (!guard || goff != 0xffffffffu) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)dst, 16, goff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes), 16, goff, 0, 0, 0);
+  }
+}
+// the same with the two buffer resources built by the caller ONCE per sequence (building them per request costs 8 v_readfirstlane each)
+__device__ __forceinline__ void fill_one_r(unsigned char* dst, int kv_bytes, const __amdgpu_buffer_rsrc_t rk, const __amdgpu_buffer_rsrc_t rv, uint32_t goff, bool guard) {
+  typedef __attribute__((address_space(3))) void lds_void;
   if (!guard || goff != 0xffffffffu) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)dst, 16, goff, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes), 16, goff, 0, 0, 0);
@@ -717,6 +755,7 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+  const s16x4_ ident = bias_ident_frag(lane);
   const int L = p.L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
   const int logical = xcd_remap(blockIdx.x, heads * nch * nqg);
   const int qg = logical % nqg;
@@ -744,7 +783,7 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = t * 16 + g * 4 + j;
-        float b = NEG_INF;
+        float b = PAD_BIAS;
         if (key < L) {
           b = tabs[rcq - rcs[key]];
           if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
@@ -822,26 +861,34 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
     const unsigned char* tv1 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
     const uint32_t tv0a = lds_addr(tv0), tv1a = lds_addr(tv1);
     // pass 1: scores (+ bias through the C operand) for the whole row block, running maximum
+    const __amdgpu_buffer_rsrc_t rk_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(kv_nx + p.k_off), 0, (int)fill_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(kv_nx + p.v_off), 0, (int)fill_bytes, 0x00020000);
     f32x4 acc[NX];
     float mx = NEG_INF;
+    // pass 0: the bias + mask blocks of all NX tiles through the matrix core (independent products, NX - 1 of them between any block
+    // and the score MFMA that accumulates onto it -- see the hazard note at bias_block_mfma)
+#pragma unroll
+    for (int t = 0; t < NX; ++t) acc[t] = bias_block_mfma(ident, bm[2 * t], bm[2 * t + 1], f32x4{0.f, 0.f, 0.f, 0.f});
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
-      float b0f, b1f, b2f, b3f;                           // volatile: keeps the unpack next to its MFMA (else 4*NX VGPRs get hoisted)
-      asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b0f) : "v"(bm[2 * t]));
-      asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b1f) : "v"(bm[2 * t]));
-      asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(b2f) : "v"(bm[2 * t + 1]));
-      asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(b3f) : "v"(bm[2 * t + 1]));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 1024), cqf, f32x4{b0f, b1f, b2f, b3f}, 0, 0, 0);
-      if (t < NF && has_next) fill_one(dst_nx + t * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[t], t == NF - 1);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 1024), cqf, acc[t], 0, 0, 0);
+      if (t < NF && has_next) fill_one_r(dst_nx + t * NWV * 64 * 16, KV, rk_nx, rv_nx, goff[t], t == NF - 1);
     }
+    float mx1 = NEG_INF;                                  // two chains of v_max3_f32: two new elements per instruction
 #pragma unroll
-    for (int t = 0; t < NX; ++t) mx = fmaxf(fmaxf(mx, fmaxf(acc[t][0], acc[t][1])), fmaxf(acc[t][2], acc[t][3]));
+    for (int t = 0; t < NX; ++t) { mx = max3_f32(mx, acc[t][0], acc[t][1]); mx1 = max3_f32(mx1, acc[t][2], acc[t][3]); }
+    mx = fmaxf(mx, mx1);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     f32x2 nm2 = {-mx * LOG2E, -mx * LOG2E};
     asm volatile("" : "+v"(nm2));                         // real register pair (see attn_bwd_dq_win2_kernel)
     // pass 2: p = exp2((s - max) * log2 e), row sum, P V with P as the B operand (the MFMA k-slot order is free)
-    f32x2 sum2 = {0.f, 0.f};
+    // row sums through the matrix core as well: an all-ones A operand makes every row of the product the column sums of P over the
+    // pair's 32 keys (of the bf16 P the output is built from), complete across the wave -- no per-element adds, no shuffles
+    typedef __attribute__((ext_vector_type(8))) short s16x8o;
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, s16x8o{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+    f32x4 osum = {0.f, 0.f, 0.f, 0.f};
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int c = 0; c < NPK; ++c) {
@@ -856,7 +903,6 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
           for (int hj = 0; hj < 2; ++hj) {
             const f32x2 e = __builtin_elementwise_fma(f32x2{acc[t][2 * hj], acc[t][2 * hj + 1]}, f32x2{LOG2E, LOG2E}, nm2);
             const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-            sum2 += pr;
             pw[2 * u + hj] = pack_bf2v(pr);
           }
         }
@@ -868,10 +914,9 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
       const s16x8 v1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), pf, o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), pf, o[1], 0, 0, 0);
+      osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf, osum, 0, 0, 0);
     }
-    float sum = sum2[0] + sum2[1];
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    const float sum = osum[0];
     if (qv) {
       const float inv = seq_scale / sum;
       u16* op = reinterpret_cast<u16*>(p.out) + seq * L * p.ld_out + off_o;
