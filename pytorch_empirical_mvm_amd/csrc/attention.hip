@@ -90,6 +90,14 @@ __device__ __forceinline__ int k_off_swz(int row, int chunk) {   // row-major [r
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// a pointer the compiler must treat as wave-uniform (it is: derived from blockIdx and loop counters, but after SGPR spilling the
+// compiler loses that and wraps every buffer instruction built on it in a waterfall loop)
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
 // fill row-major swizzled [rows][HD] from global rows (zero beyond L) with direct-to-LDS DMA (buffer_load ... lds): no VGPR
 // round trip, all requests of a thread in flight at once.  The LDS image is lane-linear per wave instruction, so the chunk
 // swizzle is applied to the SOURCE column; rows >= L fall beyond the descriptor's num_records and read as zero.
@@ -98,7 +106,7 @@ template <int HD>
 __device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src, int ld, int L, int rows, int tid, int nthreads) {
   constexpr int CPR = HD / 8;
   const unsigned bytes = (unsigned)(((size_t)(L - 1) * ld + HD) * 2);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(src)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   const int total = rows * CPR;
   const int wave_base = tid & ~63;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -116,8 +124,8 @@ __device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src
 template <int NF, int STEP>
 __device__ __forceinline__ void fill_pre(unsigned char* dst, int kv_bytes, const u16* ksrc, const u16* vsrc, unsigned bytes, const uint32_t* goff) {
   typedef __attribute__((address_space(3))) void lds_void;
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(ksrc), 0, (int)bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vsrc), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(ksrc)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(vsrc)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
     if (i < NF - 1 || goff[i] != 0xffffffffu) {
@@ -130,8 +138,8 @@ __device__ __forceinline__ void fill_pre(unsigned char* dst, int kv_bytes, const
 // ~16 cycles per 1-KiB wave request, so 8 waves issuing a whole fill back to back serialise for ~1500 cycles)
 __device__ __forceinline__ void fill_one(unsigned char* dst, int kv_bytes, const u16* ksrc, const u16* vsrc, unsigned bytes, uint32_t goff, bool guard) {
   typedef __attribute__((address_space(3))) void lds_void;
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(ksrc), 0, (int)bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vsrc), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(ksrc)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(vsrc)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   if (!guard || goff != 0xffffffffu) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)dst, 16, goff, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + kv_bytes), 16, goff, 0, 0, 0);
@@ -149,8 +157,8 @@ __device__ __forceinline__ void fill_one_r(unsigned char* dst, int kv_bytes, con
 __device__ __forceinline__ void dma16_pair(unsigned char* dst, int img_bytes, const u16* src0, unsigned bytes0, uint32_t off0,
                                            const u16* src1, unsigned bytes1, uint32_t off1, bool guard) {
   typedef __attribute__((address_space(3))) void lds_void;
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src0), 0, (int)bytes0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(src1), 0, (int)bytes1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(src0)), 0, __builtin_amdgcn_readfirstlane((int)bytes0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(src1)), 0, __builtin_amdgcn_readfirstlane((int)bytes1), 0x00020000);
   if (!guard || off0 != 0xffffffffu) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_void*)dst, 16, off0, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(dst + img_bytes), 16, off1, 0, 0, 0);
@@ -158,7 +166,7 @@ __device__ __forceinline__ void dma16_pair(unsigned char* dst, int img_bytes, co
 }
 __device__ __forceinline__ void dma16_one(unsigned char* dst, const float* src, unsigned bytes, uint32_t off) {
   typedef __attribute__((address_space(3))) void lds_void;
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(src)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_void*)dst, 16, off, 0, 0, 0);
 }
 __device__ __forceinline__ void fill_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -204,6 +212,13 @@ __device__ __forceinline__ void tr_read4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4&
                "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
                : "=&v"(a0), "=&v"(a1), "=&v"(c0), "=&v"(c1) : "v"(pa), "v"(pc), "i"(off), "i"(off + 1024) : "memory");
 }
+// Two 16-byte LDS reads through inline asm (immediate offset, as tr_read4): a plain load of an LDS region that a direct-to-LDS DMA
+// also writes makes the compiler put s_waitcnt vmcnt(0) in front of it -- i.e. the wave drains the NEXT sequence's prefetch it has
+// just issued (measured in attn_bwd_dkv_win2_kernel: 5 drains per sequence, ~half of its wave cycles)
+__device__ __forceinline__ void lds_read2_b128(f32x4& a, f32x4& b, uint32_t pa, uint32_t pb, const int off) {
+  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb), "i"(off) : "memory");
+}
+__device__ __forceinline__ void lds_wait2(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void tr_wait4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
 }
@@ -861,8 +876,8 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
     const unsigned char* tv1 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
     const uint32_t tv0a = lds_addr(tv0), tv1a = lds_addr(tv1);
     // pass 1: scores (+ bias through the C operand) for the whole row block, running maximum
-    const __amdgpu_buffer_rsrc_t rk_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(kv_nx + p.k_off), 0, (int)fill_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(kv_nx + p.v_off), 0, (int)fill_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(kv_nx + p.k_off)), 0, __builtin_amdgcn_readfirstlane((int)fill_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(kv_nx + p.v_off)), 0, __builtin_amdgcn_readfirstlane((int)fill_bytes), 0x00020000);
     f32x4 acc[NX];
     float mx = NEG_INF;
     // pass 0: the bias + mask blocks of all NX tiles through the matrix core (independent products, NX - 1 of them between any block
@@ -1499,11 +1514,11 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
   auto dma_step = [&](size_t seq, int buf, int i) {
     unsigned char* dst = smem + buf * BUF;
     if (i < NF) {
-      const u16* qsrc = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + p.q_off + h * HD;
-      const u16* dsrc = reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout + h * HD;
+      const u16* qsrc = uniform_ptr(reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + p.q_off + h * HD);
+      const u16* dsrc = uniform_ptr(reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout + h * HD);
       dma16_pair(dst + (tid & ~63) * 16 + i * NWV * 64 * 16, IMG, qsrc, q_bytes, goq[i], dsrc, do_bytes, god[i], i == NF - 1);
     } else if (wave < 4) {
-      const float* src = ((wave < 2) ? p.lse : pb.delta) + (seq * heads + h) * L;
+      const float* src = uniform_ptr(((wave < 2) ? p.lse : pb.delta) + (seq * heads + h) * L);
       dma16_one(dst + 2 * IMG + (wave >> 1) * LV * 4 + (wave & 1) * 1024, src, (unsigned)(L * 4), (uint32_t)(((wave & 1) * 64 + lane) * 16));
     }
   };
@@ -1561,6 +1576,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
     const unsigned char* dOs = Qs + IMG;
     const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * IMG);
     const float* delta_s = lse_s + LV;
+    const uint32_t lse_a = lds_addr(reinterpret_cast<const unsigned char*>(lse_s + g * 4)), delta_a = lds_addr(reinterpret_cast<const unsigned char*>(delta_s + g * 4));
     f32x4 dk[KT][2], dv[KT][2];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
@@ -1586,10 +1602,11 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
         if (qt < NX) {
           const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qb_ + qt * 1024);
           const bf16x8 dof = *reinterpret_cast<const bf16x8*>(qb_ + IMG + qt * 1024);
-          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + g * 4);
-          const float4 d4 = *reinterpret_cast<const float4*>(delta_s + qt * 16 + g * 4);
-          f32x2 nl[2] = {f32x2{-l4.x * LOG2E, -l4.y * LOG2E}, f32x2{-l4.z * LOG2E, -l4.w * LOG2E}};
-          f32x2 nd[2] = {f32x2{-d4.x, -d4.y}, f32x2{-d4.z, -d4.w}};
+          f32x4 l4, d4;
+          lds_read2_b128(l4, d4, lse_a, delta_a, qt * 64);
+          lds_wait2(l4, d4);
+          f32x2 nl[2] = {f32x2{-l4[0] * LOG2E, -l4[1] * LOG2E}, f32x2{-l4[2] * LOG2E, -l4[3] * LOG2E}};
+          f32x2 nd[2] = {f32x2{-d4[0], -d4[1]}, f32x2{-d4[2], -d4[3]}};
 #pragma unroll
           for (int t = 0; t < KT; ++t) {
             float b0f, b1f, b2f, b3f;                     // volatile: keeps the unpack inside the loop (else 4x the registers get hoisted)
