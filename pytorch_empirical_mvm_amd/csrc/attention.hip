@@ -890,9 +890,14 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 1024), cqf, acc[t], 0, 0, 0);
       if (t < NF && has_next) fill_one_r(dst_nx + t * NWV * 64 * 16, KV, rk_nx, rv_nx, goff[t], t == NF - 1);
     }
+    // The maxima run on inline-asm v_max3_f32 and hipcc does not insert MFMA-result wait states in front of inline asm: the
+    // barrier keeps every one of them BEHIND all score MFMAs (measured without it: a max3 scheduled one instruction after the MFMA
+    // whose result it reads -- stale data, flaky tests).  The last tile's maximum is 2 (NX - 1) instructions after its MFMA's issue.
+    __builtin_amdgcn_sched_barrier(0);
     float mx1 = NEG_INF;                                  // two chains of v_max3_f32: two new elements per instruction
 #pragma unroll
     for (int t = 0; t < NX; ++t) { mx = max3_f32(mx, acc[t][0], acc[t][1]); mx1 = max3_f32(mx1, acc[t][2], acc[t][3]); }
+    __builtin_amdgcn_sched_barrier(0);
     mx = fmaxf(mx, mx1);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));

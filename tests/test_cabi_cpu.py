@@ -89,3 +89,19 @@ def test_product_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle|violet_ref", src, flags=re.M), f"{f} imports the oracle"
+
+
+@pytest.mark.timeout(600)
+def test_attention_isa_lint():
+    """tools/isa_lint.py on a fresh gfx950 compile of attention.hip (needs hipcc; cross-compiles without a GPU): no DMA-queue drains or
+    waterfall loops in the hot loops of the batch-persistent window-attention kernels, no inline-asm VALU reading an MFMA result
+    the compiler would have had to wait for, no back-to-back 16x16x16 -> 16x16x32 SrcC chain (hipcc 7.2 hazard)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_lint.py")], capture_output=True, text=True, timeout=580)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
