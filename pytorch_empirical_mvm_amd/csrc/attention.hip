@@ -84,10 +84,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
 }
 
+// 16-byte chunk swizzle of the row-major [row][HD] bf16 LDS images.  Measured (tools/probe/lds_conflict_probe.hip, 16 waves hammering
+// the two access patterns of these kernels -- ds_read_b128 fragments: lane (r, g) -> row r, chunk g; ds_read_b64_tr_b16: lane (r, g) ->
+// row 4g + r/4, chunk (r & 3) / 2, byte 8 (r & 1)), cycles per 4 reads x 16 waves:
+//   64-byte rows (head_dim 32):  (row >> 1) & 3 : 208 / 128     the round-1 choice (row >> 2) & 3 : 321 / 192 (= no swizzle at all)
+//   128-byte rows (head_dim 64): row & 7        : 224 / 128     the round-1 choice (row >> 1) & 7 : 224 / 195
+// Periodic in 8 rows, so per-tile immediate offsets (16 rows) still work.
+template <int HD>
+__device__ __forceinline__ int swz_chunk(int row) { return HD == 32 ? ((row >> 1) & 3) : (row & 7); }
 template <int HD>
 __device__ __forceinline__ int k_off_swz(int row, int chunk) {   // row-major [row][HD] bf16, 16B chunk swizzle
-  if (HD == 32) return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  if (HD == 32) return row * 64 + ((chunk ^ swz_chunk<32>(row)) << 4);
+  return row * 128 + ((chunk ^ swz_chunk<64>(row)) << 4);
 }
 
 // a pointer the compiler must treat as wave-uniform (it is: derived from blockIdx and loop counters, but after SGPR spilling the
@@ -114,7 +122,7 @@ __device__ __forceinline__ void fill_rowmajor(unsigned char* dst, const u16* src
     const int u = i0 + tid;
     if (u < total) {
       const int row = u / CPR, chs = u - row * CPR;
-      const int ch = (HD == 32) ? (chs ^ ((row >> 2) & 3)) : (chs ^ ((row >> 1) & 7));
+      const int ch = chs ^ swz_chunk<HD>(row);
       const unsigned goff = (unsigned)(((size_t)row * ld + ch * 8) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + (size_t)(i0 + wave_base) * 16), 16, goff, 0, 0, 0);
     }
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
     const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
-    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ ((row >> 2) & 3)) << 3)) * 2) : 0xffffffffu;
+    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ swz_chunk<32>(row)) << 3)) * 2) : 0xffffffffu;
   }
   const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
   bf16x8 qf;
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
     const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
-    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ ((row >> 2) & 3)) << 3)) * 2) : 0xffffffffu;   // (beyond the image: out of range -> no-op)
+    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ swz_chunk<32>(row)) << 3)) * 2) : 0xffffffffu;   // (beyond the image: out of range -> no-op)
   }
   const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
   auto issue = [&](size_t seq, int buf) {
@@ -1510,7 +1518,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
   uint32_t goq[NF], god[NF];
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
-    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3, cs = (chs ^ ((row >> 2) & 3)) << 3;
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3, cs = (chs ^ swz_chunk<32>(row)) << 3;
     goq[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + cs) * 2) : 0xffffffffu;
     god[i] = (u < LP32 * 4) ? (uint32_t)((row * pb.ld_dout + cs) * 2) : 0xffffffffu;
   }
