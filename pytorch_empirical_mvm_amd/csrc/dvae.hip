@@ -12,35 +12,41 @@ inline int nblk(long n, int per) { return (int)((n + per - 1) / per); }
 // (x * std + mean) and map_pixels (utils.py:46-52) squeezes into [eps, 1 - eps]: v = 0.8 * (x * std + mean) + 0.1; the convolution pads
 // the PRE-PROCESSED image with zeros.  Row m = pixel (n, y, x); column k = ky * 24 + kx * 3 + c for kx < 7 (columns 21..23 of a ky
 // block and 168..191 are zero): 192 fp16 per row, K a multiple of the GEMM's 64-wide K tile.
-__global__ void dvae_stem_im2col_kernel(const float* __restrict__ img, u16* __restrict__ cols, int n_img, int H, int W) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)n_img * H * W * 24;                 // one thread per 16-byte chunk
-  if (i >= total) return;
-  const int q = (int)(i % 24);
-  const long pix = i / 24;
-  const int x = (int)(pix % W);
-  const long t = pix / W;
+// One workgroup = TW consecutive output pixels of one image row: the 7 x (TW + 6) x 3 input patch is loaded ONCE, coalesced along x,
+// pre-processed and zero-padded on the way into LDS (every input pixel is used by up to 49 outputs); then item (pixel, 16-byte chunk)
+// with the chunk index fastest, so 24 adjacent threads write one pixel's 384 contiguous bytes.
+constexpr int STEM_TW = 32;
+__global__ __launch_bounds__(256) void dvae_stem_im2col_kernel(const float* __restrict__ img, u16* __restrict__ cols, int n_img, int H, int W) {
+  __shared__ float patch[3][7][STEM_TW + 6];
+  const int segs = (W + STEM_TW - 1) / STEM_TW;
+  const long wg = blockIdx.x;
+  const int seg = (int)(wg % segs);
+  const long t = wg / segs;
   const int y = (int)(t % H);
   const int n = (int)(t / H);
-  const int ky = q / 3, part = q - ky * 3;
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  const int yy = y + ky - 3;
-  if (ky < 7 && yy >= 0 && yy < H) {
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int x0 = seg * STEM_TW;
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (int i = threadIdx.x; i < 3 * 7 * (STEM_TW + 6); i += 256) {
+    const int xx = i % (STEM_TW + 6), r = i / (STEM_TW + 6), ky = r % 7, c = r / 7;
+    const int gy = y + ky - 3, gx = x0 + xx - 3;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = 0.8f * (img[(((long)n * 3 + c) * H + gy) * W + gx] * stdv[c] + mean[c]) + 0.1f;
+    patch[c][ky][xx] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < STEM_TW * 24; i += 256) {
+    const int q = i % 24, px = i / 24;
+    if (x0 + px >= W) break;
+    const int ky = q / 3, part = q - ky * 3;
+    float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int idx = part * 8 + e;
       const int kx = idx / 3, c = idx - kx * 3;
-      const int xx = x + kx - 3;
-      if (idx < 21 && xx >= 0 && xx < W) {
-        const float p = img[(((long)n * 3 + c) * H + yy) * W + xx];
-        v[e] = 0.8f * (p * stdv[c] + mean[c]) + 0.1f;
-      }
+      v[e] = (ky < 7 && idx < 21) ? patch[c][ky < 7 ? ky : 0][px + kx] : 0.f;
     }
+    *reinterpret_cast<uint4*>(cols + ((((long)n * H + y) * W) + x0 + px) * 192 + q * 8) = pack_h8(v);
   }
-  *reinterpret_cast<uint4*>(cols + pix * 192 + q * 8) = pack_h8(v);
 }
 
 // ---- MaxPool2d(2) (encoder.py:62,66,70) on an NHWC fp16 activation: one thread per 8 channels of an output pixel -------------------
@@ -87,8 +93,8 @@ __global__ void argmax_pairs_kernel(const float* __restrict__ pairs, int ld, int
 
 extern "C" int vmvm_dvae_stem_im2col(const float* img, void* cols, int32_t n_img, int32_t H, int32_t W, void* stream) {
   if (!img || !cols || n_img <= 0 || H <= 0 || W <= 0) return VMVM_EINVAL;
-  const long n = (long)n_img * H * W * 24;
-  hipLaunchKernelGGL(dvae_stem_im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, ST, img, reinterpret_cast<u16*>(cols), n_img, H, W);
+  const long wgs = (long)n_img * H * ((W + STEM_TW - 1) / STEM_TW);
+  hipLaunchKernelGGL(dvae_stem_im2col_kernel, dim3((unsigned)wgs), dim3(256), 0, ST, img, reinterpret_cast<u16*>(cols), n_img, H, W);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

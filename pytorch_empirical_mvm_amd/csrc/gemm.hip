@@ -1033,6 +1033,7 @@ static int epi_need(const vmvm_gemm_desc& d) {
 constexpr int EF_TEACHER = EF_BIAS | EF_COLSCALE | EF_ACT24 | EF_RESID | EF_F32;
 constexpr int EF_TEACHER_CONV = EF_BIAS | EF_ACT24;
 constexpr int EF_TEACHER_ARGMAX = EF_BIAS | EF_ARGMAX;
+constexpr int EF_TEACHER_RES = EF_BIAS | EF_COLSCALE | EF_RESID;      // id_path / conv_4: the two 1x1 forms inside a block (16-bit out, no activation)
 template <bool CONV, int F, int TM, bool ARELU>
 int launch_pers_teacher(const vmvm_gemm_desc& d, hipStream_t st) {
   constexpr int BM_ = TM == 2 ? 256 : 128, BN_ = TM == 2 ? 64 : 128;
@@ -1126,6 +1127,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
       return ar ? launch_pers_teacher<true, EF_TEACHER_CONV, 1, true>(dt, st_) : launch_pers_teacher<true, EF_TEACHER_CONV, 1, false>(dt, st_);
     }
     if (dt.act == 5) return ar ? launch_pers_teacher<false, EF_TEACHER_ARGMAX, 1, true>(dt, st_) : launch_pers_teacher<false, EF_TEACHER_ARGMAX, 1, false>(dt, st_);
+    if (!ar && !dt.out_fp32 && dt.act == 0) return launch_pers_teacher<false, EF_TEACHER_RES, 1, false>(dt, st_);
     return ar ? launch_pers_teacher<false, EF_TEACHER, 1, true>(dt, st_) : launch_pers_teacher<false, EF_TEACHER, 1, false>(dt, st_);
   }
   // 16-byte chunks may straddle the logical extent as long as the row stride covers the round-up
