@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
 }
 
 template <int NCH, bool XF32>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
+__global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {   // NCH = 2: 131 VGPRs without the hint, 4 waves per SIMD need <= 128
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][C] partial dgamma/dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = p.C, nch = C >> 3, cseg = C / p.nseg;
@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
     long b = 0, ml = m;
     if (p.src) { b = m / p.rows_out_per_batch; ml = m - b * p.rows_out_per_batch; }
     if (p.src && p.pad_mode == 0 && p.src[ml] < 0) continue;     // pad slot: constant zero output
-    float xh[NCH][8], gdy[NCH][8];
+    // bf16 inputs stay PACKED between the two passes over the row (x-hat and gamma * dy are recomputed for the output: the kernel is
+    // memory-latency bound at 19 % VALU, and the 16 registers saved at NCH = 2 are the difference between 3 and 4 waves per SIMD)
+    float xh[XF32 ? NCH : 1][8], gdy[XF32 ? NCH : 1][8];
+    uint4 xraw[NCH], dyraw[NCH];
     long srow[NCH]; int within[NCH];
     uint4 addv[NCH];                                      // residual-path gradient, requested WITH x / dY (not after the row reduction)
     float s1 = 0.f, s2 = 0.f;
@@ -132,8 +135,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       srow[i] = -1; within[i] = 0;
+      xraw[i] = make_uint4(0, 0, 0, 0); dyraw[i] = make_uint4(0, 0, 0, 0);
+      if (XF32) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; gdy[i][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { xh[XF32 ? i : 0][e] = 0.f; gdy[XF32 ? i : 0][e] = 0.f; }
+      }
       if (c < nch) {
         const int col = c * 8;
         srow[i] = m; within[i] = col;
@@ -143,20 +149,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
           srow[i] = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
         }
         float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
-        if (srow[i] >= 0) load_x8<XF32>(p.X, (size_t)srow[i] * p.ldx + within[i], xv);
+        if (XF32) {
+          if (srow[i] >= 0) load_x8<XF32>(p.X, (size_t)srow[i] * p.ldx + within[i], xv);
+        } else {
+          if (srow[i] >= 0) xraw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.X) + (size_t)srow[i] * p.ldx + within[i]);
+          unpack_bf8(xraw[i], xv);
+        }
         addv[i] = make_uint4(0, 0, 0, 0);
         if (ADD && srow[i] >= 0) addv[i] = *reinterpret_cast<const uint4*>(ADD + (size_t)srow[i] * p.ldadd + within[i]);
-        unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col), dyv);
+        dyraw[i] = *reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col);
+        unpack_bf8(dyraw[i], dyv);
         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (xv[e] - mean) * rstd;
-          gdy[i][e] = dyv[e] * gg[e];
-          dg[i][e] += dyv[e] * xh[i][e];
+          const float xhe = (xv[e] - mean) * rstd, gde = dyv[e] * gg[e];
+          if (XF32) { xh[XF32 ? i : 0][e] = xhe; gdy[XF32 ? i : 0][e] = gde; }
+          dg[i][e] += dyv[e] * xhe;
           db[i][e] += dyv[e];
-          s1 += gdy[i][e];
-          s2 += gdy[i][e] * xh[i][e];
+          s1 += gde;
+          s2 += gde * xhe;
         }
       }
     }
@@ -167,8 +179,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const vmvm_ln_bwd_desc p) {
       const int c = lane + i * 64;
       if (c < nch && srow[i] >= 0) {
         float o[8];
+        if (XF32) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rstd * (gdy[i][e] - s1 - xh[i][e] * s2);
+          for (int e = 0; e < 8; ++e) o[e] = rstd * (gdy[XF32 ? i : 0][e] - s1 - xh[XF32 ? i : 0][e] * s2);
+        } else {
+          float xv[8], dyv[8];
+          unpack_bf8(xraw[i], xv);
+          unpack_bf8(dyraw[i], dyv);
+          const int col = c * 8;
+          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rstd * (dyv[e] * gg[e] - s1 - (xv[e] - mean) * rstd * s2);
+        }
         if (ADD) {
           float a[8];
           unpack_bf8(addv[i], a);
@@ -444,7 +467,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
-  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 3 : 2;
+  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
   int grid = (d->M + 3) / 4;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
   const size_t sm = (size_t)8 * d->C * sizeof(float);   // 4 wave slabs x [2][C]
@@ -487,7 +510,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
 // scratch of the dgamma / dbeta reduction (one [2][C] f32 partial row per resident workgroup); without it: global atomics
 extern "C" int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d) {
   if (!d || d->M <= 0 || d->C <= 0) return VMVM_EINVAL;
-  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 3 : 2;
+  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
   int grid = (d->M + 3) / 4;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
   return (int64_t)grid * 2 * d->C * (int64_t)sizeof(float);
