@@ -362,3 +362,53 @@ def test_edge_cases_single_clip_empty_cover_padded_text_single_frame():
         assert bool(torch.isfinite(g).all()), tag
         if empty_cov:                                               # no covered patch: the pixel head receives no gradient at all
             assert float(eng.store.g("decoder_pixel.0.weight").abs().max()) == 0.0
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_c4_vq_target_step_vs_oracle():
+    """BASELINE config 4 at full width on one GPU (Swin-B, 8 x 224^2 frames, vq target with the full dVAE tokenizer: n_hid 256, 8192
+    codes, every pass a libvmvm kernel), B = 2, against the CPU oracle on the same weights and batch: token agreement of the native
+    fp16 tokenizer with the oracle's fp32 encoder, then -- with the ORACLE's tokens as targets on both sides, so an arg-max near-tie
+    does not decide the comparison -- the three losses, the vq-head gradients (cosine >= 0.99, norm +-5 %) and the global norm."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    B, T = 2, 8
+    cfg = R.make_cfg("base", T=T, mvm_target=["vq"], temp=1.0)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=T, max_size_frame=8, mvm_target=["vq"], temp=1.0))
+    assert model.dalle.native
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    agent = Agent_Pretrain(args, model)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=3)
+    neg = R.vtm_negatives_default(B)
+    with torch.no_grad():
+        tok_ref = R.vq_tokens(sd, cfg, mb["unmask_img"])                                  # (B*T, 28, 28) from the fp32 encoder
+    tok = model.dalle.extract_vq_token(img.view(B * T, 3, 224, 224).cuda()).cpu()
+    agree = float((tok == tok_ref.view_as(tok)).float().mean())
+    assert agree >= 0.98, agree
+    mb["vq_tokens"] = tok_ref
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ls = R.pretrain_losses(params, cfg, mb, negatives=neg)
+    ls["total"].backward()
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    vqi = agent.vq_index(cov)
+    batch = dict(img=img.cuda(), cov=cov.cuda().contiguous(), txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda(),
+                 vq_patch_rows=vqi["vq_patch_rows"].cuda(), vq_tok_index=vqi["vq_tok_index"].cuda(), vq_tokens=tok_ref.view_as(tok).cuda())
+    eng = model.engine
+    eng.store.grad.zero_()
+    losses, _ = eng.forward_backward(batch, negatives=neg, train=False, backward=True, want_outputs=True)
+    torch.cuda.synchronize()
+    for k in ("mtm", "vtm", "mvm"):
+        got, want = float(losses[k].item()), float(ls[k].detach())
+        assert abs(got - want) <= 2e-2 * abs(want) + 2e-3, (k, got, want)
+    for k in ("decoder_vq.0.weight", "decoder_vq.0.bias", "fc_mvm.1.weight", "fc_mvm.1.bias", "fc_mvm.3.weight", "fc_mvm.3.bias"):
+        got = eng.store.g(k).detach().cpu().double().flatten()
+        ref = params[k].grad.double().flatten()
+        c, ratio = _cos(got, ref), float(got.norm() / ref.norm())
+        assert c >= 0.99 and abs(ratio - 1.0) <= 0.05, (k, c, ratio)
+    ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
+    S = eng.store
+    got_norm = float(torch.sqrt((S.grad[:S.n_trainable].double() ** 2).sum()).item())
+    assert abs(got_norm - ref_norm) <= 2e-2 * ref_norm, (got_norm, ref_norm)
