@@ -986,8 +986,9 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
   const int h = t1 / nch;
   const int tl4 = (p.table_len + 3) & ~3, lr4 = (L + 3) & ~3;
   float* dtab = reinterpret_cast<float*>(smem + 4 * KV);
-  float* xch = dtab + tl4;                                              // [NS-1][NQ][64 lanes][8] f32 : dQ partials of splits 1..
-  float* tabs = xch + (NS - 1) * NQ * 64 * 8;                           // this head's bias-table column
+  constexpr int XCH = (NS - 1) * NQ * 64 * 8;
+  float* xch = dtab + tl4;                                              // [2][NS-1][NQ][64 lanes][8] f32 : dQ partials of splits 1.., double-buffered by sequence parity
+  float* tabs = xch + 2 * XCH;                                          // this head's bias-table column
   int* rcs = reinterpret_cast<int*>(tabs + tl4);
   unsigned char* regs = reinterpret_cast<unsigned char*>(rcs + lr4);    // region ids of the current window position
   const bool want_dtab = pb.dbias_table != nullptr;
@@ -1069,12 +1070,12 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
   if (b0 < b1) { issue(seq_nx(), 0); fetch(seq_nx()); advance(); }
 
   f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // this half's partial of the PREVIOUS clip (kh == 0 keeps it)
-  auto flush_prev = [&](size_t seq) {                    // split 0: add the other splits' partials (in LDS) and store dQ of clip bprev
+  auto flush_prev = [&](size_t seq, int par) {           // split 0: add the other splits' partials (in LDS buffer `par`) and store dQ of clip bprev
     if (kh == 0 && qv) {
       float4 x0 = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]), x1 = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
 #pragma unroll
       for (int o = 0; o < NS - 1; ++o) {
-        const float* x = xch + ((o * NQ + ql) * 64 + lane) * 8;
+        const float* x = xch + par * XCH + ((o * NQ + ql) * 64 + lane) * 8;
         const float4 y0 = *reinterpret_cast<const float4*>(x), y1 = *reinterpret_cast<const float4*>(x + 4);
         x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
         x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
     const size_t seq = (size_t)c_cu * nWin + w_cu;
     fill_wait();
     __syncthreads();                                      // sequence b landed; other buffer free; partials of b-1 visible; tables staged
-    if (b > b0) flush_prev(seq_pv);
+    if (b > b0) flush_prev(seq_pv, cur ^ 1);
     seq_pv = seq;
     const int wcur = w_cu;
     if (++c_cu == B) { c_cu = 0; ++w_cu; }
@@ -1116,8 +1117,8 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
       advance();
       if (!active) fill_pre<NF, NWV * 64 * 16>(dst_nx, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: __syncthreads() would also drain the DMA / prefetch queue
-    __builtin_amdgcn_s_barrier();                         // xch has been consumed before the other splits overwrite it
+    // (no second barrier per sequence: the partials of sequence b go to exchange buffer b & 1, split 0 reads them after the NEXT
+    //  loop-top barrier, and that buffer is written again only two sequences later)
     if (!active) continue;
     const unsigned char* Ksm = smem + cur * 2 * KV;
     float dl = 0.f;
@@ -1204,13 +1205,13 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
       dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), dsf, dq[1], 0, 0, 0);
     }
     if (kh > 0) {                                         // splits 1.. publish their partials; split 0 adds them after the next barrier
-      float* x = xch + (((kh - 1) * NQ + ql) * 64 + lane) * 8;
+      float* x = xch + cur * XCH + (((kh - 1) * NQ + ql) * 64 + lane) * 8;
       *reinterpret_cast<float4*>(x) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
       *reinterpret_cast<float4*>(x + 4) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
     }
   }
   __syncthreads();
-  if (b1 > b0 && active) flush_prev(seq_pv);
+  if (b1 > b0 && active) flush_prev(seq_pv, (b1 - 1 - b0) & 1);
   if (want_dtab) {
     if (qv) {
       const int rcq = rcs[q] + p.rc0;
@@ -2465,7 +2466,7 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     const int nq = s_.nt == 25 ? 4 : 7, ns = s_.nt == 25 ? 2 : 1;
     const int lp32 = win2_rows(s_.nt, ns);
     const int tl4 = (d->f.table_len + 3) & ~3, lr4 = (d->f.L + 3) & ~3;
-    const int smem2 = 4 * lp32 * 64 + 2 * tl4 * 4 + (ns - 1) * nq * 64 * 8 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
+    const int smem2 = 4 * lp32 * 64 + 2 * tl4 * 4 + 2 * (ns - 1) * nq * 64 * 8 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && smem2 <= 160 * 1024;
     if (pers_ok) {
       // nt = 25 (392-token window): 4 query tiles x 2 key splits (8 waves, ~220 VGPRs, no spill); nt = 13: 7 tiles x 1 split.
