@@ -895,6 +895,49 @@ def bench_attn():
         print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF (B=32 x 5 seqs)")
 
 
+def bench_attn_c5():
+    """streaming attention kernels at the config-5 shapes (B = 4 clips): Swin-L stage-3 windows (8 per clip x 24 heads x 1152 tokens,
+    head_dim 32, shifted) and the fusion sequences (B * 5 x 12 heads x 2352 tokens, head_dim 64, key mask + dropout)"""
+    print("---- attention timing, config-5 shapes")
+    B = 4
+    heads, N, ws, dims = 24, 1152, (8, 12, 12), (16, 24, 24)
+    nW = (dims[0] // 8) * (dims[1] // 12) * (dims[2] // 12)
+    nseq = B * nW
+    C_ = heads * 32
+    qkv = rnd(nseq * N, 3 * C_)
+    rc, rc0 = SI.rc_codes(N, ws)
+    rc_t = torch.from_numpy(rc).to(dev)
+    table = torch.randn(15 * 23 * 23, heads, device=dev) * 0.1
+    reg = torch.from_numpy(SI.region_ids(dims[0], dims[1], dims[2], ws, (4, 6, 6))).to(dev)
+    kw = dict(q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
+    f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, **kw)
+    out, lse = f()
+    dout = rnd(nseq * N, C_)
+    dtab = torch.zeros_like(table)
+    b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=dtab, **kw)
+    b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=None, **kw)
+    fl = 4.0 * nseq * heads * N * N * 32
+    tests = [("c5 win fwd", f, 1, fl), ("c5 win bwd", b, 2.5, fl), ("c5 win bwd (no table grad)", b0, 2.5, fl)]
+    nseq2, Lq, heads2, Hd = B * 5, 2352, 12, 768
+    qkv2 = rnd(nseq2 * Lq, 3 * Hd)
+    km = torch.ones(nseq2, Lq, dtype=torch.uint8, device=dev)
+    f2 = lambda: K.attention_fwd(qkv2, nseq2, Lq, heads2, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    out2, lse2 = f2()
+    dout2 = rnd(nseq2 * Lq, Hd)
+    b2 = lambda: K.attention_bwd(dout2, qkv2, out2, lse2, nseq2, Lq, heads2, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    fl2 = 4.0 * nseq2 * heads2 * Lq * Lq * 64
+    tests += [("c5 fusion fwd", f2, 1, fl2), ("c5 fusion bwd", b2, 2.5, fl2)]
+    for name, fn, mult, flops in tests:
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"     {name}: {ms:.3f} ms  {flops * mult / ms / 1e9:.1f} TF (B={B})")
+
+
 def bench_ln():
     print("---- layernorm timing (ms, algorithmic GB/s = bf16 tensors touched)")
     K.set_workspace(torch.empty(64 << 20, device=dev, dtype=torch.uint8))
@@ -938,6 +981,8 @@ if __name__ == "__main__":
             run(bench_gemm); run(bench_attn)
         elif w == "benchattn":
             run(bench_attn)
+        elif w == "benchattn5":
+            run(bench_attn_c5)
         elif w == "benchln":
             run(bench_ln)
         else:
