@@ -2004,10 +2004,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dbias_stream_kernel(const vm
   const int qb = rest % nqb, ch = rest / nqb;
   const int chunk = ch / heads, h = ch - chunk * heads;
   const int k0 = kc * KC;
+  constexpr int BUF = 2 * KC * HD * 2;               // one (K chunk, V chunk) pair; TWO of them sit in front of the stream layout's tables
   unsigned char* Ksm = smem;
-  unsigned char* Vsm = smem + sm.off_b;
-  int* rc = reinterpret_cast<int*>(smem + sm.off_rc);
-  float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
+  unsigned char* Vsm = smem + KC * HD * 2;
+  int* rc = reinterpret_cast<int*>(smem + BUF + sm.off_rc);
+  float* tab = reinterpret_cast<float*>(smem + BUF + sm.off_tab);
   float* dtab = tab;                                 // the gradient copy reuses the table's LDS once the sequence loop is done
   for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
   for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h];
@@ -2041,27 +2042,46 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dbias_stream_kernel(const vm
         }
       }
     }
+    // The clip loop is latency-bound (16 MFMAs per wave and clip against a DMA fill, four global loads and a barrier), so it is
+    // software-pipelined: clip b+1's K / V chunk streams into the other LDS buffer and its Q / dO / lse / delta rows into registers
+    // while clip b is computed; the fragments are read with inline asm (a plain load would make the compiler drain that prefetch).
+    auto seq_of = [&](int b) { return (size_t)b * nwin + w; };
+    auto issue = [&](int b, int buf) {
+      const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + seq_of(b) * L * p.ld_qkv;
+      fill_rowmajor<HD>(Ksm + buf * BUF, qkv + (size_t)k0 * p.ld_qkv + p.k_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+      fill_rowmajor<HD>(Vsm + buf * BUF, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
+    };
+    bf16x8 qf_n, dof_n;
+    float nl_n = 0.f, ndl_n = 0.f, ss_n = 1.0f;
+    auto fetch = [&](int b) {
+      const size_t seq = seq_of(b);
+      const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv;
+      const u16* dO = reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout + h * HD;
+      ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+      qf_n = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8, qv);
+      dof_n = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8, qv);
+      nl_n = qv ? p.lse[(seq * heads + h) * L + q] : 0.f;
+      ndl_n = qv ? pb.delta[(seq * heads + h) * L + q] : 0.f;
+    };
+    __syncthreads();                                   // everyone is done with both buffers (previous window position)
+    issue(0, 0);
+    fetch(0);
     for (int b = 0; b < nclip; ++b) {
-      const int seq = b * nwin + w;
-      const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * L * p.ld_qkv;
-      const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * L * pb.ld_dout + h * HD;
-      __syncthreads();
-      fill_rowmajor<HD>(Ksm, qkv + (size_t)k0 * p.ld_qkv + p.k_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
-      fill_rowmajor<HD>(Vsm, qkv + (size_t)k0 * p.ld_qkv + p.v_off + h * HD, p.ld_qkv, L - k0, KC, tid, NW * 64);
-      const float ss = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
-      const bf16x8 qf = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8, qv);
-      const bf16x8 dof = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8, qv);
-      const float nl = qv ? -p.lse[((size_t)seq * heads + h) * L + q] * LOG2E : 0.f;
-      const float ndl = qv ? -pb.delta[((size_t)seq * heads + h) * L + q] : 0.f;
+      const int cur = b & 1;
       fill_wait();
-      __syncthreads();
+      __syncthreads();                                 // clip b's chunk landed for everyone; everyone left the other buffer
+      const bf16x8 qf = qf_n, dof = dof_n;
+      const float nl = -nl_n * LOG2E, ndl = -ndl_n, ss = ss_n;
+      if (b + 1 < nclip) { issue(b + 1, cur ^ 1); fetch(b + 1); }
+      const uint32_t ka = lds_addr(Ksm + cur * BUF + k_off_swz<HD>(r, g)), va = lds_addr(Vsm + cur * BUF + k_off_swz<HD>(r, g));
+      f32x4 kraw[NTC], vraw[NTC];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) lds_read2_b128(kraw[t], vraw[t], ka, va, t * 1024);
 #pragma unroll
       for (int t = 0; t < NTC; ++t) {
-        const int row = t * 16 + r;
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, g));
-        const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, bm[t], 0, 0, 0);
-        const bf16x8 vf = frag_hd<HD>(Vsm, row, g);
-        const f32x4 dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        lds_wait2(kraw[t], vraw[t]);                   // ties THIS tile's registers to the wait (all 2 * NTC reads are in flight together: only the first one waits)
+        const f32x4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kraw[t]), qf, bm[t], 0, 0, 0);
+        const f32x4 dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vraw[t]), dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[j], LOG2E, nl));
@@ -2434,9 +2454,10 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       // per-sequence load latency is the number of workgroups in flight per CU (3 at this size, 1 with 8 waves)
       constexpr int NWB = 4;
       const int nqbb = (nt_ + NWB - 1) / NWB;
-      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWB, KCS>, sa.total);
+      const int sm_db = sa.total + 2 * KCS * 32 * 2;                    // second (K chunk, V chunk) buffer of the pipelined clip loop
+      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWB, KCS>, sm_db);
       if (rc_) return rc_;
-      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWB, KCS>), dim3(ncb * d->f.heads * nqbb * nkc), dim3(NWB * 64), sa.total, st, *d, ncb, nqbb, nwin);
+      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWB, KCS>), dim3(ncb * d->f.heads * nqbb * nkc), dim3(NWB * 64), sm_db, st, *d, ncb, nqbb, nwin);
       VMVM_CHECK_LAUNCH();
     }
     return VMVM_OK;
