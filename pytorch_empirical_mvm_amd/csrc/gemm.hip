@@ -15,7 +15,8 @@
 #include "common.h"
 #include "gemm_epi.h"
 
-int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st);      // gemm_pp.hip: 256x256 ping-pong main loop
+int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st);
+int vmvm_gemm_pp_fp8(const vmvm_gemm_desc& d, int need, hipStream_t st);      // gemm_pp.hip: 256x256 ping-pong main loop
 
 namespace {
 
@@ -1096,12 +1097,22 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // fp8 (OCP e4m3) operands: k-major both, whole 128-element K tiles, epilogue features within EF_FP8
     if (!d->a_kmajor || !d->b_kmajor || d->in_fp16 || d->conv_taps) return VMVM_ENOSUPPORT;
     if ((d->K % 128) || (d->N & 7) || (d->lda & 15) || (d->ldb & 15) || d->lda < d->K || d->ldb < d->K) return VMVM_EINVAL;
-    if (d->row_scale || d->dropout_p > 0.f || d->row_map || d->accumulate || d->colsum || d->col_scale_n || d->splitk > 1 ||
-        (d->act != 0 && d->act != 1 && d->act != 2)) return VMVM_ENOSUPPORT;
+    if (d->accumulate || d->colsum || d->splitk > 1 || (d->row_scale && d->rows_per_scale <= 0)) return VMVM_ENOSUPPORT;
     if ((size_t)d->M * d->lda >= 0x7fffffffull || (size_t)d->N * d->ldb >= 0x7fffffffull) return VMVM_ENOSUPPORT;
     vmvm_gemm_desc d8 = *d;
-    d8.K = d->K / 2; d8.lda = d->lda / 2; d8.ldb = d->ldb / 2;      // the kernel counts 2-byte units
+    d8.K = d->K / 2; d8.lda = d->lda / 2; d8.ldb = d->ldb / 2;      // the kernels count 2-byte units
     d8.splitk = 1;
+    // long reductions on the 256x256 ping-pong main loop (v_mfma_scale_f32_32x32x64_f8f6f4): its epilogue classes include the row
+    // scale / dropout / q-scale forms; measured against the 128x128 fp8 build in tools/gpu_check.py check_gemm_fp8
+    {
+      const int t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+      const bool pays = d->K >= 2048 && d->N >= 512 && t256 >= 128;
+      if (!d->out_fp32 && !d->row_map && d->act != 2 && (d->variant == 7 || (d->variant == 0 && pays))) {
+        const int rc_ = vmvm_gemm_pp_fp8(d8, epi_need(d8), reinterpret_cast<hipStream_t>(stream));
+        if (rc_ != VMVM_ENOSUPPORT) return rc_;
+      }
+    }
+    if (d->row_scale || d->dropout_p > 0.f || d->row_map || d->col_scale_n || (d->act != 0 && d->act != 1 && d->act != 2)) return VMVM_ENOSUPPORT;
     return launch_pers_fp8(d8, reinterpret_cast<hipStream_t>(stream));
   }
   if (d->in_fp16 || d->conv_taps) {

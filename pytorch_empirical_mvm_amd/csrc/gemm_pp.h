@@ -55,9 +55,14 @@ constexpr int pp_smem_bytes(int WM, int BK, int NS) { return NS * (WM * 128 + PP
 //                           1 -> 256 threads, tile 128x256, TWO independent workgroups per CU (each wave still owns 128x64):
 //      one workgroup's epilogue (VALU + the HBM write burst) runs under the other one's main loop.  One barrier per step.
 // DBG (probe builds only): 1 = no epilogue (accumulators kept live), 2 = s_memtime phase timers of block 0 -> p.workspace
-template <bool AK, bool BKM, int F, int WM, int BK, int NS, bool F16 = false, int DBG = 0>
+// FP8: A [M][K] and B [N][K] are OCP e4m3 bytes (k-major); the descriptor reaches the kernel with K / lda / ldb counted in 2-byte
+//      units (as the 128x128 fp8 build), so the DMA ring and the LDS images are byte-for-byte those of the bf16 kernel: a 64-"element"
+//      stage row holds 128 fp8.  A 16-MFMA sub-step becomes 8 x v_mfma_scale_f32_32x32x64_f8f6f4 (same 512 matrix-pipe cycles, twice
+//      the K): a lane's operand is the 32 consecutive K bytes = two adjacent 16-byte chunks of its row.  C = epilogue(alpha * acc).
+template <bool AK, bool BKM, int F, int WM, int BK, int NS, bool F16 = false, int DBG = 0, bool FP8 = false>
 __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_desc p) {
   static_assert(AK == BKM, "both operands k-major (forward / dgrad) or both m/n-major (weight gradient dW = dY^T X)");
+  static_assert(!FP8 || (AK && !F16), "fp8 operands: k-major x k-major");
   constexpr bool TR = !AK;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(WM == 1 || WM == 2, "WM");
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
   for (int kk = 0; kk < SUB; ++kk)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = kk * 4 + ks * 2 + hh;
+      const int c = FP8 ? kk * 4 + hh * 2 + ks : kk * 4 + ks * 2 + hh;      // fp8: (ks = 0, 1) = low / high 16 bytes of the lane's 32 K bytes
       aoff[kk][ks] = rowA * ROWB + ((c ^ pp_fsw<BK>(rowA)) << 4);
       boff[kk][ks] = OPA + rowB * ROWB + ((c ^ pp_fsw<BK>(rowB)) << 4);
     }
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
     // accumulators start at the bias (times the DropPath row scale in the 'producer' form): the epilogue then carries neither the
     // 32 bias registers nor the adds
     f32x16 acc[4][2];
+    const float inv_alpha = FP8 ? 1.0f / p.alpha : 1.0f;          // fp8: the epilogue multiplies by alpha, the folded bias is pre-divided
     {
       float bz[4][8];
 #pragma clang loop unroll(full)
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
 #pragma clang loop unroll(full)
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[mb][q >> 1][(q & 1) * 8 + e] = bz[q][e] * bs;
+          for (int e = 0; e < 8; ++e) acc[mb][q >> 1][(q & 1) * 8 + e] = FP8 ? bz[q][e] * bs * inv_alpha : bz[q][e] * bs;
       }
     }
 
@@ -346,13 +352,29 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           }
         }
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8) {
+          typedef __attribute__((ext_vector_type(8))) int i32x8;
+          typedef __attribute__((ext_vector_type(4))) int i32x4;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+          for (int mb = 0; mb < 4; ++mb) {
+            const i32x4 alo_ = __builtin_bit_cast(i32x4, fa[0][mb]), ahi_ = __builtin_bit_cast(i32x4, fa[1][mb]);
+            const i32x8 a8 = {alo_[0], alo_[1], alo_[2], alo_[3], ahi_[0], ahi_[1], ahi_[2], ahi_[3]};
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb)
+            for (int nb_ = 0; nb_ < 2; ++nb_) {
+              const i32x4 blo_ = __builtin_bit_cast(i32x4, fb[0][nb_]), bhi_ = __builtin_bit_cast(i32x4, fb[1][nb_]);
+              const i32x8 b8 = {blo_[0], blo_[1], blo_[2], blo_[3], bhi_[0], bhi_[1], bhi_[2], bhi_[3]};
+              acc[mb][nb_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[mb][nb_], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+          }
+        } else {
 #pragma unroll
-            for (int nb_ = 0; nb_ < 2; ++nb_)
-              acc[mb][nb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][nb_], fa[ks][mb], acc[mb][nb_], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+              for (int nb_ = 0; nb_ < 2; ++nb_)
+                acc[mb][nb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][nb_], fa[ks][mb], acc[mb][nb_], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         if (WM == 2) __builtin_amdgcn_sched_barrier(0);
       }
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           const int n = n0 + wc * 64 + q * 16 + hh * 8;
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[mb][q >> 1][(q & 1) * 8 + e];
+          for (int e = 0; e < 8; ++e) v[e] = FP8 ? acc[mb][q >> 1][(q & 1) * 8 + e] * p.alpha : acc[mb][q >> 1][(q & 1) * 8 + e];
           o[q] = make_uint4(0, 0, 0, 0); pr[q] = make_uint4(0, 0, 0, 0);
           if (rvalid[mb] && n < N) epi_math8<(F & ~EF_BIAS), F16>(p, ec, v, m, n, rrs[mb], bz0, auxv[q], resv[q], o[q], pr[q]);
         }
@@ -508,7 +530,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           const int n = n0 + wc * 64 + q * 16 + hh * 8;
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[mb][q >> 1][(q & 1) * 8 + e];
+          for (int e = 0; e < 8; ++e) v[e] = FP8 ? acc[mb][q >> 1][(q & 1) * 8 + e] * p.alpha : acc[mb][q >> 1][(q & 1) * 8 + e];
           if (rvalid[mb] && n < N) epi_store8<(F & ~EF_BIAS), F16>(p, ec, v, m, rdst[mb], n, rrs[mb], N - n, bz0, auxv[q], resv[q]);
         }
       }
@@ -525,20 +547,20 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // phantom requests of the ring's tail
 }
 
-template <bool AK, bool BKM, int F, int WM, int BK, int NS, int DBG = 0>
+template <bool AK, bool BKM, int F, int WM, int BK, int NS, int DBG = 0, bool FP8 = false>
 int launch_pp_f(const vmvm_gemm_desc& d, hipStream_t st) {
   constexpr int smem = pp_smem_bytes(WM, BK, NS);
   static_assert(smem <= (WM == 2 ? 160 : 80) * 1024, "LDS budget");
   const int items = ((d.M + WM * 128 - 1) / (WM * 128)) * ((d.N + PP_T - 1) / PP_T) * (d.splitk > 1 ? d.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
   int grid = 512 / WM;                                  // one (WM = 2) or two workgroups per CU, multiple of 8
   if (items < grid) grid = ((items + 7) / 8) * 8;
   if (DBG & 8) grid = 64;                               // probe: a quarter of the CUs (is the store tail a per-CU or a chip-wide limit?)
-  hipLaunchKernelGGL((gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG>), dim3(grid), dim3(WM * 256), smem, st, d);
+  hipLaunchKernelGGL((gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG, FP8>), dim3(grid), dim3(WM * 256), smem, st, d);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -12,6 +12,9 @@ int launch_nt(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<true
 template <int F>
 int launch_tn(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<false, false, F, 2, 64, 2>(d, st); }
 
+template <int F>
+int launch_nt_fp8(const vmvm_gemm_desc& d, hipStream_t st) { return launch_pp_f<true, true, F, 2, 64, 2, 0, true>(d, st); }
+
 }  // namespace
 
 // need = epilogue feature mask of the descriptor (epi_need in gemm.hip).  Returns VMVM_ENOSUPPORT when no instantiation covers it.
@@ -27,6 +30,18 @@ int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st) {
   TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS);
   TRY_EPI(EF_ACT3 | EF_RS);
   TRY_EPI(EF_BIAS | EF_RESID | EF_RS);
+  TRY_EPI(EF_BIAS | EF_RESID | EF_DROP);
+#undef TRY_EPI
+  return VMVM_ENOSUPPORT;
+}
+
+// fp8 (e4m3) operands on the same kernel (vmvm_gemm_desc.in_fp8; K / lda / ldb already in 2-byte units): the forward epilogue classes
+int vmvm_gemm_pp_fp8(const vmvm_gemm_desc& d, int need, hipStream_t st) {
+  if (!(d.a_kmajor && d.b_kmajor)) return VMVM_ENOSUPPORT;
+#define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_nt_fp8<(MASK)>(d, st)
+  TRY_EPI(0);
+  TRY_EPI(EF_BIAS | EF_COLSCALE | EF_RS);
+  TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS);
   TRY_EPI(EF_BIAS | EF_RESID | EF_DROP);
 #undef TRY_EPI
   return VMVM_ENOSUPPORT;

@@ -659,6 +659,43 @@ def check_gemm_fp8():
         err = (out.float() - ref0).norm() / ref0.norm()
         print(f"     end-to-end relative error of the fp8 path vs the unquantised product: {float(err):.3e}")
         rep(f"fp8 gemm {M}x{N}x{Kd} quantisation error (Frobenius, <= 4e-2)", (out.float() - ref0).norm().view(1) / ref0.norm(), torch.zeros(1, device=dev) + 1e-9, tol=4e7)
+    # the 256x256 ping-pong main loop on fp8 operands (variant 7 forces it): plain, bias + q-scale + row scale, bias + GELU + saved
+    # pre-activation, bias + residual + dropout(p = 0 here: exact), ragged M
+    for (M, N, Kd) in [(1024, 512, 256), (3000, 768, 1024), (4096, 3072, 768)]:
+        A = rnd(M, Kd, scale=1.0)
+        W = rnd(N, Kd, scale=0.02)
+        bias = torch.randn(N, device=dev) * 0.1
+        res = rnd(M, N, scale=0.5)
+        rs = torch.rand((M + 255) // 256, device=dev) + 0.5
+        sa, sw = 16.0, 2048.0
+        A8, W8 = K.cast_fp8(A, sa), K.cast_fp8(W, sw)
+        Aq, Wq = A8.view(f8).float() / sa, W8.view(f8).float() / sw
+        z = Aq @ Wq.t()
+        al = 1.0 / (sa * sw)
+        rep(f"fp8 pp {M}x{N}x{Kd} plain", K.gemm(A8, W8, fp8=True, alpha=al, variant=7), z, tol=1e-2)
+        zq = z + bias
+        zq[:, :N // 2] *= 0.125
+        rep(f"fp8 pp {M}x{N}x{Kd} bias+colscale+rowscale", K.gemm(A8, W8, bias=bias, col_scale=0.125, col_scale_n=N // 2, row_scale=rs, rows_per_scale=256, fp8=True, alpha=al, variant=7),
+            zq * rs.repeat_interleave(256)[:M, None], tol=1e-2)
+        pre = torch.empty((M, N), device=dev, dtype=BF)
+        rep(f"fp8 pp {M}x{N}x{Kd} bias+gelu", K.gemm(A8, W8, bias=bias, act=1, out_preact=pre, fp8=True, alpha=al, variant=7), torch.nn.functional.gelu(z + bias), tol=1e-2)
+        rep(f"fp8 pp {M}x{N}x{Kd} saved pre-activation", pre, z + bias, tol=1e-2)
+        rep(f"fp8 pp {M}x{N}x{Kd} bias+resid", K.gemm(A8, W8, bias=bias, resid=res, fp8=True, alpha=al, variant=7), z + bias + res.float(), tol=1e-2)
+    for (M, N, Kk) in [(55296, 768, 3072), (36864, 1536, 6144)]:
+        A = rnd(M, Kk, scale=1.0); W = rnd(N, Kk, scale=0.02)
+        A8, W8 = K.cast_fp8(A, 16.0), K.cast_fp8(W, 2048.0)
+        bias = torch.randn(N, device=dev) * 0.1
+        res = rnd(M, N, scale=0.5)
+        for name, fn in (("bf16 bias+resid", lambda: K.gemm(A, W, bias=bias, resid=res)), ("fp8 128^2 bias+resid", lambda: K.gemm(A8, W8, bias=bias, resid=res, fp8=True, alpha=1.0 / 32768.0, variant=6)),
+                         ("fp8 ping-pong bias+resid", lambda: K.gemm(A8, W8, bias=bias, resid=res, fp8=True, alpha=1.0 / 32768.0, variant=7))):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"     {name:26s} {M}x{N}x{Kk}: {ms:.3f} ms  {2.0 * M * N * Kk / ms / 1e9:.0f} TFLOP/s")
     M, N, Kk = 69120, 3072, 768
     A = rnd(M, Kk, scale=1.0); W = rnd(N, Kk, scale=0.02)
     A8, W8 = K.cast_fp8(A, 16.0), K.cast_fp8(W, 2048.0)
