@@ -279,7 +279,10 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           __builtin_amdgcn_sched_barrier(0);
         }
         tick(1);
+        typedef __attribute__((ext_vector_type(8))) int i32x8_;
+        typedef __attribute__((ext_vector_type(4))) int i32x4_;
         bf16x8 fa[2][4], fb[2][2];
+        i32x8_ fa8[4], fb8[2];
         s16x4 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
         if (TR) {
           const uint32_t sbase = pp_lds_addr(sb);
@@ -301,6 +304,18 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
           if (kk == 0) { PP_TR_SET(0, 0); PP_TR_SET(0, 1); }
           else { PP_TR_SET(1, 0); PP_TR_SET(1, 1); }
 #undef PP_TR_SET
+        } else if constexpr (FP8) {
+          // a lane's 32 K bytes = two 16-byte chunks, loaded straight into the halves of the 8-register MFMA operand
+#pragma unroll
+          for (int nb_ = 0; nb_ < 2; ++nb_) {
+            const i32x4_ lo = *reinterpret_cast<const i32x4_*>(sb + boff[kk][0] + nb_ * 32 * ROWB), hi = *reinterpret_cast<const i32x4_*>(sb + boff[kk][1] + nb_ * 32 * ROWB);
+            fb8[nb_] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            const i32x4_ lo = *reinterpret_cast<const i32x4_*>(sb + aoff[kk][0] + mb * 32 * ROWB), hi = *reinterpret_cast<const i32x4_*>(sb + aoff[kk][1] + mb * 32 * ROWB);
+            fa8[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
         } else {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
@@ -353,19 +368,11 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
         }
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
-          typedef __attribute__((ext_vector_type(8))) int i32x8;
-          typedef __attribute__((ext_vector_type(4))) int i32x4;
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            const i32x4 alo_ = __builtin_bit_cast(i32x4, fa[0][mb]), ahi_ = __builtin_bit_cast(i32x4, fa[1][mb]);
-            const i32x8 a8 = {alo_[0], alo_[1], alo_[2], alo_[3], ahi_[0], ahi_[1], ahi_[2], ahi_[3]};
+          for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int nb_ = 0; nb_ < 2; ++nb_) {
-              const i32x4 blo_ = __builtin_bit_cast(i32x4, fb[0][nb_]), bhi_ = __builtin_bit_cast(i32x4, fb[1][nb_]);
-              const i32x8 b8 = {blo_[0], blo_[1], blo_[2], blo_[3], bhi_[0], bhi_[1], bhi_[2], bhi_[3]};
-              acc[mb][nb_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[mb][nb_], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-            }
-          }
+            for (int nb_ = 0; nb_ < 2; ++nb_)
+              acc[mb][nb_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb8[nb_], fa8[mb], acc[mb][nb_], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         } else {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
