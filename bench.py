@@ -69,7 +69,7 @@ def synth_batch(args, B, device, seed):
 
 class InStepTimers:
     """HIP events (on the launching stream) around the roofline kernels INSIDE a real training step: the fusion FFN fc1 GEMM
-    (bias + GELU + saved pre-activation; M = B*4*432 rows of the VTM pass, N = 3072, K = 768) and the AdamW launches."""
+    (bias + GELU + saved 8-bit GELU' code; M = B*4*432 rows of the VTM pass, N = 3072, K = 768) and the AdamW launches."""
 
     def __init__(self, M):
         self.M, self.gemm, self.adamw = M, [], []
@@ -264,10 +264,10 @@ def main():
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
-                     "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved pre-activation (M={B * O * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
-                               f"gemm_pp_kernel<k-major,k-major,F=bias|GELU|rowscale> 256x256 ping-pong when M*N >= 1024 tiles else gemm_pers_kernel 128x128; "
+                     "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * O * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
+                               f"gemm_pp_kernel<k-major,k-major,F=bias|GELU|rowscale|code8> 256x256 ping-pong when M*N >= 1024 tiles else gemm_pers_kernel 128x128; "
                                f"average of the {kcalls} launches of one real step, HIP events on the launching stream",
-                     "algorithmic_bytes": int((B * O * Lq) * 768 * 2 + 3072 * 768 * 2 + 2 * (B * O * Lq) * 3072 * 2),
+                     "algorithmic_bytes": int((B * O * Lq) * 768 * 2 + 3072 * 768 * 2 + (B * O * Lq) * 3072 * (2 + 1)),      # A + W read, bf16 output + 1-byte codes written
                      # the dominant memory-bound kernel of the step, against HBM: fused clip + AdamW over the flat arena
                      # (f32 p, g, m, v read + p, m, v written + bf16 copy written = 30 B per parameter)
                      "hbm": {"bound": "hbm", "kernel": "adamw_kernel (4 launches over the parameter arena: clip coefficient + AdamW + bf16 copy)",

@@ -87,6 +87,14 @@ typedef struct {
    * pair C[m*ldc + 2q] = max_n (acc + bias)[m, 64q .. 64q+63], C[m*ldc + 2q + 1] = that column's index (int32 bit pattern; ties:
    * the smaller column); ldc >= 2 * N / 64.  vmvm_argmax_pairs() reduces the pairs to token ids (visbackbone/dalle/__init__.py:53). */
   int32_t a_relu;
+  /* aux_code8 = 1 (bf16 builds, k-major x k-major, K % 64 == 0, N % 8 == 0; 128x128 persistent kernel, or the 256x256 ping-pong kernel
+   * when N and the row stride of the code tensor are multiples of 16): the tensor saved
+   * for the GELU backward is an 8-bit code of GELU'(pre-activation) instead of the bf16 pre-activation --
+   *   act = 1: C2 is uint8 [M][ldc2] and receives round((GELU'(v) + 0.13) * 255 / 1.26)   (GELU' lies in [-0.129, 1.129]);
+   *   act = 3: aux is that uint8 tensor [M][ldaux], v *= -0.13 + code * 1.26 / 255.
+   * A quarter of the fc1 forward's stores, half of the fc2-dgrad's operand bytes and its whole erf / exp evaluation go away; the
+   * multiplier is quantised to 0.0025 absolute (the bf16 product it feeds carries 0.4 % relative). */
+  int32_t aux_code8;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 /* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never

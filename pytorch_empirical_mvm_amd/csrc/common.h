@@ -118,6 +118,48 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   const f32x2 h = x * f32x2{0.5f, 0.5f};
   return __builtin_elementwise_fma(h, erf_poly2(x * f32x2{0.70710678118654752f, 0.70710678118654752f}), h);
 }
+// 8-bit code of GELU' (vmvm_gemm_desc.aux_code8): g in [-0.129, 1.129] -> round((g + 0.13) * 255 / 1.26), and back
+constexpr float GC8_LO = -0.13f, GC8_STEP = 1.26f / 255.0f, GC8_INV = 255.0f / 1.26f;
+// GELU and the (unrounded) code of GELU' together.  g = cdf + x * pdf with cdf = 0.5 + 0.5 * erf(z), z = x / sqrt(2), shares the erf
+// polynomial, its clamped argument zc and t = zc^2 with GELU; the affine map onto the code and the constants of the pdf are folded:
+//   code = erf * (INV / 2) + (INV / 2 - LO * INV) + zc * 2^(-t * log2(e) + log2(sqrt(2) * INV / sqrt(2 pi)))
+// (x * pdf(x) < 1e-3 beyond the clamp |z| = 3, so the clamped argument serves).  Cost over GELU alone: 3 packed FMAs + 2 v_exp_f32.
+__device__ __forceinline__ void gelu_and_code2(f32x2 x, f32x2& y, f32x2& cf) {
+  const f32x2 z = x * f32x2{0.70710678118654752f, 0.70710678118654752f};
+  const f32x2 zc = f32x2{__builtin_amdgcn_fmed3f(z[0], -3.0f, 3.0f), __builtin_amdgcn_fmed3f(z[1], -3.0f, 3.0f)};
+  const f32x2 t = zc * zc;
+  f32x2 p = f32x2{-4.0375596e-07f, -4.0375596e-07f};
+  p = __builtin_elementwise_fma(p, t, f32x2{1.7119051e-05f, 1.7119051e-05f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-3.1437373e-04f, -3.1437373e-04f});
+  p = __builtin_elementwise_fma(p, t, f32x2{3.3201380e-03f, 3.3201380e-03f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-2.2705898e-02f, -2.2705898e-02f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.0779675e-01f, 1.0779675e-01f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-3.7335253e-01f, -3.7335253e-01f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.1279515e+00f, 1.1279515e+00f});
+  const f32x2 pz = p * zc;
+  const f32x2 e = f32x2{__builtin_amdgcn_fmed3f(pz[0], -1.0f, 1.0f), __builtin_amdgcn_fmed3f(pz[1], -1.0f, 1.0f)};
+  const f32x2 h = x * f32x2{0.5f, 0.5f};
+  y = __builtin_elementwise_fma(h, e, h);
+  constexpr float L2C = 6.83518164f;                    // log2(sqrt(2) * 0.39894228 * 255 / 1.26)
+  const f32x2 a = __builtin_elementwise_fma(t, f32x2{-1.44269504f, -1.44269504f}, f32x2{L2C, L2C});
+  const f32x2 ex = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  constexpr float HI = 0.5f * GC8_INV, K0 = 0.5f * GC8_INV - GC8_LO * GC8_INV;
+  cf = __builtin_elementwise_fma(zc, ex, __builtin_elementwise_fma(e, f32x2{HI, HI}, f32x2{K0, K0}));
+}
+__device__ __forceinline__ uint32_t gelu_code4(float c0, float c1, float c2, float c3) {      // round + saturate to bytes 0..3
+  uint32_t w = 0;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c0, 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c1, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c2, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c3, 3, w);
+  return w;
+}
+__device__ __forceinline__ void gelu_decode4(uint32_t w, float* g) {
+  g[0] = __builtin_fmaf((float)((w >> 0) & 0xffu), GC8_STEP, GC8_LO);
+  g[1] = __builtin_fmaf((float)((w >> 8) & 0xffu), GC8_STEP, GC8_LO);
+  g[2] = __builtin_fmaf((float)((w >> 16) & 0xffu), GC8_STEP, GC8_LO);
+  g[3] = __builtin_fmaf((float)((w >> 24) & 0xffu), GC8_STEP, GC8_LO);
+}
 __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
   const f32x2 a = x * x * f32x2{-0.72134752044448170f, -0.72134752044448170f};           // -0.5 * log2(e) * x^2
   const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} * f32x2{0.39894228040143268f, 0.39894228040143268f};

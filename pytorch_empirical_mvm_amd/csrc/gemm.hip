@@ -956,8 +956,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r;
         auxv[i][jb] = make_uint4(0, 0, 0, 0); resv[i][jb] = make_uint4(0, 0, 0, 0);
-        if ((F & (EF_ACT3 | EF_ACT24)) && p.act >= 3 && rvalid[i] && full)
-          auxv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+        if ((F & (EF_ACT3 | EF_ACT24)) && p.act >= 3 && rvalid[i] && full) {
+          if (!F16 && p.aux_code8) {
+            const uint2 c8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.aux) + (size_t)m * p.ldaux + n);
+            auxv[i][jb] = make_uint4(c8.x, c8.y, 0, 0);
+          } else {
+            auxv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+          }
+        }
         if ((F & EF_RESID) && p.resid && rvalid[i] && full)
           resv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)rdst[i] * p.ldr + n);
       }
@@ -1093,6 +1099,12 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
   if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
   if (d->a_relu && !d->in_fp16) return VMVM_ENOSUPPORT;
+  if (d->aux_code8) {                                   // 8-bit GELU' code: an epilogue form of the 128x128 persistent and the 256x256 ping-pong kernels
+    if (d->in_fp8 || d->in_fp16 || d->conv_taps || d->out_fp32 || !d->a_kmajor || !d->b_kmajor || (d->variant != 0 && d->variant != 6 && d->variant != 7)) return VMVM_ENOSUPPORT;
+    if ((d->K % BK) || (d->N & 7) || (d->act != 1 && d->act != 3)) return VMVM_EINVAL;
+    if (d->act == 1 && d->C2 && (d->ldc2 & 7)) return VMVM_EINVAL;
+    if (d->act == 3 && (d->ldaux & 7)) return VMVM_EINVAL;
+  }
   if (d->in_fp8) {
     // fp8 (OCP e4m3) operands: k-major both, whole 128-element K tiles, epilogue features within EF_FP8
     if (!d->a_kmajor || !d->b_kmajor || d->in_fp16 || d->conv_taps) return VMVM_ENOSUPPORT;
@@ -1245,6 +1257,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
       if (dd.variant == 7) return rc_;
     }
   }
+  if (dd.aux_code8 && !pers) return VMVM_ENOSUPPORT;      // operands beyond the 32-bit DMA offsets
   if (pers) {
     if (d->a_kmajor && d->b_kmajor) return launch_pers<true, true>(*d, st);
     if (d->a_kmajor && !d->b_kmajor) return launch_pers<true, false>(*d, st);

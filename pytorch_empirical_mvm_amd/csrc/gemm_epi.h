@@ -98,7 +98,8 @@ __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx&
 enum : int { EF_BIAS = 1, EF_COLSCALE = 2, EF_ACT1 = 4, EF_ACT24 = 8, EF_ACT3 = 16, EF_RS = 32, EF_DROP = 64, EF_RESID = 128,
              EF_SPLIT = 256, EF_F32 = 512, EF_MAP = 1024, EF_EDGE4 = 2048, EF_ALL = 4095,
              EF_COLSUM = 4096 /* fused column sum of the m-major A operand (not part of EF_ALL: only the wgrad build carries it) */,
-             EF_ARGMAX = 8192 /* act 5: (row maximum, column) pairs per 64-column group instead of the outputs (dVAE tokenizer's last conv) */ };
+             EF_ARGMAX = 8192 /* act 5: (row maximum, column) pairs per 64-column group instead of the outputs (dVAE tokenizer's last conv) */,
+             EF_CODE8 = 16384 /* gemm_pp.h builds of aux_code8 (8-bit GELU' codes move through 64-byte LDS rows); the 128x128 kernels test the descriptor */ };
 template <int F, bool F16 = false>
 __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[8], int m, long dst, int n, float rs, int nvalid,
                                            const float (&bz)[8], const uint4& auxv, const uint4& resv) {
@@ -119,17 +120,36 @@ __device__ __forceinline__ void epi_store8(const vmvm_gemm_desc& p, const EpiCtx
     for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
   }
   if ((F & EF_ACT1) && p.act == 1) {
-    if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack8<F16>(v);
+    if (!F16 && p.C2 && p.aux_code8) {                      // saved for the backward: an 8-bit code of GELU'(v) instead of v
+      float gq[8];
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 y, g;
+        gelu_and_code2(f32x2{v[e], v[e + 1]}, y, g);
+        v[e] = y[0]; v[e + 1] = y[1]; gq[e] = g[0]; gq[e + 1] = g[1];
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)m * p.ldc2 + n) =
+          make_uint2(gelu_code4(gq[0], gq[1], gq[2], gq[3]), gelu_code4(gq[4], gq[5], gq[6], gq[7]));
+    } else {
+      if (p.C2) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)m * p.ldc2 + n) = pack8<F16>(v);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+    }
   } else if ((F & EF_ACT24) && p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   } else if ((F & EF_ACT3) && p.act == 3) {
-    float u[8];
-    unpack8<F16>(auxv, u);
+    if (!F16 && p.aux_code8) {                              // auxv.x / .y: the eight codes of this fragment
+      float gq[8];
+      gelu_decode4(auxv.x, gq); gelu_decode4(auxv.y, gq + 4);
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+      for (int e = 0; e < 8; ++e) v[e] *= gq[e];
+    } else {
+      float u[8];
+      unpack8<F16>(auxv, u);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+    }
   } else if ((F & EF_ACT24) && p.act == 4) {
     float u[8];
     unpack8<F16>(auxv, u);
@@ -197,17 +217,35 @@ __device__ __forceinline__ void epi_math8(const vmvm_gemm_desc& p, const EpiCtx&
     for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
   }
   if ((F & EF_ACT1) && p.act == 1) {
-    pre = pack8<F16>(v);
+    if constexpr ((F & EF_CODE8) != 0) {                   // pre.x / .y: the eight GELU' codes of this fragment
+      float gq[8];
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 y, g;
+        gelu_and_code2(f32x2{v[e], v[e + 1]}, y, g);
+        v[e] = y[0]; v[e + 1] = y[1]; gq[e] = g[0]; gq[e + 1] = g[1];
+      }
+      pre = make_uint4(gelu_code4(gq[0], gq[1], gq[2], gq[3]), gelu_code4(gq[4], gq[5], gq[6], gq[7]), 0, 0);
+    } else {
+      pre = pack8<F16>(v);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) { const f32x2 y = gelu2(f32x2{v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+    }
   } else if ((F & EF_ACT24) && p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   } else if ((F & EF_ACT3) && p.act == 3) {
-    float u[8];
-    unpack8<F16>(auxv, u);
+    if constexpr ((F & EF_CODE8) != 0) {
+      float gq[8];
+      gelu_decode4(auxv.x, gq); gelu_decode4(auxv.y, gq + 4);
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+      for (int e = 0; e < 8; ++e) v[e] *= gq[e];
+    } else {
+      float u[8];
+      unpack8<F16>(auxv, u);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) { const f32x2 gg = gelu_grad2(f32x2{u[e], u[e + 1]}); v[e] *= gg[0]; v[e + 1] *= gg[1]; }
+    }
   } else if ((F & EF_ACT24) && p.act == 4) {
     float u[8];
     unpack8<F16>(auxv, u);

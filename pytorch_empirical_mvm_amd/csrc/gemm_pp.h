@@ -436,9 +436,25 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
     constexpr bool TL = TS && (HAS_AUX != HAS_RES) && (F & (EF_MAP | EF_DROP)) == 0;      // (dropout: no registers left for it)
     const bool use_aux = HAS_AUX && p.act >= 3, use_res = HAS_RES && p.resid != nullptr;
     constexpr int XB = HAS_AUX ? 2 : 1;          // row blocks of requests in flight (register budget: the residual classes also hold the bias)
+    // 8-bit GELU' codes (EF_CODE8): a row block of the wave's tile is 32 rows x 64 BYTES; global side = lane (row c8r + 16 * s2, 16-byte
+    // group c8g), MFMA side = 8 bytes per (row l31, chunk 2q + hh); the 8-byte chunk index is XORed with an even row code so a 16-byte
+    // group stays whole and the 8-byte reads of rows l31 and l31 + 16 are the only ones that share banks (512 bytes = two passes anyway)
+    constexpr bool C8 = (F & EF_CODE8) != 0;
+    const int c8r = lane >> 2, c8g = lane & 3;
+    auto c8swz = [](int row) { return ((row >> 2) & 3) << 1; };
     uint4 xin[XB][4];
     auto request_block = [&](int mb, uint4 (&x)[4]) {
       const int n_s = n0 + wc * 64 + sg * 8;
+      if constexpr (C8) {
+#pragma clang loop unroll(full)
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int ms = m0 + wr * 128 + mb * 32 + s2 * 16 + c8r, n_c = n0 + wc * 64 + c8g * 16;
+          x[s2] = make_uint4(0, 0, 0, 0);
+          if (ms < M && n_c + 16 <= N && use_aux)
+            x[s2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.aux) + (size_t)ms * p.ldaux + n_c);
+        }
+        return;
+      }
 #pragma clang loop unroll(full)
       for (int s4 = 0; s4 < 4; ++s4) {
         const int ms = m0 + wr * 128 + mb * 32 + s4 * 8 + sr;
@@ -468,7 +484,21 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
 #pragma clang loop unroll(full)
       for (int q = 0; q < 4; ++q) { auxv[q] = make_uint4(0, 0, 0, 0); resv[q] = make_uint4(0, 0, 0, 0); }
       if constexpr (TL) {
-        if (use_aux || use_res) {
+        if constexpr (C8) {
+          if (use_aux) {
+#pragma clang loop unroll(full)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int row = s2 * 16 + c8r;
+              *reinterpret_cast<uint4*>(stg + row * 64 + (((c8g * 2) ^ c8swz(row)) << 3)) = xin[mb % XB][s2];
+            }
+            if (mb + XB < 4) request_block(mb + XB, xin[mb % XB]);
+#pragma clang loop unroll(full)
+            for (int q = 0; q < 4; ++q) {
+              const uint2 t = *reinterpret_cast<const uint2*>(stg + l31 * 64 + (((2 * q + hh) ^ c8swz(l31)) << 3));
+              auxv[q] = make_uint4(t.x, t.y, 0, 0);
+            }
+          }
+        } else if (use_aux || use_res) {
 #pragma clang loop unroll(full)
           for (int s4 = 0; s4 < 4; ++s4) *reinterpret_cast<uint4*>(stg + (s4 * 8 + sr) * 128 + ((sg ^ sr) << 4)) = xin[mb % XB][s4];
           if (mb + XB < 4) request_block(mb + XB, xin[mb % XB]);
@@ -518,6 +548,24 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
 #pragma clang loop unroll(full)
         for (int pass = 0; pass < 2; ++pass) {
           if (pass == 1 && !has_pre) break;
+          if (C8 && pass == 1) {                        // the codes: 64-byte rows, 16 rows per store instruction
+#pragma clang loop unroll(full)
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<uint2*>(stg + l31 * 64 + (((2 * q + hh) ^ c8swz(l31)) << 3)) = make_uint2(pr[q].x, pr[q].y);
+            uint4 t2[2];
+#pragma clang loop unroll(full)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int row = s2 * 16 + c8r;
+              t2[s2] = *reinterpret_cast<const uint4*>(stg + row * 64 + (((c8g * 2) ^ c8swz(row)) << 3));
+            }
+#pragma clang loop unroll(full)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int ms = m0 + wr * 128 + mb * 32 + s2 * 16 + c8r, n_c = n0 + wc * 64 + c8g * 16;
+              if (ms < M && n_c + 16 <= N)
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)ms * p.ldc2 + n_c) = t2[s2];
+            }
+            break;
+          }
 #pragma clang loop unroll(full)
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<uint4*>(stg + l31 * 128 + (((2 * q + hh) ^ (l31 & 7)) << 4)) = pass ? pr[q] : o[q];

@@ -25,6 +25,12 @@ int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st) {
   }
   if (!(d.a_kmajor && d.b_kmajor)) return VMVM_ENOSUPPORT;
 #define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_nt<(MASK)>(d, st)
+  if (d.aux_code8) {                                    // 8-bit GELU' codes: the forward-with-code and the decode-and-multiply classes
+    if ((d.N & 15) || (d.act == 1 && (d.ldc2 & 15)) || (d.act == 3 && (d.ldaux & 15))) return VMVM_ENOSUPPORT;
+    if (d.act == 1 && d.C2) TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS | EF_CODE8);
+    if (d.act == 3) TRY_EPI(EF_ACT3 | EF_RS | EF_CODE8);
+    return VMVM_ENOSUPPORT;
+  }
   TRY_EPI(0);
   TRY_EPI(EF_BIAS | EF_COLSCALE | EF_RS);
   TRY_EPI(EF_BIAS | EF_ACT1 | EF_RS);

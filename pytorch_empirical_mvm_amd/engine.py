@@ -9,6 +9,7 @@ Reference call stack reproduced: VIOLET_Pretrain.forward
 EncVideo.forward (model.py:32-78) -> SwinTransformer3D.forward (video_swin.py:470-482) ; EncTxt (model.py:106-115) ;
 go_cross x2 (model.py:204-214) ; heads + losses (main_pretrain.py:374-432, 555-567)."""
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -222,6 +223,7 @@ class VioletEngine:
         # BASELINE config 5 ("fp8 MFMA path"): forward GEMMs of the fusion encoder's qkv and FFN-in projections on e4m3 operands
         # (per-tensor static scales, v_mfma_scale_f32_16x16x128_f8f6f4); backward stays bf16 on the bf16 activations
         self.fp8 = bool(cfg.get("fp8_forward", False)) and self.device.type == "cuda"
+        self.gelu_code8 = bool(cfg.get("gelu_code8", os.environ.get("VMVM_GELU_CODE8", "1") != "0"))         # Swin MLPs keep GELU' as an 8-bit code
         self.A8_SCALE = 16.0
         if self.fp8:
             self.store.enable_fp8()
@@ -313,8 +315,11 @@ class VioletEngine:
                     scale_bias_only=True, resid=x, row_map=src, map_len=Lp, map_stride=L, out_rows=B * L)
         g2, b2 = S.p(pre + "norm2.weight"), S.p(pre + "norm2.bias")
         y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5)
-        u = torch.empty((B * L, 4 * C), device=dev, dtype=BF16)
-        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp, rows_per_scale=L)
+        # saved for the GELU backward: an 8-bit code of GELU'(fc1 output) (vmvm_gemm_desc.aux_code8) where the persistent kernel's
+        # whole-K-tile staging applies, the bf16 pre-activation otherwise
+        c8 = getattr(self, "gelu_code8", True) and C % 64 == 0 and not S.frozen
+        u = None if S.frozen else torch.empty((B * L, 4 * C), device=dev, dtype=torch.uint8 if c8 else BF16)      # frozen teacher: no backward, nothing saved
+        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp, rows_per_scale=L, code8=c8)
         x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dp, rows_per_scale=L,
                     scale_bias_only=True, resid=x1)
         out = V(x2)
@@ -322,7 +327,7 @@ class VioletEngine:
         def bwd():
             dx2 = out.g
             du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dp, rows_per_scale=L,
-                                  dx_kw=dict(act=3, aux=u, row_scale=dp, rows_per_scale=L))
+                                  dx_kw=dict(act=3, aux=u, row_scale=dp, rows_per_scale=L, code8=c8))
             dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
             dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
             dx1w = K.gather_rows(dx1, src, B * Lp, Lp, L)
@@ -470,12 +475,13 @@ class VioletEngine:
                    dropout_p=p_h, seed=self.seed, offset=o1)
         g1, b1 = S.p(pre + "attention.output.LayerNorm.weight"), S.p(pre + "attention.output.LayerNorm.bias")
         x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
-        u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=BF16)
+        c8 = self.gelu_code8 and not self.fp8                    # GELU' saved as an 8-bit code (as in the Swin MLPs)
+        u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=torch.uint8 if c8 else BF16)
         if self.fp8:
             h = K.gemm(K.cast_fp8(x1, self.A8_SCALE), S.b8(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"),
                        act=1, out_preact=u, fp8=True, alpha=a8)
         else:
-            h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u)
+            h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u, code8=c8)
         o2 = self._next_offset(M * Hd)
         f = K.gemm(h, S.b(pre + "output.dense.weight"), bias=S.p(pre + "output.dense.bias"), resid=x1, dropout_p=p_h, seed=self.seed, offset=o2)
         g2, b2 = S.p(pre + "output.LayerNorm.weight"), S.p(pre + "output.LayerNorm.bias")
@@ -486,7 +492,7 @@ class VioletEngine:
             df, dfm = K.layernorm_bwd(out.g, f, g2, mean2, rstd2, S.g(pre + "output.LayerNorm.weight"), S.g(pre + "output.LayerNorm.bias"),
                                       want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o2)
             dfm = df if dfm is None else dfm
-            du = self._linear_bwd(dfm, h, pre + "output.dense.weight", pre + "output.dense.bias", dx_kw=dict(act=3, aux=u))
+            du = self._linear_bwd(dfm, h, pre + "output.dense.weight", pre + "output.dense.bias", dx_kw=dict(act=3, aux=u, code8=c8))
             dx1 = self._linear_bwd(du, x1, pre + "intermediate.dense.weight", pre + "intermediate.dense.bias", dx_kw=dict(resid=df))
             da, dam = K.layernorm_bwd(dx1, a, g1, mean1, rstd1, S.g(pre + "attention.output.LayerNorm.weight"),
                                       S.g(pre + "attention.output.LayerNorm.bias"), want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o1)

@@ -27,7 +27,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0, a_relu=False):
+         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0, a_relu=False, code8=False):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -65,6 +65,12 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.conv_taps, d.conv_h, d.conv_w = conv if conv is not None else (0, 0, 0)
     d.in_fp8, d.alpha = int(fp8), float(alpha)
     d.a_relu = int(a_relu)
+    d.aux_code8 = int(code8)
+    if code8:
+        t = aux if act == 3 else out_preact
+        assert t is None or t.dtype == torch.uint8, "code8: the saved tensor is uint8"
+    else:
+        assert (aux is None or aux.dtype != torch.uint8) and (out_preact is None or out_preact.dtype != torch.uint8)
     L.check(L.load().vmvm_gemm_bf16(C.byref(d), L.stream()), "gemm")
     return out
 

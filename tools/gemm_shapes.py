@@ -45,7 +45,7 @@ def timed(A, Bm, **kw):
     N = kw.get("N") or (Bm.shape[0] if bk else Bm.shape[1])
     flags = ("T" if ak else "N") + ("T" if bk else "N")
     epi = "+".join(x for x, c in (("bias", kw.get("bias") is not None), ("act%d" % kw.get("act", 0), kw.get("act", 0)), ("aux", kw.get("aux") is not None),
-                                  ("pre", kw.get("out_preact") is not None), ("res", kw.get("resid") is not None), ("map", kw.get("row_map") is not None),
+                                  ("pre", kw.get("out_preact") is not None), ("c8", kw.get("code8", False)), ("res", kw.get("resid") is not None), ("map", kw.get("row_map") is not None),
                                   ("rs", kw.get("row_scale") is not None), ("drop", kw.get("dropout_p", 0) > 0), ("acc", kw.get("accumulate", False)),
                                   ("f32", kw.get("out_dtype", None) == torch.float32 or (kw.get("out") is not None and kw["out"].dtype == torch.float32))) if c)
     s = stats[(M, N, Kd, flags, epi)]

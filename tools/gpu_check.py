@@ -221,6 +221,32 @@ def check_gemm_p3():
     check_gemm_big(5, "p3")
 
 
+def check_code8(variant, M, N, K_, tag):
+    """8-bit GELU' code (vmvm_gemm_desc.aux_code8): forward output unchanged, code within one step of the f32 rounding of GELU'(pre),
+    backward = multiply by the decode; pre-activations spread over +-6 so both saturating ends and the negative lobe of GELU' are hit"""
+    A, B = rnd(M, K_), rnd(N, K_, scale=0.1)
+    base = A.float() @ B.float().t()
+    bias = torch.randn(N, device=dev)
+    Aw, Bw = rnd(M, K_, scale=1.0), rnd(N, K_, scale=2.0 / math.sqrt(K_))
+    basew = Aw.float() @ Bw.float().t()
+    code = torch.full((M, N), 7, device=dev, dtype=torch.uint8)
+    rs8 = torch.rand((M + 195) // 196, device=dev) + 0.5
+    rows8 = torch.arange(M, device=dev) // 196
+    out8 = K.gemm(Aw, Bw, bias=bias, act=1, out_preact=code, code8=True, row_scale=rs8, rows_per_scale=196, variant=variant)
+    rep(f"{tag} {M}x{N}x{K_} gelu (code8 build)", out8, torch.nn.functional.gelu(basew + bias) * rs8[rows8, None])
+    pf = (basew + bias).requires_grad_(True)
+    torch.nn.functional.gelu(pf).sum().backward()
+    want = torch.round((pf.grad + 0.13) * (255.0 / 1.26)).clamp(0, 255)
+    dcode = (code.float() - want).abs()
+    print(f"     code8: max |code - round(g)| = {dcode.max().item():.0f}, off-by-one fraction {(dcode > 0).float().mean().item():.4f}, "
+          f"code range {int(code.min())}..{int(code.max())}")
+    RESULTS.append((f"{tag} code8 codes within 1 of the f32 rounding", dcode.max().item(), 1, dcode.max().item() > 1 or (dcode > 0).float().mean().item() > 0.02))
+    dec = code.float() * (1.26 / 255.0) - 0.13
+    rep(f"{tag} code8 decode vs GELU'", dec, pf.grad, tol=0.0026 / 1.13)
+    rep(f"{tag} act3 code8", K.gemm(A, B, act=3, aux=code, code8=True, row_scale=rs8, rows_per_scale=196, variant=variant), base * dec * rs8[rows8, None])
+    rep(f"{tag} act3 code8 vs exact GELU'", K.gemm(A, B, act=3, aux=code, code8=True, variant=variant), base * pf.grad, tol=1e-2)
+
+
 def check_gemm_epilogues():
     M, N, K_ = 784, 256, 128
     A, B = rnd(M, K_), rnd(N, K_, scale=0.1)
@@ -237,6 +263,9 @@ def check_gemm_epilogues():
     torch.nn.functional.gelu(uf).sum().backward()
     rep("gemm act3 gelu'", K.gemm(A, B, act=3, aux=u), base * uf.grad)
     rep("gemm act4 relu'", K.gemm(A, B, act=4, aux=u), base * (u.float() > 0))
+    check_code8(0, 784, 256, 128, 'pers')
+    check_code8(7, 1000, 560, 256, 'pp')
+    check_code8(7, 4096, 3072, 768, 'pp')
     rs = torch.rand(4, device=dev) + 0.5
     rows = torch.arange(M, device=dev) // 196
     rep("gemm row_scale", K.gemm(A, B, bias=bias, row_scale=rs, rows_per_scale=196), (base + bias) * rs[rows, None])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes (separate --pmc runs, only --kernel-trace beside them) + kernel trace of the roofline kernels of bench.py:
-# the fusion FFN fc1 GEMM (bias + GELU + saved pre-activation, M = 55296, N = 3072, K = 768) and AdamW over a 225 M parameter arena.
+# the fusion FFN fc1 GEMM (bias + GELU + saved 8-bit GELU' code, M = 55296, N = 3072, K = 768) and AdamW over a 225 M parameter arena.
 #   gpurun -- tools/pmc_roofline.sh      -> gpurun_out/r02_pmc_roofline_gemm.txt  (copy to profiles/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_pmc_roofline_gemm.txt; mkdir -p $R/gpurun_out
