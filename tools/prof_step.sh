@@ -9,4 +9,5 @@ mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $DB 80 > $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_shapes.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_shapes.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_gaps.py $DB > $GRAFT_REPO_ROOT/gpurun_out/step_gaps.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_neighbors.py $DB copyBuffer > $GRAFT_REPO_ROOT/gpurun_out/step_copies.txt 2>&1
 head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
