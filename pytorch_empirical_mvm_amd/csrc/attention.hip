@@ -250,6 +250,20 @@ __device__ __forceinline__ uint4 quad_bcast(const uint4& b) {
 __device__ __forceinline__ uint4 quad_bcast_i(const uint4& b, int i) {   // i is a constant after unrolling
   return i == 0 ? quad_bcast<0>(b) : i == 1 ? quad_bcast<1>(b) : i == 2 ? quad_bcast<2>(b) : quad_bcast<3>(b);
 }
+// Forward / dQ layout: quad lane c (= q & 3) needs dword c of the block of every tile of the group, i.e. the 4 x 4 TRANSPOSE of
+// (owner lane, dword) across the quad: y[u] = block of tile t0 + u, dword c  ==  u4_get(quad_bcast<u>(own), q & 3).  Two butterfly
+// stages (lane ^ 1, lane ^ 2), 4 DPP moves + 12 selects per FOUR tiles, instead of 4 DPP moves + a lane-indexed dword select per
+// tile (which the compiler turned into exec-mask branches).  b0 / b1 = bit 0 / bit 1 of the lane index.
+__device__ __forceinline__ uint4 quad_transpose(const uint4& x, bool b0, bool b1) {
+  constexpr int X1 = 1 | (0 << 2) | (3 << 4) | (2 << 6), X2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);       // quad_perm:[1,0,3,2] / [2,3,0,1]
+  const uint32_t s0 = b0 ? x.x : x.y, s1 = b0 ? x.z : x.w;
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)s0, X1, 0xf, 0xf, false), r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)s1, X1, 0xf, 0xf, false);
+  const uint32_t z0 = b0 ? r0 : x.x, z1 = b0 ? x.y : r0, z2 = b0 ? r1 : x.z, z3 = b0 ? x.w : r1;
+  const uint32_t t0 = b1 ? z0 : z2, t1 = b1 ? z1 : z3;
+  const uint32_t q0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t0, X2, 0xf, 0xf, false), q1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, X2, 0xf, 0xf, false);
+  return make_uint4(b1 ? q0 : z0, b1 ? q1 : z1, b1 ? z2 : q0, b1 ? z3 : q1);
+}
+__device__ __forceinline__ uint32_t u4_static(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }      // i constant after unrolling
 
 // ================================================================================================
 // forward
@@ -405,11 +419,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
       uint4 own = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
-        if ((t & 3) == 0 && TILE_ON(t))                   // quad lane i: block of tile t+i  (block id = (sequence-head, q/4, key/4))
-          own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g));
+        if ((t & 3) == 0 && TILE_ON(t))                   // quad lane i: block of tile t+i  (block id = (sequence-head, q/4, key/4)), then transposed
+          own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
         if (TILE_ON(t)) {
-          const uint4 blk = quad_bcast_i(own, t & 3);
-          const uint32_t w = u4_get(blk, q & 3);
+          const uint32_t w = u4_static(own, t & 3);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j];      // the 1/(1-p) keep scale rides on 1/sum below
         }
@@ -563,9 +576,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
           const int key0 = t * 16 + g * 4;
           uint32_t w = 0;
           if (has_drop) {
-            if ((t & 3) == 0) own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g));
-            const uint4 blk = (c & 1) ? (u ? quad_bcast<3>(own) : quad_bcast<2>(own)) : (u ? quad_bcast<1>(own) : quad_bcast<0>(own));
-            w = u4_get(blk, q & 3);
+            if ((t & 3) == 0) own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
+            w = u4_static(own, t & 3);
           }
           if (MODE == 0) {
             const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
         const bf16x8 kf = frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
       }
+      if (NXB) __builtin_amdgcn_sched_barrier(0);       // exact-tile build: straight-line code -- keep the scheduler from hoisting all pairs' LDS reads / Philox blocks (spills)
     }
     if (qv) {
       u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + q) * pb.ld_dqkv + p.q_off + h * HD + g * 4;
@@ -1371,17 +1384,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
                 const f32x2 c2 = f32x2{cdk, cdk};
                 const f32x2 d01 = f32x2{dp4[t][0], dp4[t][1]} * c2, d23 = f32x2{dp4[t][2], dp4[t][3]} * c2;
-                float dp[4] = {d01[0], d01[1], d23[0], d23[1]}, pj[4] = {pr[0], pr[1], pr[2], pr[3]};
+                // dS = P * (mask * dP - delta) = (mask * P) * dP - P * delta: ONE select per element (the masked P, which dV needs anyway)
+                float pj[4] = {pr[0], pr[1], pr[2], pr[3]};
                 if (has_drop) {
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
                     const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
-                    dp[j] = dropped ? 0.f : dp[j];
                     pj[j] = dropped ? 0.f : pj[j];
                   }
                 }
-                const f32x2 o01 = f32x2{pr[0], pr[1]} * (f32x2{dp[0], dp[1]} - f32x2{dls[0], dls[1]});
-                const f32x2 o23 = f32x2{pr[2], pr[3]} * (f32x2{dp[2], dp[3]} - f32x2{dls[2], dls[3]});
+                const f32x2 o01 = __builtin_elementwise_fma(f32x2{pj[0], pj[1]}, d01, -(f32x2{pr[0], pr[1]} * f32x2{dls[0], dls[1]}));
+                const f32x2 o23 = __builtin_elementwise_fma(f32x2{pj[2], pj[3]}, d23, -(f32x2{pr[2], pr[3]} * f32x2{dls[2], dls[3]}));
                 pt[t][u][0] = pj[0]; pt[t][u][1] = pj[1]; pt[t][u][2] = pj[2]; pt[t][u][3] = pj[3];
                 ds[t][u][0] = o01[0]; ds[t][u][1] = o01[1]; ds[t][u][2] = o23[0]; ds[t][u][3] = o23[1];
               } else {
@@ -1814,9 +1827,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
 #pragma unroll
       for (int t = 0; t < NTC; ++t) {
         if ((t & 3) == 0)                           // quad lane i: block of (absolute) tile t+i; chunks are whole groups of four tiles
-          own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g));
-        const uint4 blk = quad_bcast_i(own, t & 3);
-        const uint32_t w = u4_get(blk, q & 3);
+          own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
+        const uint32_t w = u4_static(own, t & 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
       }
@@ -1934,9 +1946,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_
           const int key0 = k0 + t * 16 + g * 4;
           uint32_t w = 0;
           if (has_drop) {
-            if ((t & 3) == 0) own = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g));
-            const uint4 blk = (c & 1) ? (u ? quad_bcast<3>(own) : quad_bcast<2>(own)) : (u ? quad_bcast<1>(own) : quad_bcast<0>(own));
-            w = u4_get(blk, q & 3);
+            if ((t & 3) == 0) own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
+            w = u4_static(own, t & 3);
           }
           if (MODE == 0) {
             const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
