@@ -554,9 +554,35 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
     for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 own = make_uint4(0, 0, 0, 0);               // quad-shared dropout block (see quad_bcast)
+    // score / dP MFMAs of one pair of key tiles
+    auto score_pair = [&](int c, f32x4 (&so)[2], f32x4 (&dpo)[2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * c + u;
+        so[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dpo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (NXB ? (t < NXB) : (t < nt)) {
+          const int row = t * 16 + r;
+#pragma unroll
+          for (int s = 0; s < HD / 32; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
+            so[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], so[u], 0, 0, 0);
+            const bf16x8 vf = frag_hd<HD>(Vsm, row, s * 4 + g);
+            dpo[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dpo[u], 0, 0, 0);
+          }
+        }
+      }
+    };
+    // exact-tile fusion build: software-pipelined by one pair -- the score MFMAs of pair c + 1 are issued in front of the softmax-side
+    // VALU work of pair c (they only depend on LDS reads), so their latency sits under it instead of in front of the next pair
+    constexpr bool PIPE = FAST1 && NXB > 0;
+    f32x4 s4c[2], dpc[2];
+    if (PIPE) score_pair(0, s4c, dpc);
     // NXB > 0: exact tile count -> fully unrolled, immediate LDS offsets, no per-tile guards
 #pragma unroll
     for (int c = 0; c < (NXB ? (NXB + 1) / 2 : nt2); ++c) {
+      f32x4 s4n[2], dpn[2];
+      if (PIPE) { if (c + 1 < (NXB + 1) / 2) score_pair(c + 1, s4n, dpn); }
+      else score_pair(c, s4c, dpc);
       float ds[2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -564,15 +590,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
 #pragma unroll
         for (int j = 0; j < 4; ++j) ds[u][j] = 0.f;
         if (NXB ? (t < NXB) : (t < nt)) {
-          const int row = t * 16 + r;
-          f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < HD / 32; ++s) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
-            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], s4, 0, 0, 0);
-            const bf16x8 vf = frag_hd<HD>(Vsm, row, s * 4 + g);
-            dp4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dp4, 0, 0, 0);
-          }
+          const f32x4 s4 = s4c[u], dp4 = dpc[u];
           const int key0 = t * 16 + g * 4;
           uint32_t w = 0;
           if (has_drop) {
@@ -630,6 +648,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
         const bf16x8 kf = frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
       }
+      if (PIPE) { s4c[0] = s4n[0]; s4c[1] = s4n[1]; dpc[0] = dpn[0]; dpc[1] = dpn[1]; }
       if (NXB) __builtin_amdgcn_sched_barrier(0);       // exact-tile build: straight-line code -- keep the scheduler from hoisting all pairs' LDS reads / Philox blocks (spills)
     }
     if (qv) {
@@ -1321,8 +1340,36 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
     uint4 own[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) own[t] = make_uint4(0, 0, 0, 0);
+    // score / dP MFMAs of one pair of query tiles (software-pipelined by one pair in the exact-tile fusion build, as in the dQ kernel)
+    auto score_pair = [&](int c, f32x4 (&so)[2][KT], f32x4 (&dpo)[2][KT]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * c + u;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) { so[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dpo[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (NXB ? (qt < NXB) : (qt < nt)) {
+          const int qrow = qt * 16 + r;            // A-operand row owned by this lane
+#pragma unroll
+          for (int s = 0; s < HD / 32; ++s) {
+            const bf16x8 qf = frag_hd<HD>(Qsm, qrow, s * 4 + g);
+            const bf16x8 dof = frag_hd<HD>(dOsm, qrow, s * 4 + g);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              so[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[t][s], so[u][t], 0, 0, 0);
+              dpo[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[t][s], dpo[u][t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    constexpr bool PIPE = FAST1 && NXB > 0;
+    f32x4 s4c[2][KT], dpc[2][KT];
+    if (PIPE) score_pair(0, s4c, dpc);
 #pragma unroll
     for (int c = 0; c < (NXB ? (NXB + 1) / 2 : nt2); ++c) {
+      f32x4 s4n[2][KT], dpn[2][KT];
+      if (PIPE) { if (c + 1 < (NXB + 1) / 2) score_pair(c + 1, s4n, dpn); }
+      else score_pair(c, s4c, dpc);
       float pt[KT][2][4], ds[KT][2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -1332,20 +1379,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 #pragma unroll
           for (int j = 0; j < 4; ++j) { pt[t][u][j] = 0.f; ds[t][u][j] = 0.f; }
         if (NXB ? (qt < NXB) : (qt < nt)) {
-          const int qrow = qt * 16 + r;            // A-operand row owned by this lane
           f32x4 s4[KT], dp4[KT];
 #pragma unroll
-          for (int t = 0; t < KT; ++t) { s4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-          for (int s = 0; s < HD / 32; ++s) {
-            const bf16x8 qf = frag_hd<HD>(Qsm, qrow, s * 4 + g);
-            const bf16x8 dof = frag_hd<HD>(dOsm, qrow, s * 4 + g);
-#pragma unroll
-            for (int t = 0; t < KT; ++t) {
-              s4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[t][s], s4[t], 0, 0, 0);
-              dp4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[t][s], dp4[t], 0, 0, 0);
-            }
-          }
+          for (int t = 0; t < KT; ++t) { s4[t] = s4c[u][t]; dp4[t] = dpc[u][t]; }
           // lane now holds (query = qt*16 + 4g + j, key[t])
           const int q0 = qt * 16 + g * 4;
           const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
@@ -1430,7 +1466,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
           dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf[t], dk[t][dt], 0, 0, 0);
         }
       }
-      if (NXB) asm volatile("" ::: "memory");             // exact-tile build: keep the unrolled pairs' LDS reads from being hoisted en bloc
+      if (PIPE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) { s4c[u][t] = s4n[u][t]; dpc[u][t] = dpn[u][t]; }
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (NXB) {
+        asm volatile("" ::: "memory");             // exact-tile build: keep the unrolled pairs' LDS reads from being hoisted en bloc
+      }
     }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {

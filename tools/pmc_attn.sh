@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes over the window-attention kernels (tools/pmc_kernels.py attn; separate --pmc passes, only --kernel-trace beside them)
-# -> gpurun_out/pmc_attn.txt
+# -> gpurun_out/pmc_attn.txt   (PMC_WHICH=bert: the fusion-encoder attention kernels instead)
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/pmc_attn.txt
 run() {
   local n=$1; shift
   rm -rf /tmp/pa_$n
-  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pa_$n -- python3 $R/tools/pmc_kernels.py attn > /tmp/pa_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pa_$n -- python3 $R/tools/pmc_kernels.py ${PMC_WHICH:-attn} > /tmp/pa_$n.log 2>&1
   echo "--- pass $n: $*" >> $OUT
   python3 $R/tools/pmc_summary.py $(find /tmp/pa_$n -name "*.db" | head -1) >> $OUT 2>&1
 }

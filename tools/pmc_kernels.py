@@ -31,4 +31,12 @@ if "attn" in which:
     for _ in range(3):
         out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, **kw)
         K.attention_bwd(rnd(nseq * N, C_), qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, dbias_table=dtab, **kw)
+if "bert" in which:                                               # fusion-encoder attention at the C2 shape (160 sequences x 12 heads x 432, head_dim 64, dropout 0.1)
+    nseq, Lq, heads, Hd = 160, 432, 12, 768
+    qkv = rnd(nseq * Lq, 3 * Hd)
+    km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+    kw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    for _ in range(3):
+        out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, **kw)
+        K.attention_bwd(rnd(nseq * Lq, Hd), qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, **kw)
 torch.cuda.synchronize()
