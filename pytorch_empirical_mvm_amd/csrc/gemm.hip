@@ -793,6 +793,44 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     const bool more = wn_ < x_cnt;
     int nslice = 0, nm0 = 0, nn0 = 0, nkt0 = 0, nnk = 0;
     if (more) { decode(wn_, nslice, nm0, nn0, nkt0, nnk); tile_offsets(nm0, nn0, nvoA, nvoB, npyA, npxA); }
+    // Epilogue operands first: row bookkeeping and the per-element loads of the tile (saved activation / code, residual) go out BEFORE the K
+    // loop -- they only depend on the tile origin, and the first K step's vmcnt(0) (which waits for the operand DMA anyway) covers
+    // their latency; issued after the loop they queued behind the next tile's prefetch and stalled every tile's first store.
+    bool rvalid[4]; long rdst[4]; float rrs[4];
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + r;
+      bool valid = m < M;
+      long dst = m;
+      if ((F & EF_MAP) && valid && p.row_map) {
+        const int mapped = p.row_map[m % p.map_len];
+        valid = mapped >= 0;
+        dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
+      }
+      rvalid[i] = valid; rdst[i] = dst;
+      rrs[i] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    }
+    uint4 auxv[4][2], resv[4][2];
+#pragma clang loop unroll(full)
+    for (int jb = 0; jb < 2; ++jb) {
+      const int n = n0 + wn * 64 + jb * 32 + g * 8;
+      const bool full = n + 8 <= N;
+#pragma clang loop unroll(full)
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        auxv[i][jb] = make_uint4(0, 0, 0, 0); resv[i][jb] = make_uint4(0, 0, 0, 0);
+        if ((F & (EF_ACT3 | EF_ACT24)) && p.act >= 3 && rvalid[i] && full) {
+          if (!F16 && p.aux_code8) {
+            const uint2 c8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.aux) + (size_t)m * p.ldaux + n);
+            auxv[i][jb] = make_uint4(c8.x, c8.y, 0, 0);
+          } else {
+            auxv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
+          }
+        }
+        if ((F & EF_RESID) && p.resid && rvalid[i] && full)
+          resv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)rdst[i] * p.ldr + n);
+      }
+    }
     for (int kt = kt0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
@@ -925,47 +963,17 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         }
       }
     } else {
-    // epilogue in three passes: row bookkeeping, ALL loads of the tile (bias, saved activation, residual), then math + stores
-    bool rvalid[4]; long rdst[4]; float rrs[4];
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + r;
-      bool valid = m < M;
-      long dst = m;
-      if ((F & EF_MAP) && valid && p.row_map) {
-        const int mapped = p.row_map[m % p.map_len];
-        valid = mapped >= 0;
-        dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
-      }
-      rvalid[i] = valid; rdst[i] = dst;
-      rrs[i] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
-    }
+    // epilogue: math + stores (the row bookkeeping and the big loads of the tile were issued in front of the K loop; the bias is a
+    // cached 256-byte read that is not worth 16 registers across the main loop)
     float bz[2][8];
-    uint4 auxv[4][2], resv[4][2];
 #pragma clang loop unroll(full)
     for (int jb = 0; jb < 2; ++jb) {
       const int n = n0 + wn * 64 + jb * 32 + g * 8;
-      const bool full = n + 8 <= N;
 #pragma unroll
       for (int e = 0; e < 8; ++e) bz[jb][e] = 0.f;
-      if ((F & EF_BIAS) && p.bias && full) {
+      if ((F & EF_BIAS) && p.bias && n + 8 <= N) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
         bz[jb][0] = b0.x; bz[jb][1] = b0.y; bz[jb][2] = b0.z; bz[jb][3] = b0.w; bz[jb][4] = b1.x; bz[jb][5] = b1.y; bz[jb][6] = b1.z; bz[jb][7] = b1.w;
-      }
-#pragma clang loop unroll(full)
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r;
-        auxv[i][jb] = make_uint4(0, 0, 0, 0); resv[i][jb] = make_uint4(0, 0, 0, 0);
-        if ((F & (EF_ACT3 | EF_ACT24)) && p.act >= 3 && rvalid[i] && full) {
-          if (!F16 && p.aux_code8) {
-            const uint2 c8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.aux) + (size_t)m * p.ldaux + n);
-            auxv[i][jb] = make_uint4(c8.x, c8.y, 0, 0);
-          } else {
-            auxv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.aux) + (size_t)m * p.ldaux + n);
-          }
-        }
-        if ((F & EF_RESID) && p.resid && rvalid[i] && full)
-          resv[i][jb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.resid) + (size_t)rdst[i] * p.ldr + n);
       }
     }
 #pragma clang loop unroll(full)
