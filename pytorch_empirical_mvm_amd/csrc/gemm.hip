@@ -23,6 +23,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;       // A,B x double buffer = 64 KiB
+constexpr int PERS_SMEM_BYTES = SMEM_BYTES + 4 * 4096;   // + the wave-private store tiles of gemm_pers_kernel: 80 KiB, two workgroups per CU fill the 160 KiB
 
 __device__ __forceinline__ int swz_m(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
@@ -976,6 +977,101 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         bz[jb][0] = b0.x; bz[jb][1] = b0.y; bz[jb][2] = b0.z; bz[jb][3] = b0.w; bz[jb][4] = b1.x; bz[jb][5] = b1.y; bz[jb][6] = b1.z; bz[jb][7] = b1.w;
       }
     }
+    // 16-bit outputs of the bf16 build leave through a wave-private 4 KiB LDS tile (no barrier: the tile sits behind the operand
+    // ring and belongs to one wave): in the MFMA layout a store instruction writes 16 rows x 64 bytes -- 16 half lines, each paid
+    // for on the address path -- re-tiled it writes 8 rows x 128 bytes, whole lines.  Two passes of 32 rows per wave tile.
+    // Measured per class inside a step (tools/probe/ab_shapes.sh, profiles/r02_gemm_pers_retile_ab.txt): the bias / GELU / GELU'
+    // classes gain 5-15 % (two outputs, or epilogue-bound short-K shapes); the plain and the residual classes LOSE 2-10 % (their tiles
+    // are main-loop bound and the LDS round trip only adds latency), so they keep the direct stores.
+    constexpr bool RT = TM == 1 && !F16 && !FP8 &&
+                        (F == (EF_BIAS | EF_COLSCALE | EF_RS) || F == (EF_BIAS | EF_ACT1 | EF_RS) || F == (EF_ACT3 | EF_RS));
+    if constexpr (RT) {
+      unsigned char* stg = smem + 2 * STAGE_BYTES + wave * 4096;
+      const int sr = lane >> 3, sg = lane & 7;             // store layout: row inside an 8-row group, 16-byte column group
+      const bool has_pre = (F & EF_ACT1) && p.act == 1 && p.C2;
+      const bool code8 = (F & (EF_ACT1 | EF_ACT3)) && p.aux_code8 != 0;     // 8-bit GELU' codes in C2 (act 1) / aux (act 3)
+      const bool c8 = has_pre && code8;
+      const int n_s = n0 + wn * 64 + sg * 8;
+#pragma clang loop unroll(full)
+      for (int hb = 0; hb < 2; ++hb) {
+        uint4 o[2][2], pr[2][2];
+#pragma clang loop unroll(full)
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = hb * 2 + ii;
+          const int m = m0 + wm * 64 + i * 16 + r;
+#pragma clang loop unroll(full)
+          for (int jb = 0; jb < 2; ++jb) {
+            const int n = n0 + wn * 64 + jb * 32 + g * 8;
+            float v[8] = {acc[i][2 * jb][0], acc[i][2 * jb][1], acc[i][2 * jb][2], acc[i][2 * jb][3],
+                          acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
+            o[ii][jb] = make_uint4(0, 0, 0, 0); pr[ii][jb] = make_uint4(0, 0, 0, 0);
+            if (rvalid[i] && n < N) {
+              if (code8) epi_math8<(F | EF_CODE8), F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
+              else epi_math8<F, F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
+            }
+          }
+        }
+        // store-side rows of this half: 8 * s4 + sr
+        bool svalid[4]; long sdst[4]; int srow[4];
+#pragma clang loop unroll(full)
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int ms = m0 + wm * 64 + hb * 32 + s4 * 8 + sr;
+          bool valid = ms < M && n_s < N;
+          long dst = ms;
+          if ((F & EF_MAP) && valid && p.row_map) {
+            const int mapped = p.row_map[ms % p.map_len];
+            valid = mapped >= 0;
+            dst = (long)mapped + (long)(ms / p.map_len) * p.map_stride;
+          }
+          svalid[s4] = valid; sdst[s4] = dst; srow[s4] = ms;
+        }
+#pragma clang loop unroll(full)
+        for (int pass = 0; pass < 2; ++pass) {
+          if (pass == 1 && !has_pre) break;
+          if (pass == 1 && c8) {                          // 8-bit GELU' codes: 64-byte rows, 16 rows per store instruction (as in gemm_pp.h)
+            const int c8r = lane >> 2, c8g = lane & 3;
+#pragma clang loop unroll(full)
+            for (int ii = 0; ii < 2; ++ii)
+#pragma clang loop unroll(full)
+              for (int jb = 0; jb < 2; ++jb) {
+                const int row = ii * 16 + r;
+                *reinterpret_cast<uint2*>(stg + row * 64 + (((jb * 4 + g) ^ (((row >> 2) & 3) << 1)) << 3)) = make_uint2(pr[ii][jb].x, pr[ii][jb].y);
+              }
+            uint4 t2[2];
+#pragma clang loop unroll(full)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int row = s2 * 16 + c8r;
+              t2[s2] = *reinterpret_cast<const uint4*>(stg + row * 64 + (((c8g * 2) ^ (((row >> 2) & 3) << 1)) << 3));
+            }
+#pragma clang loop unroll(full)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int ms = m0 + wm * 64 + hb * 32 + s2 * 16 + c8r, n_c = n0 + wn * 64 + c8g * 16;
+              if (ms < M && n_c + 16 <= N)
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)ms * p.ldc2 + n_c) = t2[s2];
+              else if (ms < M && n_c + 8 <= N)
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)ms * p.ldc2 + n_c) = make_uint2(t2[s2].x, t2[s2].y);
+            }
+            break;
+          }
+#pragma clang loop unroll(full)
+          for (int ii = 0; ii < 2; ++ii)
+#pragma clang loop unroll(full)
+            for (int jb = 0; jb < 2; ++jb) {
+              const int row = ii * 16 + r;
+              *reinterpret_cast<uint4*>(stg + row * 128 + (((jb * 4 + g) ^ (row & 7)) << 4)) = pass ? pr[ii][jb] : o[ii][jb];
+            }
+          uint4 t[4];
+#pragma clang loop unroll(full)
+          for (int s4 = 0; s4 < 4; ++s4) t[s4] = *reinterpret_cast<const uint4*>(stg + (s4 * 8 + sr) * 128 + ((sg ^ sr) << 4));
+#pragma clang loop unroll(full)
+          for (int s4 = 0; s4 < 4; ++s4) {
+            if (!svalid[s4]) continue;
+            if (pass == 0) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)sdst[s4] * p.ldc + n_s) = t[s4];
+            else *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)srow[s4] * p.ldc2 + n_s) = t[s4];
+          }
+        }
+      }
+    } else {
 #pragma clang loop unroll(full)
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + i * 16 + r;
@@ -992,6 +1088,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       }
     }
     }
+    }
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
 #pragma unroll
@@ -1006,12 +1103,12 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
   const int items = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * (d.splitk > 1 ? d.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, PERS_SMEM_BYTES);
     attr_done = true;
   }
   int grid = 512;                                       // 2 workgroups per CU (64 KiB LDS each), multiple of 8
   if (items < grid) grid = ((items + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
+  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
     const long n = (long)d.M * (d.N >> 2);
