@@ -8,6 +8,7 @@
 // Backward: a fixed grid of waves walks rows grid-stride, keeps dgamma/dbeta partials in registers,
 // reduces them across the block in LDS and issues one f32 atomic per column per block.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -467,7 +468,12 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
-  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
+  // Workgroups that fit per CU at the variant's VGPR count.  Allocation granule 8: the packed C <= 128 build takes 100 -> 104
+  // registers, FOUR waves per SIMD, not five (the C <= 256 build takes 96: five) -- a fifth workgroup per CU ran as a second round and cost 25 % at C = 128.
+  // (Measured and dropped: one workgroup fewer per CU to trim a mostly-empty last round of rows -- slower in the step wherever the
+  // memory system is not yet saturated; a second row per wave in flight -- costs the wave it was meant to replace.)
+  int per_cu = d->C <= 128 ? 4 : d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
+  if (const char* e = getenv("VMVM_LN_PER_CU")) per_cu = atoi(e);           // probe hook (tools/gpu_check.py benchln)
   int grid = (d->M + 3) / 4;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
   const size_t sm = (size_t)8 * d->C * sizeof(float);   // 4 wave slabs x [2][C]
