@@ -88,7 +88,7 @@ typedef struct {
    * the smaller column); ldc >= 2 * N / 64.  vmvm_argmax_pairs() reduces the pairs to token ids (visbackbone/dalle/__init__.py:53). */
   int32_t a_relu;
   /* aux_code8 = 1 (bf16 builds, k-major x k-major, K % 64 == 0, N % 8 == 0; 128x128 persistent kernel, or the 256x256 ping-pong kernel
-   * when N and the row stride of the code tensor are multiples of 16): the tensor saved
+   * when N and the row stride of the code tensor are multiples of 16; with in_fp8 the act = 1 form on the 128x128 fp8 build): the tensor saved
    * for the GELU backward is an 8-bit code of GELU'(pre-activation) instead of the bf16 pre-activation --
    *   act = 1: C2 is uint8 [M][ldc2] and receives round((GELU'(v) + 0.13) * 255 / 1.26)   (GELU' lies in [-0.129, 1.129]);
    *   act = 3: aux is that uint8 tensor [M][ldaux], v *= -0.13 + code * 1.26 / 255.

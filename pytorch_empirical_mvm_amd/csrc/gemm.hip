@@ -1205,8 +1205,8 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if ((d->N & 3) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VMVM_EINVAL;
   if (d->a_relu && !d->in_fp16) return VMVM_ENOSUPPORT;
   if (d->aux_code8) {                                   // 8-bit GELU' code: an epilogue form of the 128x128 persistent and the 256x256 ping-pong kernels
-    if (d->in_fp8 || d->in_fp16 || d->conv_taps || d->out_fp32 || !d->a_kmajor || !d->b_kmajor || (d->variant != 0 && d->variant != 6 && d->variant != 7)) return VMVM_ENOSUPPORT;
-    if ((d->K % BK) || (d->N & 7) || (d->act != 1 && d->act != 3)) return VMVM_EINVAL;
+    if ((d->in_fp8 && d->act != 1) || d->in_fp16 || d->conv_taps || d->out_fp32 || !d->a_kmajor || !d->b_kmajor || (d->variant != 0 && d->variant != 6 && d->variant != 7)) return VMVM_ENOSUPPORT;
+    if ((d->K % (d->in_fp8 ? 2 * BK : BK)) || (d->N & 7) || (d->act != 1 && d->act != 3)) return VMVM_EINVAL;
     if (d->act == 1 && d->C2 && (d->ldc2 & 7)) return VMVM_EINVAL;
     if (d->act == 3 && (d->ldaux & 7)) return VMVM_EINVAL;
   }

@@ -43,7 +43,7 @@ int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st) {
 
 // fp8 (e4m3) operands on the same kernel (vmvm_gemm_desc.in_fp8; K / lda / ldb already in 2-byte units): the forward epilogue classes
 int vmvm_gemm_pp_fp8(const vmvm_gemm_desc& d, int need, hipStream_t st) {
-  if (!(d.a_kmajor && d.b_kmajor)) return VMVM_ENOSUPPORT;
+  if (!(d.a_kmajor && d.b_kmajor) || d.aux_code8) return VMVM_ENOSUPPORT;       // (8-bit GELU' codes: the 128x128 fp8 build writes them)
 #define TRY_EPI(MASK) if ((need & ~(MASK)) == 0) return launch_nt_fp8<(MASK)>(d, st)
   TRY_EPI(0);
   TRY_EPI(EF_BIAS | EF_COLSCALE | EF_RS);

@@ -475,11 +475,11 @@ class VioletEngine:
                    dropout_p=p_h, seed=self.seed, offset=o1)
         g1, b1 = S.p(pre + "attention.output.LayerNorm.weight"), S.p(pre + "attention.output.LayerNorm.bias")
         x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
-        c8 = self.gelu_code8 and not self.fp8                    # GELU' saved as an 8-bit code (as in the Swin MLPs)
+        c8 = self.gelu_code8                                     # GELU' saved as an 8-bit code (as in the Swin MLPs)
         u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=torch.uint8 if c8 else BF16)
         if self.fp8:
             h = K.gemm(K.cast_fp8(x1, self.A8_SCALE), S.b8(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"),
-                       act=1, out_preact=u, fp8=True, alpha=a8)
+                       act=1, out_preact=u, fp8=True, alpha=a8, code8=c8)
         else:
             h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u, code8=c8)
         o2 = self._next_offset(M * Hd)

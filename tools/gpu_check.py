@@ -683,6 +683,12 @@ def check_gemm_fp8():
         rep(f"fp8 gemm {M}x{N}x{Kd} act={act} vs fp32 on the quantised operands", out, ref, tol=1e-2)
         if act == 1:
             rep(f"fp8 gemm {M}x{N}x{Kd} saved pre-activation", pre, z, tol=1e-2)
+            code = torch.empty((M, N), device=dev, dtype=torch.uint8)          # the same call saving 8-bit GELU' codes instead
+            out_c = K.gemm(A8, W8, bias=bias, act=1, out_preact=code, resid=res, fp8=True, alpha=1.0 / (sa * sw), code8=True)
+            rep(f"fp8 gemm {M}x{N}x{Kd} act=1 (code8 build)", out_c, ref, tol=1e-2)
+            zf = z.clone().requires_grad_(True)
+            torch.nn.functional.gelu(zf).sum().backward()
+            rep(f"fp8 gemm {M}x{N}x{Kd} code8 decode vs GELU'", code.float() * (1.26 / 255.0) - 0.13, zf.grad, tol=0.0045 / 1.13)
         z0 = A.float() @ W.float().t() + bias
         ref0 = (torch.nn.functional.gelu(z0) if act == 1 else (z0.clamp_min(0) if act == 2 else z0)) + res.float()
         err = (out.float() - ref0).norm() / ref0.norm()
