@@ -1763,7 +1763,7 @@ __host__ __device__ inline SmemS smem_stream(int L, int hd, int mode, int table_
 // the softmax needs exp2 only; MASK = false: no region map (un-shifted windows), the compare/select/add per element is compiled out;
 // the key < L guard runs only in the last chunk.
 template <int HD, int MODE, int NW, int KC, bool MASK>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_attn_fwd_desc p, const int nqb) {
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_stream_kernel(const vmvm_attn_fwd_desc p, const int nqb) {
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTC = KC / 16;
@@ -1905,7 +1905,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_stream_kernel(const vmvm_att
 // dQ (+ delta): workgroup (sequence chunk, head, query block) walks its sequences (the per-head table is staged once); K / V
 // stream through LDS in KC-token chunks.  The bias-table gradient has its own kernel (attn_bwd_dbias_stream_kernel).
 template <int HD, int MODE, int NW, int KC, bool MASK>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb) {
+__global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dq_stream_kernel(const vmvm_attn_bwd_desc pb, const int nchunks, const int nqb) {
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -2164,7 +2164,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dbias_stream_kernel(const vm
 
 // dK / dV: workgroup = (sequence, head, block of NW*KT key tiles); Q / dO (+ lse, delta) stream through LDS in KC-query chunks.
 template <int HD, int MODE, int NW, int KC, bool MASK>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_stream_kernel(const vmvm_attn_bwd_desc pb, const int nkb) {
+__global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dkv_stream_kernel(const vmvm_attn_bwd_desc pb, const int nkb) {
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
