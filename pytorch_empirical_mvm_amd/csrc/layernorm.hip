@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
 }
 
 // dgamma[c] += sum_rows ws[row][c], dbeta[c] += sum_rows ws[row][C + c] : 64 columns x 4 row lanes per workgroup, blockIdx.y
-// splits the rows 8 ways (8 atomics per column in total)
+// splits the rows gridDim.y ways (that many atomics per column in total)
 __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* ws, int rows, int C, float* dgamma, float* dbeta) {
   __shared__ float part[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -506,7 +506,8 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   else LAUNCH_LNB(6, false);
   if (dd.workspace) {
     VMVM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * d->C + 63) / 64, 8), dim3(256), 0, st,
+    const int ysplit = grid >= 256 ? 32 : 8;             // row splits (= atomics per column): 11.2 -> 5.2 us per call at 32 (tools/scratch/ln_ysplit_sweep.sh)
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * d->C + 63) / 64, ysplit), dim3(256), 0, st,
                        reinterpret_cast<const float*>(dd.workspace), grid, d->C, d->dgamma, d->dbeta);
   }
   VMVM_CHECK_LAUNCH();
