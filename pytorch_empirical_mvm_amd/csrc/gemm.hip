@@ -1355,7 +1355,10 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   // 256x256 tile is not hidden by a second workgroup) and when M*N gives fewer than ~3 rounds of 256 tiles at K < 2048.
   if (pers && pp_shape && (dd.variant == 7 || dd.variant == 0)) {
     const long tiles = (long)((dd.M + 255) / 256) * ((dd.N + 255) / 256);
-    const bool pays = dd.K >= 768 && dd.N >= 512 && (dd.K >= 2048 ? tiles >= 128 : tiles >= 1024);
+    bool pays = dd.K >= 768 && dd.N >= 512 && (dd.K >= 2048 ? tiles >= 128 : tiles >= 1024);
+    // without an epilogue the 256x256 tile's store tail is one bf16 output: it already wins from ~1.5 rounds of tiles (in-step A/B,
+    // tools/scratch/force_pp_compare.sh: 50176 x 512 x 1536 108 -> 97 us, 200704 x 256 x 768 125 -> 114; 12544-row shapes lose)
+    if (!pays && epi_need(dd) == 0 && dd.K >= 768 && dd.N >= 256 && tiles >= 384) pays = true;
     if (pays || dd.variant == 7) {
       const int rc_ = vmvm_gemm_pp(dd, epi_need(dd), st);
       if (rc_ != VMVM_ENOSUPPORT) return rc_;
