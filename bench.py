@@ -265,7 +265,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
                      "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * O * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
-                               f"gemm_pp_kernel<k-major,k-major,F=bias|GELU|rowscale|code8> 256x256 ping-pong when M*N >= 1024 tiles else gemm_pers_kernel 128x128; "
+                               f"gemm_pers_kernel<k-major,k-major,F=bias|GELU|rowscale> 128x128 persistent, two workgroups per CU, re-tiled stores; "
                                f"average of the {kcalls} launches of one real step, HIP events on the launching stream",
                      "algorithmic_bytes": int((B * O * Lq) * 768 * 2 + 3072 * 768 * 2 + (B * O * Lq) * 3072 * (2 + 1)),      # A + W read, bf16 output + 1-byte codes written
                      # the dominant memory-bound kernel of the step, against HBM: fused clip + AdamW over the flat arena

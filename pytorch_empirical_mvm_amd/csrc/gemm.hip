@@ -1359,6 +1359,10 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // without an epilogue the 256x256 tile's store tail is one bf16 output: it already wins from ~1.5 rounds of tiles (in-step A/B,
     // tools/scratch/force_pp_compare.sh: 50176 x 512 x 1536 108 -> 97 us, 200704 x 256 x 768 125 -> 114; 12544-row shapes lose)
     if (!pays && epi_need(dd) == 0 && dd.K >= 768 && dd.N >= 256 && tiles >= 384) pays = true;
+    // GELU forward with its second output (saved pre-activation / 8-bit code): the 128x128 kernel's epilogue of one workgroup runs under
+    // the main loop of the other one on the CU, and since its stores are re-tiled it beats the ping-pong kernel's exposed store tail at
+    // K < 2048 (55296 x 3072 x 768: 367 -> 348 us, tools/scratch/no_pp_compare.sh)
+    if ((epi_need(dd) & EF_ACT1) && dd.C2 && dd.K < 2048) pays = false;
     if (pays || dd.variant == 7) {
       const int rc_ = vmvm_gemm_pp(dd, epi_need(dd), st);
       if (rc_ != VMVM_ENOSUPPORT) return rc_;
