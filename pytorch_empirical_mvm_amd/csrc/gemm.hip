@@ -315,19 +315,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   }
 }
 
-// C[m][n] += sum_s ws[s][m][n]   (float4 lanes; every slab element was written by exactly one block)
+// C[m][n] += sum_s ws[s][m][n]   (float4 lanes; every slab element was written by exactly one block).  gridDim.y > 1: the slabs are
+// split over blockIdx.y and the partial sums land with f32 atomics -- small outputs with hundreds of slices (the 128 x 128 weight
+// gradient of Swin stage 1: 512 slabs, 16 workgroups' worth of output) otherwise sum their slabs one after the other on a handful of CUs
+// (122 us; the reduce of a gradient is upstream of the all-reduce, so the order of the partial sums does not have to be fixed).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int S) {
   const long n4 = N >> 2;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)M * n4) return;
   const long m = i / n4, c = (i - m * n4) * 4;
-  float4 a = *reinterpret_cast<const float4*>(C + m * ldc + c);
   const size_t slab = (size_t)M * N;
-  for (int s = 0; s < S; ++s) {
+  const int per = (S + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = (s0 + per < S) ? s0 + per : S;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = s0; s < s1; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(ws + s * slab + m * N + c);
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
-  *reinterpret_cast<float4*>(C + m * ldc + c) = a;
+  float* o = C + m * ldc + c;
+  if (gridDim.y == 1) {
+    const float4 c0 = *reinterpret_cast<const float4*>(o);
+    *reinterpret_cast<float4*>(o) = make_float4(c0.x + a.x, c0.y + a.y, c0.z + a.z, c0.w + a.w);
+  } else if (s1 > s0) {
+    atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+  }
+}
+static inline int launch_splitk_reduce(const void* ws, void* C, int M, int N, int ldc, int S, hipStream_t st) {
+  const long n = (long)M * (N >> 2);
+  const unsigned nbx = (unsigned)((n + 255) / 256);
+  unsigned ny = 1;
+  if (nbx <= 64 && S >= 16) {                            // a quarter of the CUs or fewer: spread the slabs too (from 256 workgroups of output on,
+    ny = (1024 + nbx - 1) / nbx;                         //  the atomics cost more than the sequential sum: 512 x 512, 32 slabs: 47 -> 63 us)
+    if (ny > (unsigned)S / 4) ny = (unsigned)S / 4;
+    if (ny < 1) ny = 1;
+  }
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nbx, ny), dim3(256), 0, st, reinterpret_cast<const float*>(ws), reinterpret_cast<float*>(C), M, N, ldc, S);
+  return 0;
 }
 
 template <bool AK, bool BKM, bool TR, bool DIRECT>
@@ -342,9 +365,7 @@ int launch(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<AK, BKM, TR, DIRECT>), dim3(nb), dim3(256), SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    const long n = (long)d.M * (d.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
-                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -502,9 +523,7 @@ int launch_big(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_big_kernel<AK, BKM>), dim3(nb), dim3(512), BIG_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    const long n = (long)d.M * (d.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
-                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -647,9 +666,7 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_p3_kernel<AK, BKM>), dim3(nb), dim3(512), P3_SMEM, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    const long n = (long)d.M * (d.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
-                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -1111,9 +1128,7 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    const long n = (long)d.M * (d.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(d.workspace),
-                       reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, d.splitk);
+    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -1310,9 +1325,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
       if (s == 1) dp.workspace = nullptr;
       const int rc_ = vmvm_gemm_pp(dp, epi_need(dp) | (s > 1 ? EF_SPLIT : 0), st);
       if (rc_ == VMVM_OK && s > 1) {
-        const long n = (long)dp.M * (dp.N >> 2);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(dp.workspace),
-                           reinterpret_cast<float*>(dp.C), dp.M, dp.N, dp.ldc, s);
+        launch_splitk_reduce(dp.workspace, dp.C, dp.M, dp.N, dp.ldc, s, st);
         VMVM_CHECK_LAUNCH();
       }
       if (rc_ != VMVM_ENOSUPPORT) return rc_;
