@@ -6,4 +6,5 @@ rocprofv3 --kernel-trace -d /tmp/prof_c5 -- python3 $GRAFT_REPO_ROOT/bench.py --
 tail -1 /tmp/prof_c5.log | cut -c1-200
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_c5 -name "*.db" | head -1) 60 > $GRAFT_REPO_ROOT/gpurun_out/c5_trace.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_shapes.py $(find /tmp/prof_c5 -name "*.db" | head -1) > $GRAFT_REPO_ROOT/gpurun_out/c5_shapes.txt 2>&1
 head -34 $GRAFT_REPO_ROOT/gpurun_out/c5_trace.txt | cut -c1-170
