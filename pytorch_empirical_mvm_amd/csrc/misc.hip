@@ -397,7 +397,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
   const int col = blockIdx.x * 64 + cc * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < N) {
-    for (long m = (long)blockIdx.y * 32 + rl; m < M; m += (long)gridDim.y * 32) {
+    // four rows per trip: the loads (and the row-scale lookups) of a trip are independent, so four requests per lane are in flight
+    const long step = (long)gridDim.y * 32;
+    long m = (long)blockIdx.y * 32 + rl;
+    for (; m + 3 * step < M; m += 4 * step) {
+      uint4 raw[4]; float sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        raw[u] = *reinterpret_cast<const uint4*>(X + (m + u * step) * ldx + col);
+        sc[u] = row_scale ? row_scale[(m + u * step) / rows_per_scale] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack_bf8(raw[u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e] * sc[u];
+      }
+    }
+    for (; m < M; m += step) {
       float v[8];
       unpack_bf8(*reinterpret_cast<const uint4*>(X + m * ldx + col), v);
       const float s = row_scale ? row_scale[m / rows_per_scale] : 1.f;
