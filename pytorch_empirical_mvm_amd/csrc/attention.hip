@@ -830,23 +830,39 @@ __global__ __launch_bounds__(448) void attn_fwd_win2_kernel(const vmvm_attn_fwd_
   for (int i = tid; i < L; i += NWV * 64) rcs[i] = p.rc[i];
   uint32_t bm[NX * 2];
   auto build_bm = [&]() {                                 // bias + shift mask of this wave's score block, packed bf16 (from LDS)
+    // four keys per LDS read (rc codes as int4, region ids as one dword) and selects instead of per-element branches: every tile but
+    // the last holds only keys < L in the exact-tile build; the last one clamps its reads and selects the pad value
     const int rcq = rcs[qv ? q : 0] + p.rc0;
     const int regq = MASK ? regs[qv ? q : 0] : 0;
 #pragma unroll
     for (int t = 0; t < NX; ++t) {
+      const int key0 = t * 16 + g * 4;
+      const bool whole = (t < NX - 1) || (key0 + 4 <= L);
+      const int k0c = whole ? key0 : 0;
+      const int4 rk = *reinterpret_cast<const int4*>(rcs + k0c);
+      const uint32_t gk = MASK ? *reinterpret_cast<const uint32_t*>(regs + k0c) : 0u;
+      const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
       float b4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = t * 16 + g * 4 + j;
-        float b = PAD_BIAS;
-        if (key < L) {
-          b = tabs[rcq - rcs[key]];
-          if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+        float b = tabs[rcq - rks[j]];
+        if (MASK) b += ((int)((gk >> (8 * j)) & 0xffu) != regq) ? -100.f : 0.f;
+        b4[j] = whole ? b : PAD_BIAS;
+      }
+      if (!whole && t == NX - 1) {                         // ragged last tile: keys L-1 and below inside this lane's four
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = key0 + j;
+          if (key < L) {
+            float b = tabs[rcq - rcs[key]];
+            if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+            b4[j] = b;
+          }
         }
-        b4[j] = b;
       }
       bm[2 * t] = pack_bf2(b4[0], b4[1]);
       bm[2 * t + 1] = pack_bf2(b4[2], b4[3]);
+      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);                // straight-line code: keep the tiles' reads from piling up (registers)
     }
   };
 
@@ -1036,23 +1052,39 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
   for (int i = tid; i < L; i += NWV * 64) rcs[i] = p.rc[i];
   uint32_t bm[NH * 2];
   auto build_bm = [&]() {                                 // bias + shift mask of this wave's score block, packed bf16 (from LDS)
+    // (vector reads + selects, as in attn_fwd_win2_kernel; only a lane whose four keys straddle L takes the per-element path)
     const int rcq = rcs[qv ? q : 0] + p.rc0;
     const int regq = MASK ? regs[qv ? q : 0] : 0;
 #pragma unroll
     for (int tl = 0; tl < NH; ++tl) {
+      const int key0 = (tbase + tl) * 16 + g * 4;
+      const bool on = tl < ntl;
+      const bool whole = on && key0 + 4 <= L;
+      const int k0c = whole ? key0 : 0;
+      const int4 rk = *reinterpret_cast<const int4*>(rcs + k0c);
+      const uint32_t gk = MASK ? *reinterpret_cast<const uint32_t*>(regs + k0c) : 0u;
+      const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
       float b4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = (tbase + tl) * 16 + g * 4 + j;
-        float b = NEG_INF;
-        if (tl < ntl && key < L) {
-          b = tabs[rcq - rcs[key]];
-          if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+        float b = tabs[rcq - rks[j]];
+        if (MASK) b += ((int)((gk >> (8 * j)) & 0xffu) != regq) ? -100.f : 0.f;
+        b4[j] = whole ? b : NEG_INF;
+      }
+      if (on && !whole) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = key0 + j;
+          if (key < L) {
+            float b = tabs[rcq - rcs[key]];
+            if (MASK) b += (regs[key] != regq) ? -100.f : 0.f;
+            b4[j] = b;
+          }
         }
-        b4[j] = b;
       }
       bm[2 * tl] = pack_bf2(b4[0], b4[1]);
       bm[2 * tl + 1] = pack_bf2(b4[2], b4[3]);
+      if ((tl & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
   };
   f32x2 racc[NH][2];
@@ -1539,20 +1571,50 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win2_kernel(const vmvm_
       const int rck = rcs[kv[t] ? key[t] : 0] - p.rc0;
       const int regk = MASK ? regs[kv[t] ? key[t] : 0] : 0;
 #pragma unroll
-      for (int qt = 0; qt < NX; ++qt) {
+      for (int qt = 0; qt < NX; ++qt) {                   // (vector reads + selects, as in attn_fwd_win2_kernel)
+        if constexpr (KT > 1) {                           // two key tiles per wave (196-token windows): no registers to spare for the vector form
+          float b4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = qt * 16 + g * 4 + j;
+            float b = NEG_INF;
+            if (kv[t] && q < L) {
+              b = tabs[rcs[q] - rck];
+              if (MASK) b += (regs[q] != regk) ? -100.f : 0.f;
+            }
+            b4[j] = b;
+          }
+          bm[t][qt][0] = pack_bf2(b4[0], b4[1]);
+          bm[t][qt][1] = pack_bf2(b4[2], b4[3]);
+          continue;
+        }
+        const int q0 = qt * 16 + g * 4;
+        const bool whole = kv[t] && ((qt < NX - 1) || (q0 + 4 <= L));
+        const int q0c = whole ? q0 : 0;
+        const int4 rq = *reinterpret_cast<const int4*>(rcs + q0c);
+        const uint32_t gq = MASK ? *reinterpret_cast<const uint32_t*>(regs + q0c) : 0u;
+        const int rqs[4] = {rq.x, rq.y, rq.z, rq.w};
         float b4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int q = qt * 16 + g * 4 + j;
-          float b = NEG_INF;
-          if (kv[t] && q < L) {
-            b = tabs[rcs[q] - rck];
-            if (MASK) b += (regs[q] != regk) ? -100.f : 0.f;
+          float b = tabs[rqs[j] - rck];
+          if (MASK) b += ((int)((gq >> (8 * j)) & 0xffu) != regk) ? -100.f : 0.f;
+          b4[j] = whole ? b : NEG_INF;
+        }
+        if (kv[t] && !whole && qt == NX - 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j;
+            if (q < L) {
+              float b = tabs[rcs[q] - rck];
+              if (MASK) b += (regs[q] != regk) ? -100.f : 0.f;
+              b4[j] = b;
+            }
           }
-          b4[j] = b;
         }
         bm[t][qt][0] = pack_bf2(b4[0], b4[1]);
         bm[t][qt][1] = pack_bf2(b4[2], b4[3]);
+        if ((qt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
