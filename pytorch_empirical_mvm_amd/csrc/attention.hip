@@ -21,6 +21,7 @@
 // Attention-prob dropout: Philox4x32-7 per 4x4 (query,key) block, 8 random bits per element
 // (p_eff = round(256p)/256), the same block is addressed row-wise by fwd/A and column-wise by B.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -528,6 +529,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
   const float* lse_g = p.lse + ((size_t)seq * heads + h) * L;
   float* delta_g = pb.delta + ((size_t)seq * heads + h) * L;
 
+  // the dropout tests are compile-time inside the tile loops (two copies of the loop, chosen once per sequence): as run-time tests they
+  // were ~60 scalar branches per query tile, each one a scheduling boundary between the tiles' MFMA and VALU work
+  auto qloop = [&](auto drop_c) {
+  constexpr bool DROP = decltype(drop_c)::value;
   for (int qt = wave; qt < nt; qt += NW) {
     const int q = qt * 16 + r;
     const bool qv = q < L;
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
           const f32x4 s4 = s4c[u], dp4 = dpc[u];
           const int key0 = t * 16 + g * 4;
           uint32_t w = 0;
-          if (has_drop) {
+          if (DROP) {
             if ((t & 3) == 0) own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
             w = u4_static(own, t & 3);
           }
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
             const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
             const f32x2 d01 = f32x2{dp4[0], dp4[1]} * c2, d23 = f32x2{dp4[2], dp4[3]} * c2;
             float dp[4] = {d01[0], d01[1], d23[0], d23[1]};
-            if (has_drop) {
+            if (DROP) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) dp[j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dp[j];
             }
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
               if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q >= p.causal_from && key0 + j <= q && key0 + j < L);
               const float pr = (ok && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
               float dpj = dp4[j] * seq_scale;
-              if (has_drop) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
+              if (DROP) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
               ds[u][j] = pr * (dpj - dl);
             }
           }
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
         *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
     }
   }
+  };
+  if (has_drop) qloop(std::true_type{}); else qloop(std::false_type{});
   }   // sequences
   if (MODE == 0 && want_dtab) {
     __syncthreads();
@@ -1349,6 +1356,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
   // each wave owns TWO key tiles at a time: the Q / dO fragments (k = hd) and the transposed Q^T / dO^T fragments
   // (k = tokens) are read from LDS once and feed both tiles -> half the LDS traffic per MFMA.
   constexpr int KT = (HD == 32) ? 2 : 1;
+  auto kloop = [&](auto drop_c) {                       // (compile-time dropout tests, as in attn_bwd_dq_kernel)
+  constexpr bool DROP = decltype(drop_c)::value;
   for (int kp = wave; kp * KT < nt; kp += NW) {
     int key[KT]; bool kv[KT];
     bf16x8 kf[KT][HD / 32], vf[KT][HD / 32];
@@ -1438,7 +1447,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
               uint4 blk = make_uint4(0, 0, 0, 0);
-              if (has_drop) {                               // quad lane i evaluates the block of query tile (qt & ~3) + i
+              if (DROP) {                               // quad lane i evaluates the block of query tile (qt & ~3) + i
                 if ((qt & 3) == 0) own[t] = drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)((qt + (lane & 3)) * 4 + g), (uint32_t)(key[t] >> 2));
                 blk = (c & 1) ? (u ? quad_bcast<3>(own[t]) : quad_bcast<2>(own[t])) : (u ? quad_bcast<1>(own[t]) : quad_bcast<0>(own[t]));
               }
@@ -1454,7 +1463,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 const f32x2 d01 = f32x2{dp4[t][0], dp4[t][1]} * c2, d23 = f32x2{dp4[t][2], dp4[t][3]} * c2;
                 // dS = P * (mask * dP - delta) = (mask * P) * dP - P * delta: ONE select per element (the masked P, which dV needs anyway)
                 float pj[4] = {pr[0], pr[1], pr[2], pr[3]};
-                if (has_drop) {
+                if (DROP) {
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
                     const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
@@ -1472,7 +1481,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 if (CAUSAL) ok = (key[t] < p.causal_from) ? ok : (kv[t] && q0 + j >= p.causal_from && key[t] <= q0 + j);
                 const float pr = ok ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
                 float dpj = dp4[t][j] * seq_scale, pj = pr;
-                if (has_drop) {
+                if (DROP) {
                   const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
                   dpj = dropped ? 0.f : dpj * keep;
                   pj = dropped ? 0.f : pr * keep;
@@ -1524,6 +1533,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
       }
     }
   }
+  };
+  if (has_drop) kloop(std::true_type{}); else kloop(std::false_type{});
 }
 
 
