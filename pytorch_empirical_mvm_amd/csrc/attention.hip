@@ -392,6 +392,60 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (FAST1 && NX > 0 && !COLSUM) {
+      // exact-tile fusion build: exp2 / row sum / dropout mask / bf16 pack / P V of one PAIR of key tiles at a time, so the P V MFMAs of
+      // a pair run while the VALU works on the next pair (as three separate loops over the row block, the matrix pipe idled through
+      // the whole softmax pass and the VALU through the whole P V pass)
+      f32x2 sum2 = f32x2{0.f, 0.f};
+      const f32x2 nmx = f32x2{-mx, -mx};
+      f32x4 o[HD / 16];
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto pairs = [&](auto drop_c) {
+        constexpr bool DROP = decltype(drop_c)::value;
+        uint4 own = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NT_MAX / 2; ++c) {
+          if (PAIR_ON(c)) {
+            float e[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int t = 2 * c + u;
+              const f32x2 d01 = f32x2{acc[t][0], acc[t][1]} + nmx, d23 = f32x2{acc[t][2], acc[t][3]} + nmx;
+              const f32x2 e01 = f32x2{__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+              const f32x2 e23 = f32x2{__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+              sum2 += e01; sum2 += e23;                        // the row sum is of the UN-dropped probabilities
+              e[u][0] = e01[0]; e[u][1] = e01[1]; e[u][2] = e23[0]; e[u][3] = e23[1];
+              if (DROP && TILE_ON(t)) {
+                if ((t & 3) == 0)
+                  own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
+                const uint32_t w = u4_static(own, t & 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[u][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : e[u][j];
+              }
+            }
+            const bf16x8 pf = frag_from_f32(e[0], e[1]);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+              const bf16x8 vf = frag_tokens<HD>(Vsm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
+              o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+        }
+      };
+      if (has_drop) pairs(std::true_type{}); else pairs(std::false_type{});
+      float sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (g == 0 && qv) p.lse[((size_t)seq * heads + h) * L + q] = (mx + __log2f(sum)) * 0.6931471805599453f;
+      if (qv) {
+        const float inv = seq_scale * keep / sum;
+        u16* op = reinterpret_cast<u16*>(p.out) + ((size_t)seq * L + q) * p.ld_out + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt)
+          *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+      }
+    } else {
     float sum = 0.f;
     if (FAST1) {
       f32x2 sum2 = f32x2{0.f, 0.f};
@@ -468,6 +522,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt)
         *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+    }
     }
   }
 }
