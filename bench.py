@@ -174,7 +174,11 @@ def main():
     from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
     from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
 
-    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        # inside a launcher whose world size disagrees with --gpus: every rank spawning its own nested launcher on the inherited
+        # MASTER_PORT would clash and hang -- refuse instead
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} (launch with --nproc-per-node {a.gpus})")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # not under torch.distributed.run: start it as a CHILD (nothing here has touched the GPU yet) and pass its exit code on
         import subprocess
         port = os.environ.get("MASTER_PORT", "29531")

@@ -95,11 +95,19 @@ typedef struct {
    * A quarter of the fc1 forward's stores, half of the fc2-dgrad's operand bytes and its whole erf / exp evaluation go away; the
    * multiplier is quantised to 0.0025 absolute (the bf16 product it feeds carries 0.4 % relative). */
   int32_t aux_code8;
+  /* data-parallel runs: leave `reserve_cus` compute units (rounded up to a multiple of 8 = one per XCD, at most 128) out of the
+   * PERSISTENT kernels' grids, so that a collective in flight on another stream (RCCL's channel workgroups) keeps its CUs and the
+   * persistent workgroups -- which split the tiles statically -- are all resident at once.  0: the whole chip.  Changes grid
+   * sizes only, never results of the bf16-output classes; f32 split-K plans do not depend on it either. */
+  int32_t reserve_cus;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 /* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never
  * allocates: the caller (PyTorch's caching allocator in the reference loop) owns every buffer, including scratch. */
 int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d);
+/* dst[i] (f32) = src[i] (bf16): the reduced bf16 gradient payload of a data-parallel step back into the f32 gradient arena (utils/deepspeed.py:11-30
+ * reduces 16-bit gradients too) */
+int vmvm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* dst[i] (OCP e4m3, saturating at +-448) = src[i] (bf16) * scale ; n a multiple of 8 */
 int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, float scale, void* stream);
 
@@ -158,6 +166,7 @@ typedef struct {
   /* optional scratch for the dgamma/dbeta partials (>= 1280 * 2C floats): per-workgroup partials are stored
    * and summed by a second small kernel instead of 2C global atomics per workgroup.  NULL: atomics. */
   void* workspace; uint64_t workspace_bytes;
+  int32_t reserve_cus;                   /* as vmvm_gemm_desc.reserve_cus: CUs left out of the resident grid (data-parallel overlap) */
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
 int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d);   /* bytes of `workspace` for the dgamma / dbeta partial rows */

@@ -530,9 +530,12 @@ def enc_txt(sd, txt):
     return layer_norm(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], BERT["eps"])
 
 
-def bert_layer(sd, p, x, add_mask, probs_out=None):
-    """HF BertLayer (post-LN), eval mode; call site model.py:213.  probs_out: list receiving the attention probabilities
-    (B, heads, L, L) -- HF's `attentions` (output_attentions=True, model.py:213)"""
+def bert_layer(sd, p, x, add_mask, probs_out=None, drop=None):
+    """HF BertLayer (post-LN); call site model.py:213.  probs_out: list receiving the attention probabilities
+    (B, heads, L, L) -- HF's `attentions` (output_attentions=True, model.py:213).
+    drop=None: eval mode.  drop=dict(attn (B,heads,L,L), h1 (B,L,H), h2 (B,L,H)): train mode with EXPLICIT dropout multipliers
+    (0 or 1/keep) at HF's three sites -- BertSelfAttention.dropout on the probabilities, BertSelfOutput.dropout and
+    BertOutput.dropout on the dense outputs before the residual add."""
     B, L, H = x.shape
     nh, hd = BERT["heads"], H // BERT["heads"]
     q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
@@ -543,11 +546,17 @@ def bert_layer(sd, p, x, add_mask, probs_out=None):
     pr = s.softmax(-1)
     if probs_out is not None:
         probs_out.append(pr)
+    if drop is not None:
+        pr = pr * drop["attn"]
     a = (pr @ v).transpose(1, 2).reshape(B, L, H)
     a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+    if drop is not None:
+        a = a * drop["h1"]
     x = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], BERT["eps"])
     y = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
     y = F.linear(y, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    if drop is not None:
+        y = y * drop["h2"]
     return layer_norm(y + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT["eps"])
 
 
@@ -910,6 +919,33 @@ def qamc_mlm_predict(logits, mask_ans, true_id, false_id):
     sc = sc[m != -1].view(B, O)
     am = m[m != -1].view(B, O)
     return torch.argmax(sc, dim=-1), (am == true_id).nonzero()[:, 1]
+
+
+def mlm_qa_forward(sd, cfg, img, txt, mask):
+    """VIOLET_QAMC_MLM_Head_GEN.forward (main_qamc_tsv_mlm_gen_ans_idx.py:87-101) == VIOLET_QAOE_LSMDC.forward (main_qaoe_lsmdc_fib.py:71-84):
+    ONE (video, question + [MASK]) sequence per clip, txt / mask (B, X); MLM-head logits (B, X, vocab) of the text positions."""
+    return qamc_mlm_forward(sd, cfg, img, txt[:, None], mask[:, None])
+
+
+def qamc_gen_predict(logits, mask_ans, ans_tok_ids):
+    """Agent_QAMC_MLM_Head_GEN.step, eval branch (main_qamc_tsv_mlm_gen_ans_idx.py:116-125): the RAW logits of the candidate answer tokens at
+    each clip's [MASK] position, divided by their sum, arg-max -> (scores (B, n_ans), predicted candidate (B,))"""
+    B = mask_ans.shape[0]
+    p = logits[:, :, ans_tok_ids][mask_ans != -1]
+    p = (p / p.sum(dim=-1).view(B, 1)).view(B, -1)
+    return p, torch.argmax(p, dim=-1)
+
+
+def top_k_acc(out, ans, k=5):
+    """Agent_QAOE_LSMDC.get_top_k_acc (main_qaoe_lsmdc_fib.py:100-112): per labelled position 1.0 when the label is among the k largest
+    logits; the list is padded with 0.0 up to the batch size (clips without a label count as wrong)."""
+    B = out.shape[0]
+    ac = []
+    if bool((ans != -1).any()):
+        lab = ans[ans != -1].view(-1, 1)
+        top = torch.topk(out[ans != -1].view(lab.shape[0], -1), k=k, dim=-1).indices
+        ac = (top == lab).any(dim=-1).float().tolist()
+    return ac + [0.0] * (B - len(ac))
 
 
 def norm_softmax_loss(x, temperature):

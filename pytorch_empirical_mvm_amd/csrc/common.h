@@ -208,3 +208,11 @@ __device__ __forceinline__ uint4 dropout_bits(uint64_t seed, uint64_t offset, ui
   return make_uint4(lo << 16, lo & 0xffff0000u, hi << 16, hi & 0xffff0000u);
 }
 __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(fminf(fmaxf(p, 0.f), 1.f) * 4294967295.0f); }
+
+// CUs a persistent / resident grid may use: the whole chip minus `reserve` (vmvm_gemm_desc.reserve_cus), kept a multiple of 8 so the
+// XCD-aware rasterisations (workgroup b runs on XCD b % 8) still see equal shares per XCD.
+static inline int vmvm_usable_cus(int reserve) {
+  int r = reserve < 0 ? 0 : reserve > 128 ? 128 : reserve;
+  r = (r + 7) & ~7;
+  return 256 - r;
+}

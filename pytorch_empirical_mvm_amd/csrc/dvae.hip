@@ -72,7 +72,8 @@ __global__ void argmax_pairs_kernel(const float* __restrict__ pairs, int ld, int
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
   float best = -__builtin_inff();
-  int bi = 0x7fffffff;
+  int bi = 0;                                    // a row of NaNs (no comparison ever true) must still give an in-range id: it becomes a
+  //                                                cross-entropy target and a gather index downstream
   for (int q = lane; q < groups; q += 64) {
     const float2 pr = *reinterpret_cast<const float2*>(pairs + (size_t)row * ld + 2 * q);
     const int idx = __float_as_int(pr.y);
@@ -84,7 +85,7 @@ __global__ void argmax_pairs_kernel(const float* __restrict__ pairs, int ld, int
     const int oi = __shfl_xor(bi, off, 64);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if (lane == 0) out[row] = (int64_t)bi;
+  if (lane == 0) out[row] = (int64_t)min(max(bi, 0), 64 * groups - 1);
 }
 
 }  // namespace

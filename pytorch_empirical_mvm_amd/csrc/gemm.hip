@@ -1123,7 +1123,7 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, PERS_SMEM_BYTES);
     attr_done = true;
   }
-  int grid = 512;                                       // 2 workgroups per CU (64 KiB LDS each), multiple of 8
+  int grid = 2 * vmvm_usable_cus(d.reserve_cus);        // 2 workgroups per CU (64 KiB LDS each), multiple of 8
   if (items < grid) grid = ((items + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
@@ -1171,7 +1171,7 @@ int launch_pers_teacher(const vmvm_gemm_desc& d, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, F, true, CONV, false, TM, ARELU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_);
     attr_done = true;
   }
-  int grid = 512;
+  int grid = 2 * vmvm_usable_cus(d.reserve_cus);
   if (items < grid) grid = ((items + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_pers_kernel<true, true, F, true, CONV, false, TM, ARELU>), dim3(grid), dim3(256), SMEM_, st, d);
   VMVM_CHECK_LAUNCH();
@@ -1187,7 +1187,7 @@ int launch_pers_fp8(const vmvm_gemm_desc& d, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<true, true, EF_FP8, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr_done = true;
   }
-  int grid = 512;
+  int grid = 2 * vmvm_usable_cus(d.reserve_cus);
   if (items < grid) grid = ((items + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_pers_kernel<true, true, EF_FP8, false, false, true>), dim3(grid), dim3(256), SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();

@@ -612,7 +612,7 @@ int launch_pp_f(const vmvm_gemm_desc& d, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
-  int grid = 512 / WM;                                  // one (WM = 2) or two workgroups per CU, multiple of 8
+  int grid = 2 * vmvm_usable_cus(d.reserve_cus) / WM;   // one (WM = 2) or two workgroups per CU, multiple of 8
   if (items < grid) grid = ((items + 7) / 8) * 8;
   if (DBG & 8) grid = 64;                               // probe: a quarter of the CUs (is the store tail a per-CU or a chip-wide limit?)
   hipLaunchKernelGGL((gemm_pp_kernel<AK, BKM, F, WM, BK, NS, false, DBG, FP8>), dim3(grid), dim3(WM * 256), smem, st, d);

@@ -459,6 +459,19 @@ extern "C" int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream) {
   return VMVM_OK;
 }
 
+// resident grid of the backward kernels: workgroups that fit per CU at the variant's VGPR count x 256 CUs, at most one per 4 rows.
+// ONE helper for the launcher and the workspace-size query, so the two plans cannot drift.
+static int ln_bwd_grid(int M, int C, int reserve_cus) {
+  int per_cu = C <= 128 ? 4 : C <= 512 ? 5 : C <= 1024 ? 4 : 2;
+#ifdef VMVM_PROBE_BUILD
+  if (const char* e = getenv("VMVM_LN_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }    // tools/gpu_check.py benchln
+#endif
+  int grid = (M + 3) / 4;
+  const int cus = vmvm_usable_cus(reserve_cus);
+  if (grid > cus * per_cu) grid = cus * per_cu;
+  return grid;
+}
+
 extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (!d || !d->dY || !d->X || !d->gamma || !d->mean || !d->rstd || !d->dX || !d->dgamma || !d->dbeta) return VMVM_EINVAL;
   if (d->M <= 0 || d->C <= 0 || (d->C & 7) || d->nseg < 1 || (d->C % d->nseg) || ((d->C / d->nseg) & 7)) return VMVM_EINVAL;
@@ -472,10 +485,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   // registers, FOUR waves per SIMD, not five (the C <= 256 build takes 96: five) -- a fifth workgroup per CU ran as a second round and cost 25 % at C = 128.
   // (Measured and dropped: one workgroup fewer per CU to trim a mostly-empty last round of rows -- slower in the step wherever the
   // memory system is not yet saturated; a second row per wave in flight -- costs the wave it was meant to replace.)
-  int per_cu = d->C <= 128 ? 4 : d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
-  if (const char* e = getenv("VMVM_LN_PER_CU")) per_cu = atoi(e);           // probe hook (tools/gpu_check.py benchln)
-  int grid = (d->M + 3) / 4;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  int grid = ln_bwd_grid(d->M, d->C, d->reserve_cus);
   const size_t sm = (size_t)8 * d->C * sizeof(float);   // 4 wave slabs x [2][C]
   vmvm_ln_bwd_desc dd = *d;
   if (dd.workspace && dd.workspace_bytes < (uint64_t)grid * 2 * d->C * sizeof(float)) dd.workspace = nullptr;
@@ -517,9 +527,6 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
 // scratch of the dgamma / dbeta reduction (one [2][C] f32 partial row per resident workgroup); without it: global atomics
 extern "C" int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d) {
   if (!d || d->M <= 0 || d->C <= 0) return VMVM_EINVAL;
-  const int per_cu = d->C <= 512 ? 5 : d->C <= 1024 ? 4 : 2;
-  int grid = (d->M + 3) / 4;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;
-  return (int64_t)grid * 2 * d->C * (int64_t)sizeof(float);
+  return (int64_t)ln_bwd_grid(d->M, d->C, 0) * 2 * d->C * (int64_t)sizeof(float);     // same plan as the launcher (an upper bound where it trims the grid further)
 }
 

@@ -284,6 +284,17 @@ __global__ void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst
     for (long k = i; k < n; ++k) dst[k] = f2bf(src[k]);
   }
 }
+__global__ void uncast_kernel(const u16* __restrict__ src, float* __restrict__ dst, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float f[8];
+    unpack_bf8(*reinterpret_cast<const uint4*>(src + i), f);
+    *reinterpret_cast<float4*>(dst + i) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(dst + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  } else {
+    for (long k = i; k < n; ++k) dst[k] = __uint_as_float((uint32_t)src[k] << 16);
+  }
+}
 __global__ void add_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ out, long n) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i + 8 <= n) {
@@ -735,6 +746,13 @@ extern "C" int vmvm_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, floa
 extern "C" int vmvm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   if (!src || !dst || n <= 0) return VMVM_EINVAL;
   hipLaunchKernelGGL(cast_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, ST, src, reinterpret_cast<u16*>(dst), (long)n);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return VMVM_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(uncast_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), dst, (long)n);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

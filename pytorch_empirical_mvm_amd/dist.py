@@ -1,16 +1,42 @@
 """Data-parallel plumbing (replaces utils/dist.py:20-75 + DDP/DeepSpeed, agent.py:195-201).
 
 One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm) or "gloo" (CPU tests).
-The only exchange of the step is the gradient sum: the flat f32 gradient arena is reduced in two phases --
+The only exchange of the step is the gradient sum: the flat gradient arena is reduced in two phases --
 the non-Swin optimizer groups (fusion encoder, heads, embeddings: complete as soon as the fusion backward ends)
 on a side stream while the Video-Swin backward still runs, then the Swin groups.  xGMI is point-to-point, so
-a few LARGE messages (chunks of <= 256 MiB) are used instead of many small DDP-style buckets."""
+a few LARGE messages (chunks of <= 256 MiB) are used instead of many small DDP-style buckets.
+
+Payload (`VMVM_GRAD_WIRE`, default bf16): the f32 arena stays the local accumulator of the weight-gradient GEMMs; what goes on the
+wire is a bf16 image of the finished segment (cast -> all-reduce -> cast back, all on the side stream): 450 MB per step instead
+of 900 MB, ring lower bound 5.1 instead of 10.2 ms over xGMI.  The reference's DeepSpeed branch reduces fp16
+gradients as well (utils/deepspeed.py:11-30).  Every rank receives the same reduced bits, so replicas stay bit-identical.
+`VMVM_GRAD_WIRE=f32` keeps the full-precision exchange.
+
+CU reservation (`VMVM_COMM_CUS`, default 16, 0 = off; nccl backend only): the persistent GEMM / LayerNorm-backward grids fill every
+CU and split their tiles statically, so a collective's channel workgroups either wait for a kernel boundary or -- once resident --
+push persistent workgroups into a second round.  While a collective is pending the kernels are launched `VMVM_COMM_CUS` CUs short
+(vmvm_gemm_desc.reserve_cus) and RCCL is held to as many channels (NCCL_MAX_NCHANNELS, set before the process group is created,
+unless the user already set it)."""
 import os
 
 import torch
 import torch.distributed as dist
 
-CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 per collective
+CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 (128 MiB of bf16) per collective
+
+
+def comm_cus():
+    try:
+        return max(0, min(128, int(os.environ.get("VMVM_COMM_CUS", "16"))))
+    except ValueError:
+        return 16
+
+
+def grad_wire():
+    w = os.environ.get("VMVM_GRAD_WIRE", "bf16").lower()
+    if w not in ("bf16", "f32"):
+        raise RuntimeError(f"VMVM_GRAD_WIRE={w!r}: expected bf16 or f32")
+    return w
 
 
 def init_from_env(backend=None):
@@ -30,6 +56,8 @@ def init_from_env(backend=None):
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
+            if comm_cus() > 0:                       # one channel = one workgroup = one CU: keep RCCL inside the CUs the persistent grids leave free
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
             # RCCL's kernels run on the process group's own stream; high priority lets their workgroups take the first CUs that a
             # retiring GEMM workgroup frees (the persistent GEMM grids otherwise re-occupy every CU launch after launch)
             try:
@@ -86,60 +114,86 @@ class GradReducer:
     """Two-phase gradient all-reduce over the ParamStore arena (segments: 0 swin-decay, 1 other-decay, 2 swin-nodecay,
     3 other-nodecay).  Sums only -- the 1/world average is folded into the AdamW kernel's grad_scale."""
 
-    def __init__(self, store, device):
+    def __init__(self, store, device, wire=None, reserve_cus=None):
         self.store = store
         self.cuda = torch.device(device).type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
         self.pending = False
         self.tail_done = False
+        self.wire = grad_wire() if wire is None else wire
+        self.wire_buf = torch.empty_like(store.grad, dtype=torch.bfloat16) if self.wire == "bf16" else None       # bf16 image of the arena, same offsets
+        nccl = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        # (VMVM_COMM_CUS_ANY_BACKEND: test hook -- the shared-GPU gloo test runs the short grids too)
+        on = nccl or bool(os.environ.get("VMVM_COMM_CUS_ANY_BACKEND"))
+        self.reserve_cus = (comm_cus() if (on and self.cuda) else 0) if reserve_cus is None else int(reserve_cus)
+        self.collectives = 0                      # issued so far (tests / profiling)
+        self.wire_bytes = 0
 
-    def _run(self, segs):
+    # ---- one contiguous range of the arena
+    def _reduce_range(self, a, e):
         g = self.store.grad
-        for gi in segs:
-            a, e = self.store.segments[gi]
-            if e > a:
-                all_reduce_chunks_(g, a, e)
+        if self.wire_buf is None:
+            self.collectives += all_reduce_chunks_(g, a, e)
+            self.wire_bytes += 4 * (e - a)
+            return
+        w = self.wire_buf
+        if self.cuda:
+            from . import kernels as K            # HIP casts on the side stream (current stream inside the caller's stream context)
+            K.cast_bf16(g[a:e], w[a:e])
+            self.collectives += all_reduce_chunks_(w, a, e)
+            K.cast_f32(w[a:e], g[a:e])
+        else:                                     # CPU (gloo tests): same arithmetic through torch
+            w[a:e].copy_(g[a:e])
+            self.collectives += all_reduce_chunks_(w, a, e)
+            g[a:e].copy_(w[a:e])
+        self.wire_bytes += 2 * (e - a)
+
+    def _side(self, ranges):
+        """run the ranges on the side stream (GPU) / inline (CPU); from here until reduce_swin_and_wait() the persistent kernels of
+        the main stream are launched `reserve_cus` CUs short"""
+        ranges = [(a, e) for a, e in ranges if e > a]
+        if not ranges:
+            return
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for a, e in ranges:
+                    self._reduce_range(a, e)
+            self.pending = True
+            if self.reserve_cus > 0:
+                from . import kernels as K
+                K.RESERVE_CUS = self.reserve_cus
+        else:
+            for a, e in ranges:
+                self._reduce_range(a, e)
 
     def reduce_other(self):
         """called by the engine right after the last non-Swin gradient has been written"""
         if not is_initialized():
             return
-        if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self._run((1, 3))
-            self.pending = True
-        else:
-            self._run((1, 3))
+        self._side([self.store.segments[gi] for gi in (1, 3)])
 
     def reduce_swin_tail(self):
         """called by the engine when the backward leaves Swin stage n-2: stages >= n-2 (+ final norm) are final; their sum
         runs on the side stream under the two early, memory-bound stages"""
         if not is_initialized() or not self.store.swin_tail:
             return
-        g = self.store.grad
-        if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                for a, e in self.store.swin_tail:
-                    all_reduce_chunks_(g, a, e)
-            self.pending = True
-        else:
-            for a, e in self.store.swin_tail:
-                all_reduce_chunks_(g, a, e)
+        self._side(list(self.store.swin_tail))
         self.tail_done = True
 
     def reduce_swin_and_wait(self):
         if not is_initialized():
             return
-        g = self.store.grad
         tails = {a: e for a, e in self.store.swin_tail} if getattr(self, "tail_done", False) else {}
         for gi in (0, 2):
             a, e = self.store.segments[gi]
             split = next((s for s, ee in tails.items() if ee == e and a <= s), e)      # tail of this segment already reduced?
             if split > a:
-                all_reduce_chunks_(g, a, split)
+                self._reduce_range(a, split)      # nothing left to overlap with: on the main stream
         self.tail_done = False
         if self.cuda and self.pending:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.pending = False
+        if self.cuda and self.reserve_cus > 0:
+            from . import kernels as K
+            K.RESERVE_CUS = 0

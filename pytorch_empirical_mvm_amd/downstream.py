@@ -6,6 +6,10 @@
 * Multiple-choice video QA, MLM-head form: `VIOLET_QAMC_MLM_Head` / `Agent_QAMC_MLM_Head` (main_qamc_tsv_mlm_head.py:61-123) -- one
   "question + option + [MASK]" sequence per option, the clip's video tokens shared by its options, the pre-training MLM head
   predicts the true / false token at [MASK].
+* The two single-sequence MLM-head variants: generative multiple choice `VIOLET_QAMC_MLM_Head_GEN` / `Agent_QAMC_MLM_Head_GEN`
+  (main_qamc_tsv_mlm_gen_ans_idx.py:83-125: the candidate answers' token logits at [MASK]) and open-ended QA on the MLM head
+  `VIOLET_QAOE_LSMDC` / `Agent_QAOE_LSMDC` = `Agent_QAOE_MLM_Head` (main_qaoe_lsmdc_fib.py:55-115, main_qaoe_tsv_mlm_head.py:101-130:
+  top-1 / top-5 accuracy).
 Same encoders, token pool and fusion kernels as pre-training; checkpoints interchange through the shared key names."""
 import torch
 
@@ -141,3 +145,88 @@ class Agent_QAMC_MLM_Head(Agent_Pretrain):
         m = ans.reshape(B * O, X)
         sc, am = sc[m != -1].view(B, O), m[m != -1].view(B, O)
         return (sc.argmax(-1) == (am == self.true_token_id).nonzero()[:, 1]).float().tolist()
+
+
+class VIOLET_QAMC_MLM_Head_GEN(VIOLET_QAMC_MLM_Head):
+    """main_qamc_tsv_mlm_gen_ans_idx.py:83-101: ONE "question + options + [MASK]" sequence per clip -- txt / mask / mask_ans (B, X) --
+    through the same encoders and MLM head (the multiple-choice pass with a single option per clip)."""
+
+    @torch.no_grad()
+    def forward(self, batch):
+        """-> (out (B, X, vocab) f32, ans (B, X))"""
+        dev = self.engine.device
+        txt = batch["txt"]
+        B, X = txt.shape
+        _, lg = self.engine.qamc_mlm_forward_backward(batch["img"].to(dev, torch.float32).contiguous(), txt.to(dev)[:, None], batch["mask"].to(dev)[:, None],
+                                                      batch["mask_ans"].to(dev)[:, None], train=self.training, backward=False)
+        return lg.view(B, X, -1), batch["mask_ans"].to(dev)
+
+
+class VIOLET_QAOE_LSMDC(VIOLET_QAMC_MLM_Head_GEN):
+    """main_qaoe_lsmdc_fib.py:55-84 (`size_vocab == -1`: the answer is a token of the MLM vocabulary): same forward as the generative
+    multiple-choice model."""
+
+
+VIOLET_QAOE_MLM_Head = VIOLET_QAOE_LSMDC            # main_qaoe_tsv_mlm_head.py builds VIOLET_QAOE_LSMDC under this task name
+
+
+class _Agent_MLM_QA(Agent_QAMC_MLM_Head):
+    """shared train branch: CE(ignore_index=-1) over the text positions of the single-sequence form + the shared backward_step"""
+
+    def _fwd(self, batch, is_train):
+        eng, dev = self.engine, self.engine.device
+        img = batch["img"].to(dev, torch.float32).contiguous()
+        txt, mask, ans = batch["txt"].to(dev), batch["mask"].to(dev), batch["mask_ans"].to(dev)
+        loss, lg = eng.qamc_mlm_forward_backward(img, txt[:, None], mask[:, None], ans[:, None], train=is_train, backward=is_train)
+        return loss, lg.view(txt.shape[0], txt.shape[1], -1), ans
+
+    def _train(self, batch):
+        loss, _, _ = self._fwd(batch, True)
+        if self.comm is not None:
+            self.comm.reduce_other()
+        self.backward_step()
+        self.global_step += 1
+        return float(loss.item())
+
+
+class Agent_QAMC_MLM_Head_GEN(_Agent_MLM_QA):
+    """Agent_QAMC_MLM_Head_GEN.step (main_qamc_tsv_mlm_gen_ans_idx.py:103-125).  eval: the RAW logits of the candidate answer tokens
+    `ans_tok_ids` at the clip's [MASK] position, divided by their sum, arg-max against batch["ans_idx"] -> per-clip correctness."""
+
+    def __init__(self, args, model, ans_tok_ids):
+        super().__init__(args, model)
+        self.ans_tok_ids = [int(i) for i in ans_tok_ids]
+
+    def step(self, batch, is_train=True):
+        if is_train:
+            return self._train(batch)
+        _, out, ans = self._fwd(batch, False)
+        B = ans.shape[0]
+        p = out[:, :, self.ans_tok_ids][ans != -1]
+        p = (p / p.sum(dim=-1).view(B, 1)).view(B, -1)
+        return (p.argmax(dim=-1) == batch["ans_idx"].to(p.device)).float().tolist()
+
+
+class Agent_QAOE_LSMDC(_Agent_MLM_QA):
+    """Agent_QAOE_LSMDC.step / get_top_k_acc (main_qaoe_lsmdc_fib.py:86-112): train -> {'ls'}; eval -> {'ac_1', 'ac_5'} per-clip lists"""
+
+    def step(self, batch, is_train=True):
+        if is_train:
+            return {"ls": self._train(batch)}
+        _, out, ans = self._fwd(batch, False)
+        return {"ac_1": self.get_top_k_acc(out, ans, k=1), "ac_5": self.get_top_k_acc(out, ans, k=5)}
+
+    @staticmethod
+    def get_top_k_acc(out, ans, k=5):
+        """1.0 per labelled position whose label is among the k largest logits; padded with 0.0 to the batch size"""
+        B = out.shape[0]
+        sel = ans != -1
+        ac = []
+        if bool(sel.any()):
+            lab = ans[sel].view(-1, 1)
+            top = torch.topk(out[sel].view(lab.shape[0], -1), k=k, dim=-1).indices
+            ac = (top == lab).any(dim=-1).float().tolist()
+        return ac + [0.0] * (B - len(ac))
+
+
+Agent_QAOE_MLM_Head = Agent_QAOE_LSMDC              # main_qaoe_tsv_mlm_head.py:101-105 adds only the optional freeze

@@ -537,6 +537,52 @@ class VioletEngine:
         self.tape = saved
         return att
 
+    # -------------------------------------------------------------- MLM head (HF BertOnlyMLMHead), shared by every pass that reads it
+    def _mlm_dims(self):
+        Vv = self.cfg["vocab"]
+        return Vv, -(-Vv // 8) * 8, -(-Vv // 4) * 4          # vocabulary, row pitch of the f32 logits, columns the GEMM writes
+
+    def _mlm_head_fwd(self, rows, n_rows, target, loss, want_grad):
+        """dense + GELU + LayerNorm + decoder (+ bias) + cross entropy(ignore -1) on `rows` [n_rows, H] (main_pretrain.py:236,560)."""
+        S, dev, Hd = self.store, self.device, self.cfg["hidden"]
+        pm = "fc_mtm.predictions."
+        Vv, Vpad, Nlog = self._mlm_dims()
+        u_ = torch.empty((n_rows, Hd), device=dev, dtype=BF16)
+        t_ = K.gemm(rows, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
+        gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
+        tn_, mean_, rstd_ = K.layernorm_fwd(t_, gm, bm, CFG.BERT["eps"])
+        lg_ = torch.empty((n_rows, Vpad), device=dev, dtype=F32)
+        K.gemm(tn_, S.b(pm + "decoder.weight"), N=Nlog, bias=S.p(pm + "bias"), out=lg_)
+        dlog_ = K.cross_entropy(lg_, Vv, target, loss, want_grad=want_grad, ld_d=Vpad)
+        return dict(r=rows, u=u_, t=t_, tn=tn_, mean=mean_, rstd=rstd_, logits=lg_, dlog=dlog_, n=n_rows)
+
+    def _mlm_head_bwd(self, hd, dx_out=None):
+        """head gradients (accumulated into the shared fc_mtm.* tensors); returns / writes d(rows)."""
+        S, dev, Hd = self.store, self.device, self.cfg["hidden"]
+        pm = "fc_mtm.predictions."
+        Vv, Vpad, _ = self._mlm_dims()
+        n = hd["n"]
+        gm = S.p(pm + "transform.LayerNorm.weight")
+        Wdec = S.b(pm + "decoder.weight")
+        K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=n, N=Vpad)     # pad columns are zero and land in arena padding
+        K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=n, out=S.g(pm + "decoder.weight"), accumulate=True)
+        # d(tn) = dlog . W over K = the PADDED vocabulary when that is a whole number of 64-wide K tiles (30522 -> 30528): the GEMM
+        # then takes the direct-to-LDS kernel instead of the K % 64 != 0 fallback (497 -> 60 us).  Invariants this relies on:
+        #  (i) the pad columns [Vv, Vpad) of dlog are exact zeros (vmvm_cross_entropy writes them);
+        #  (ii) the (Vpad - Vv) extra rows of the [Vpad, H] weight view lie INSIDE the bf16 arena (other parameters or its zero tail:
+        #       (Vpad - Vv) * H <= ParamStore.TAIL) and are FINITE, so 0 * w = 0 -- checked after every optimizer step by the
+        #       clip coefficient being finite (a non-finite parameter makes every loss NaN long before it matters here).
+        # 48 output tiles and a 30528-long reduction: as an f32 accumulation the GEMM splits K over the chip (444 -> ~70 us), its
+        # partial slabs going through the engine's split-K workspace and a fixed-order reduce (run-to-run deterministic).
+        Kdec = Vpad if (Vpad % 64 == 0 and (Vpad - Vv) * Hd <= S.TAIL) else Vv
+        dtn32 = torch.zeros((n, Hd), device=dev, dtype=F32)
+        K.gemm(hd["dlog"], Wdec, b_kmajor=False, M=n, N=Hd, K=Kdec, out=dtn32, accumulate=True)
+        dtn = dtn32.to(BF16)
+        dt_, _ = K.layernorm_bwd(dtn, hd["t"], gm, hd["mean"], hd["rstd"], S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
+        du_ = K.gelu_bwd(dt_, hd["u"])
+        return self._linear_bwd(du_, hd["r"], pm + "transform.dense.weight", pm + "transform.dense.bias",
+                                dx_kw=None if dx_out is None else dict(out=dx_out))
+
     # -------------------------------------------------------------- full step
     def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
                          dropout=None, on_other_grads_ready=None):
@@ -589,40 +635,14 @@ class VioletEngine:
         outs = {}
 
         # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560) -- also the head of the smtm pass (:240,:567)
-        pm = "fc_mtm.predictions."
         Vv = cfg["vocab"]
-        Vpad = -(-Vv // 8) * 8
         txt_rows = self._cached(("txt_rows", B, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(B)]), dev))
-        gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
-        Wdec = S.b(pm + "decoder.weight")
-        Nlog = -(-Vv // 4) * 4
-        Kdec = Vpad if (Vpad % 64 == 0 and (Vpad - Vv) * Hd <= S.TAIL) else Vv
         tgt_m = ans_mtm.reshape(-1).contiguous()
 
         def mlm_head(outv, loss):
-            r_ = K.gather_rows(outv.t, txt_rows, B * X)
-            u_ = torch.empty((B * X, Hd), device=dev, dtype=BF16)
-            t_ = K.gemm(r_, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
-            tn_, mean_, rstd_ = K.layernorm_fwd(t_, gm, bm, CFG.BERT["eps"])
-            lg_ = torch.empty((B * X, Vpad), device=dev, dtype=F32)
-            K.gemm(tn_, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=lg_)
-            dlog_ = K.cross_entropy(lg_, Vv, tgt_m, loss, want_grad=backward, ld_d=Vpad)
-            return dict(r=r_, u=u_, t=t_, tn=tn_, mean=mean_, rstd=rstd_, logits=lg_, dlog=dlog_)
+            return self._mlm_head_fwd(K.gather_rows(outv.t, txt_rows, B * X), B * X, tgt_m, loss, backward)
 
-        def mlm_head_bwd(hd, dx_out):
-            """head gradients (accumulated into the shared fc_mtm.* tensors) ; d(text rows of the encoder output) -> dx_out"""
-            K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=B * X, N=Vpad)     # pad columns are zero and land in arena padding
-            K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=B * X, out=S.g(pm + "decoder.weight"), accumulate=True)
-            # K = the padded vocabulary when that is a whole number of 64-wide K tiles (30522 -> 30528): the extra columns of dlog are
-            # zeros and the extra rows of the weight view lie inside the arena (other parameters / its zero tail), so they add
-            # nothing -- and the GEMM takes the direct-to-LDS kernel instead of the K % 64 != 0 fallback (497 -> 60 us)
-            # 48 output tiles and a 30528-long reduction: as a plain f32 accumulation the GEMM splits K over the chip (444 -> ~70 us)
-            dtn32 = torch.zeros((B * X, Hd), device=dev, dtype=F32)
-            K.gemm(hd["dlog"], Wdec, b_kmajor=False, M=B * X, N=Hd, K=Kdec, out=dtn32, accumulate=True)
-            dtn = dtn32.to(BF16)
-            dt_, _ = K.layernorm_bwd(dtn, hd["t"], gm, hd["mean"], hd["rstd"], S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
-            du_ = K.gelu_bwd(dt_, hd["u"])
-            self._linear_bwd(du_, hd["r"], pm + "transform.dense.weight", pm + "transform.dense.bias", dx_kw=dict(out=dx_out))
+        mlm_head_bwd = self._mlm_head_bwd
 
         h_mlm = mlm_head(out1, losses["mtm"])
         if use_smtm:
@@ -929,29 +949,15 @@ class VioletEngine:
             np.concatenate([np.concatenate([(s_ // O) * Lv + ar_v, B * Lv + s_ * X + ar_t]) for s_ in range(n_seq)]), dev))
         km = torch.cat([torch.ones(n_seq, Lv, dtype=torch.uint8, device=dev), (mask2 != 0).to(torch.uint8)], 1).contiguous()
         out, inn, _ = self.go_cross(pool, idx_d, km, n_seq, Lq, train)
-        pm = "fc_mtm.predictions."
-        Vpad, Nlog = -(-Vv // 8) * 8, -(-Vv // 4) * 4
         txt_rows = self._cached(("qamc_txt_rows", n_seq, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(n_seq)]), dev))
-        gm, bm = S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias")
-        Wdec = S.b(pm + "decoder.weight")
         nr = n_seq * X
-        r_ = K.gather_rows(out.t, txt_rows, nr)
-        u_ = torch.empty((nr, Hd), device=dev, dtype=BF16)
-        t_ = K.gemm(r_, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
-        tn_, mean_, rstd_ = K.layernorm_fwd(t_, gm, bm, CFG.BERT["eps"])
-        lg_ = torch.empty((nr, Vpad), device=dev, dtype=F32)
-        K.gemm(tn_, Wdec, N=Nlog, bias=S.p(pm + "bias"), out=lg_)
         loss = torch.zeros(1, device=dev, dtype=F32)
-        dlog = K.cross_entropy(lg_, Vv, mask_ans.to(dev).reshape(-1).contiguous(), loss, want_grad=backward, ld_d=Vpad)
+        hd = self._mlm_head_fwd(K.gather_rows(out.t, txt_rows, nr), nr, mask_ans.to(dev).reshape(-1).contiguous(), loss, backward)
+        lg_ = hd["logits"]
         if not backward:
             self.tape = []
             return loss, lg_[:, :Vv]
-        K.colsum(dlog, S.g(pm + "bias"), accumulate=True, M=nr, N=Vpad)
-        K.gemm(dlog, tn_, a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=nr, out=S.g(pm + "decoder.weight"), accumulate=True)
-        dtn = K.gemm(dlog, Wdec, b_kmajor=False, M=nr, N=Hd, K=Vpad if (Vpad % 64 == 0 and (Vpad - Vv) * Hd <= S.TAIL) else Vv)   # (see forward_backward)
-        dt_, _ = K.layernorm_bwd(dtn, t_, gm, mean_, rstd_, S.g(pm + "transform.LayerNorm.weight"), S.g(pm + "transform.LayerNorm.bias"))
-        du_ = K.gelu_bwd(dt_, u_)
-        dtxt = self._linear_bwd(du_, r_, pm + "transform.dense.weight", pm + "transform.dense.bias")
+        dtxt = self._mlm_head_bwd(hd)
         inv = self._cached(("qamc_inv", n_seq, Lq, Lv, X), lambda: self._inverse_rows(n_seq * Lq, [txt_rows]))
         out.g = K.gather_rows(dtxt, inv, n_seq * Lq)
         for _ in range(cfg["bert_layers"]):

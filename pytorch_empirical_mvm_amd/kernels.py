@@ -13,6 +13,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 _TYPES_CACHE = {}        # (mask-type list, device) -> int32 device tensor (no per-step host-to-device copy in masking())
 _WORKSPACE = {}          # device -> caller-owned split-K scratch (set by the engine; the C ABI never allocates)
+RESERVE_CUS = 0          # CUs the persistent grids leave free (vmvm_gemm_desc.reserve_cus); dist.GradReducer raises it while a collective is in flight
 
 
 def set_workspace(t):
@@ -66,6 +67,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
     d.in_fp8, d.alpha = int(fp8), float(alpha)
     d.a_relu = int(a_relu)
     d.aux_code8 = int(code8)
+    d.reserve_cus = RESERVE_CUS
     if code8:
         t = aux if act == 3 else out_preact
         assert t is None or t.dtype == torch.uint8, "code8: the saved tensor is uint8"
@@ -149,6 +151,7 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
     d.x_fp32 = int(X.dtype == F32)
     ws = _WORKSPACE.get(dY.device)
     d.workspace, d.workspace_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
+    d.reserve_cus = RESERVE_CUS
     L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
     return dX, dX2
 
@@ -310,6 +313,12 @@ def cast_bf16(src, dst=None):
     if dst is None:
         dst = torch.empty(src.shape, device=src.device, dtype=BF16)
     L.check(L.load().vmvm_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()), "cast")
+    return dst
+
+
+def cast_f32(src, dst):
+    """dst f32 <- src bf16 (the reduced 16-bit gradient payload back into the f32 gradient arena)"""
+    L.check(L.load().vmvm_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()), "cast_f32")
     return dst
 
 

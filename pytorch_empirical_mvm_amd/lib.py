@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
                 ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
                 ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p),
-                ("in_fp8", c_int), ("alpha", c_float), ("a_relu", c_int), ("aux_code8", c_int)]
+                ("in_fp8", c_int), ("alpha", c_float), ("a_relu", c_int), ("aux_code8", c_int), ("reserve_cus", c_int)]
 
 
 class LnFwdDesc(C.Structure):
@@ -48,7 +48,7 @@ class LnBwdDesc(C.Structure):
                 ("pad_mode", c_int),
                 ("dX_add", c_void_p), ("ldadd", c_int),
                 ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int),
-                ("workspace", c_void_p), ("workspace_bytes", c_u64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_u64), ("reserve_cus", c_int)]
 
 
 class AttnFwdDesc(C.Structure):
@@ -105,6 +105,7 @@ _PROTOS = {
     "vmvm_argmax_pairs": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
+    "vmvm_cast_bf16_to_f32": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_add_bf16": ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_pool_grad_bf16": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_scatter_add_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),

@@ -196,7 +196,8 @@ class VIOLET_Pretrain(torch.nn.Module):
         loaded = torch.load(ckpt, map_location="cpu")
         if "SwinBERT" in os.path.splitext(os.path.basename(ckpt))[0]:
             loaded = swinbert_renames(loaded)
-        own = super().state_dict()
+        own = self.state_dict()              # the overridden one: arena parameters AND the frozen teachers (`dalle.encoder.*`,
+        #                                      `feature_model.*`), as the reference filters against self.state_dict() (model.py:309-341)
         toload = {k: v for k, v in loaded.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
         for k, dim in (("enc_img.emb_len", 1), ("enc_img.emb_pos", 2)):
             if k in loaded and k in own and tuple(loaded[k].shape) != tuple(own[k].shape):

@@ -17,8 +17,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+def _worker(rank, world, port, q, wire="f32"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VMVM_GRAD_WIRE=wire)
     from pytorch_empirical_mvm_amd import config as CFG
     from pytorch_empirical_mvm_amd import dist as D
     from pytorch_empirical_mvm_amd.engine import ParamStore
@@ -33,6 +33,12 @@ def _worker(rank, world, port, q):
     S.flat[:S.total].fill_(float(rank + 1))
     D.broadcast_(S.flat)
     red = D.GradReducer(S, "cpu")
+    assert red.wire == wire and (red.wire_buf is not None) == (wire == "bf16") and red.reserve_cus == 0       # (CU reservation: nccl only)
+    if wire == "bf16":
+        q.put((rank, _bf16_wire_checks(D, S, red, mine, rank, world)))
+        D.barrier()
+        torch.distributed.destroy_process_group()
+        return
     red.reduce_other()
     mid = S.grad[:S.total].clone()
     # phase 2a: the Swin tail (stages >= n-2 + final norm) as soon as its gradients are final, 2b: the rest
@@ -72,12 +78,35 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
+def _bf16_wire_checks(D, S, red, mine, rank, world):
+    """the 16-bit payload (utils/deepspeed.py:11-30 reduces fp16 gradients): every trainable segment = sum over ranks of the
+    bf16-ROUNDED local gradients, rounded to bf16 once more by the reduction -- identical bits on every rank; half the bytes."""
+    red.reduce_other(); red.reduce_swin_tail(); red.reduce_swin_and_wait()
+    locals_ = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)).to(torch.bfloat16) for k in range(world)]
+    want = (locals_[0].float() + locals_[1].float()).to(torch.bfloat16).float()
+    ok = True
+    for gi in range(4):
+        a, e = S.segments[gi]
+        ok &= torch.equal(S.grad[a:e], want[a:e])
+    a, e = S.segments[4]
+    ok &= torch.equal(S.grad[a:e], mine[a:e])                   # frozen segment: never cast, never reduced
+    ok &= red.wire_bytes == 2 * S.n_trainable                   # every trainable element crossed exactly once, 2 bytes each
+    ok &= abs(float((S.grad[:S.n_trainable] - (mine + 0)[:S.n_trainable]).abs().max())) > 0
+    # replicas agree bit for bit
+    chk = S.grad[:S.n_trainable].double().sum().view(1).clone()
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    torch.distributed.all_gather(both, chk)
+    ok &= bool(torch.equal(both[0], both[1]))
+    return bool(ok)
+
+
 @pytest.mark.timeout(300)
-def test_two_phase_gradient_reduction_world2_gloo():
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+def test_two_phase_gradient_reduction_world2_gloo(wire):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, wire)) for r in range(world)]
     for p in ps:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]

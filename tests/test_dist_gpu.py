@@ -19,18 +19,21 @@ def _port():
     return p
 
 
-def _run(script_args, timeout):
-    env = dict(os.environ, VMVM_DIST_BACKEND="gloo", VMVM_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(script_args, timeout, **extra):
+    env = dict(os.environ, VMVM_DIST_BACKEND="gloo", VMVM_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_gradient_mean_and_identical_replicas():
-    p = _run(["tools/dp_check.py"], 500)
+@pytest.mark.parametrize("wire,cus", [("f32", "0"), ("bf16", "16")], ids=["f32-wire", "bf16-wire+16-CUs-reserved"])
+def test_two_ranks_gradient_mean_and_identical_replicas(wire, cus):
+    """the default multi-GPU configuration -- bf16 gradient payload, persistent grids 16 CUs short while a collective is pending --
+    and the full-precision one: reduced gradient = mean of the per-rank gradients, replicas bit-identical after 3 optimizer steps"""
+    p = _run(["tools/dp_check.py"], 500, VMVM_GRAD_WIRE=wire, VMVM_COMM_CUS=cus, VMVM_COMM_CUS_ANY_BACKEND="1")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "replicas identical=True" in p.stdout, p.stdout[-2000:]
+    assert "replicas identical=True" in p.stdout and f"wire={wire} reserve_cus={cus}" in p.stdout, p.stdout[-2000:]
 
 
 @pytest.mark.timeout(900)

@@ -334,3 +334,26 @@ def test_qamc_mlm_head_forward_loss_and_eval():
     assert sorted(k for k, p in params.items() if p.grad is None) == sorted(d["no_grad"].tolist())
     for k in ("fc_mtm.predictions.transform.dense.weight", "fc_mtm.predictions.decoder.weight", "fc_mtm.predictions.bias"):
         check_samp(d, "g." + k, params[k].grad, rtol=5e-3, atol=2e-6)
+
+
+def test_mlm_qa_variants_forward_loss_and_eval():
+    """SURVEY 8f.4 tail (mlm_qa.npz, from the reference's VIOLET_QAMC_MLM_Head_GEN / Agent_QAMC_MLM_Head_GEN and VIOLET_QAOE_LSMDC /
+    Agent_QAOE_LSMDC classes): logits of the single-sequence form, CE(ignore -1), the answer-token scores and accuracy of the
+    generative multiple-choice eval, top-1 / top-5 accuracy incl. get_top_k_acc's zero padding on a crafted case."""
+    d = load("mlm_qa.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    cfg["task"] = "qamc_mlm"
+    sd = R.make_state_dict(cfg)
+    img, _, _ = R.make_batch(cfg, 3)
+    txt, mask, mask_ans = torch.from_numpy(d["txt"]), torch.from_numpy(d["mask"]), torch.from_numpy(d["mask_ans"])
+    with torch.no_grad():
+        out = R.mlm_qa_forward(sd, cfg, img, txt, mask)
+    for tag in ("gen", "oe"):
+        check_samp(d, f"{tag}.out", out)
+        np.testing.assert_allclose(float(R.qamc_mlm_loss(out, mask_ans)), float(d[f"{tag}.loss"]), rtol=1e-5)
+    sc, pred = R.qamc_gen_predict(out, mask_ans, d["ans_tok_ids"].tolist())
+    np.testing.assert_allclose(sc.numpy(), d["gen.scores"], rtol=2e-3, atol=2e-4)
+    assert (pred == torch.from_numpy(d["ans_idx"])).float().tolist() == d["gen.ac"].tolist()
+    assert R.top_k_acc(out, mask_ans, 1) == d["oe.ac_1"].tolist() and R.top_k_acc(out, mask_ans, 5) == d["oe.ac_5"].tolist()
+    lo, an = torch.from_numpy(d["oe.toy_logits"]), torch.from_numpy(d["oe.toy_ans"])
+    assert R.top_k_acc(lo, an, 1) == d["oe.toy_ac1"].tolist() and R.top_k_acc(lo, an, 5) == d["oe.toy_ac5"].tolist()

@@ -55,7 +55,15 @@ def main():
     torch.cuda.synchronize()
     red = S.grad[:S.n_trainable] / world
     err = float((red - mean_ref).abs().max() / (mean_ref.abs().max() + 1e-12))
-    assert err < 1e-5, err
+    wire = agent.comm.wire
+    # f32 payload: the mean to rounding; bf16 payload: two roundings of 2^-9 relative each (cast + reduction), element by element
+    if wire == "f32":
+        assert err < 1e-5, err
+    else:
+        rel = float(((red - mean_ref).abs() / (mean_ref.abs() + 1e-3 * mean_ref.abs().max())).max())
+        assert rel < 1.2e-2 and agent.comm.wire_bytes == 2 * S.n_trainable, (rel, agent.comm.wire_bytes)
+    from pytorch_empirical_mvm_amd import kernels as K
+    assert K.RESERVE_CUS == 0                                 # back to the whole chip once the reductions have been waited for
     S.grad.zero_()
     for _ in range(3):
         r = agent.step(mb, is_train=True)
@@ -70,7 +78,8 @@ def main():
     t = torch.tensor([1.0 if same else 0.0], device=dev)
     dist.all_reduce(t)
     if rank == 0:
-        print(f"dp_check world={world} backend={dist.get_backend()} grad-mean rel err {err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
+        print(f"dp_check world={world} backend={dist.get_backend()} wire={wire} reserve_cus={agent.comm.reserve_cus} grad-mean rel err {err:.2e} "
+              f"replicas identical={int(t.item()) == world} losses {r}", flush=True)
     assert int(t.item()) == world
     dist.barrier()
     dist.destroy_process_group()

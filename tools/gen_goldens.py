@@ -857,6 +857,87 @@ def gold_qamc(size="tiny", T=4, B=2, O=3):
     print("qamc ok loss", float(ls), "gn", gsq ** 0.5, "pred", d["pred"].tolist(), "ans", ans_idx.tolist(), "no_grad", d["no_grad"].tolist())
 
 
+def mlm_qa_batch(cfg, B, n_ans=5):
+    """deterministic (B, X) single-sequence QA batch for the MLM-head variants: make_batch's text with one [MASK] (103) before [SEP],
+    labelled with the answer's vocabulary id (main_qaoe_tsv_mlm_head.py:26-60 / main_qamc_tsv_mlm_gen_ans_idx.py:30-82); the
+    generative multiple-choice form scores `n_ans` candidate answer tokens, `ans_idx` = position of the right one among them."""
+    img, txt, mask = R.make_batch(cfg, B)
+    txt, mask = txt.clone(), mask.clone()
+    X = txt.shape[1]
+    ans_tok_ids = [2000 + 37 * j for j in range(n_ans)]
+    ans_idx = torch.tensor([(3 * i + 1) % n_ans for i in range(B)])
+    mask_ans = torch.full((B, X), -1, dtype=torch.long)
+    for i in range(B):
+        pos = max(1, int(mask[i].sum()) - 2)
+        txt[i, pos] = 103
+        mask_ans[i, pos] = ans_tok_ids[int(ans_idx[i])]
+    return img, txt, mask, mask_ans, ans_idx, ans_tok_ids
+
+
+def _patch_ref_fusion(model):
+    def mask_ext(m, shape=None, device=None):
+        m = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - m.float()) * torch.finfo(torch.float32).min
+    model.mask_ext = mask_ext
+    enc_fwd = model.trsfr.forward
+    def trsfr_forward(feat, mask=None, output_attentions=False, **kw):
+        o = enc_fwd(feat, attention_mask=mask)
+        return {"last_hidden_state": (o[0] if not hasattr(o, "last_hidden_state") else o.last_hidden_state), "attentions": ()}
+    model.trsfr.forward = trsfr_forward
+
+
+def gold_mlm_qa(size="tiny", T=4, B=3):
+    """SURVEY 8f.4 tail: the two remaining MLM-head variants through the reference's own classes --
+    VIOLET_QAMC_MLM_Head_GEN.forward + Agent_QAMC_MLM_Head_GEN.step (main_qamc_tsv_mlm_gen_ans_idx.py:83-125: answer-token eval) and
+    VIOLET_QAOE_LSMDC.forward + Agent_QAOE_LSMDC.step / get_top_k_acc (main_qaoe_lsmdc_fib.py:55-115), which
+    Agent_QAOE_MLM_Head (main_qaoe_tsv_mlm_head.py:101-130) inherits unchanged."""
+    import main_qamc_tsv_mlm_gen_ans_idx as mg
+    import main_qaoe_lsmdc_fib as ml
+    cfg = R.make_cfg(size, T=T)
+    cfg["task"] = "qamc_mlm"
+    sd = R.make_state_dict(cfg)
+    args = ref_args(size, T, mvm_target="pixel")
+    args.update(num_video_tokens=-1, size_option=5, size_vocab=-1, deepspeed=False, freeze_violet=False)
+    img, txt, mask, mask_ans, ans_idx, ans_tok_ids = mlm_qa_batch(cfg, B)
+    batch = dict(img=img, txt=txt, mask=mask, mask_ans=mask_ans, ans_idx=ans_idx)
+    d = dict(txt=txt.numpy(), mask=mask.numpy(), mask_ans=mask_ans.numpy(), ans_idx=ans_idx.numpy(), ans_tok_ids=np.array(ans_tok_ids))
+    outs = {}
+    for tag, mod, mcls, acls in (("gen", mg, "VIOLET_QAMC_MLM_Head_GEN", "Agent_QAMC_MLM_Head_GEN"), ("oe", ml, "VIOLET_QAOE_LSMDC", "Agent_QAOE_LSMDC")):
+        model = getattr(mod, mcls)(args, None).eval()
+        _patch_ref_fusion(model)
+        own = model.state_dict()
+        assert not [k for k in sd if k not in own]
+        model.load_state_dict(sd, strict=False)
+        agent = getattr(mod, acls).__new__(getattr(mod, acls))
+        agent.args, agent.model, agent.ans_tok_ids = args, model, ans_tok_ids
+        agent.forward_step = lambda b, m=model: m(b)
+        agent.loss_func = torch.nn.CrossEntropyLoss(ignore_index=-1)
+        with torch.no_grad():
+            r = agent.step(dict(batch), False)                      # the reference's own eval arithmetic
+        out, ans = model(dict(batch))
+        ls = agent.loss_func(out.flatten(0, len(out.shape) - 2), ans.flatten())
+        outs[tag] = out.detach()
+        d[f"{tag}.loss"] = np.array(float(ls.detach()))
+        if tag == "gen":
+            d["gen.ac"] = np.array(r, dtype=np.float64)
+            p = out[:, :, ans_tok_ids][ans != -1]
+            d["gen.scores"] = (p / p.sum(-1, keepdim=True)).detach().numpy().astype(np.float64)
+        else:
+            d["oe.ac_1"], d["oe.ac_5"] = np.array(r["ac_1"], dtype=np.float64), np.array(r["ac_5"], dtype=np.float64)
+            # top-k on a crafted (logits, answers) pair incl. a row without any answer: get_top_k_acc's padding rule
+            g = torch.Generator().manual_seed(3)
+            lo = torch.randn(4, 6, 50, generator=g)
+            an = torch.full((4, 6), -1, dtype=torch.long)
+            an[0, 2], an[1, 4], an[3, 1] = int(lo[0, 2].argmax()), int(lo[1, 4].topk(4).indices[3]), int(lo[3, 1].argmin())
+            d["oe.toy_logits"], d["oe.toy_ans"] = lo.numpy(), an.numpy()
+            d["oe.toy_ac1"] = np.array(agent.get_top_k_acc(lo, an, k=1), dtype=np.float64)
+            d["oe.toy_ac5"] = np.array(agent.get_top_k_acc(lo, an, k=5), dtype=np.float64)
+        put(d, f"{tag}.out", out, 512)
+    assert torch.equal(outs["gen"], outs["oe"])                     # the two variants share one forward
+    np.savez_compressed(os.path.join(OUT, "mlm_qa.npz"), **d)
+    print("mlm_qa ok", {k: (v.tolist() if v.size < 8 else v.shape) for k, v in d.items() if k.split(".")[-1] in ("loss", "ac", "ac_1", "ac_5", "toy_ac1", "toy_ac5")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -868,6 +949,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--qamc-only" in sys.argv:
         gold_qamc()
+        sys.exit(0)
+    if "--mlm-qa-only" in sys.argv:
+        gold_mlm_qa()
         sys.exit(0)
     if "--qaoe-only" in sys.argv:
         gold_qaoe()
@@ -905,4 +989,5 @@ if __name__ == "__main__":
     gold_retrieval()
     gold_qaoe()
     gold_qamc()
+    gold_mlm_qa()
     gold_tsv()
