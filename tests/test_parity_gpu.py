@@ -1,7 +1,19 @@
 """Parity of the HIP path (through the C ABI) against the reference-pinned goldens and the CPU oracle.
 
-Tolerances (bf16 activations, f32 accumulation / statistics): losses <= 2e-2 relative,
-activations / gradients cosine >= 0.999 (>= 0.99 for tiny-norm tensors), sampled elements within 5e-2 of the tensor scale."""
+Tolerances AS ASSERTED below (bf16 activations / MFMA inputs, f32 accumulation and statistics, against fp32 references):
+* losses: <= 2e-2 relative (+ 1e-3 .. 2e-3 absolute);
+* sampled outputs / gradients against the reference's fixtures (`_check_samples`): cosine >= 0.995 over the samples and every sample
+  within 2 * tol of the tensor scale, tol = 5e-2 unless a test states another (1e-1 where an L1 loss makes the gradient a sign);
+  the reduced-Swin gradient fixture: every sample within 8e-2 of the tensor scale for all but at most two tensors;
+* per-tensor gradients against the oracle's autograd: cosine >= 0.99 and norm within 5 % for every tensor whose gradient norm is
+  above 1e-3 of the largest (SURVEY.md section 9 suggests 0.999; what 24 bf16 blocks + 12 fusion layers deliver at temp = 0.05 scale
+  is measured per tensor in tests/test_round2_gpu.py: two thirds of the tensors above 0.9995, none below 0.99); global gradient
+  norm within 1 % (6 % at the reference's temp = 0.05, where the VTM branch is amplified 20x);
+* out_vtm: absolute 0.35 at logit scale 1 / temp = 20 (a difference of two bf16-rounded [CLS] states times 20);
+* the VTM head's fc.3.weight gradient (a difference of bf16-rounded activations): cosine >= 0.95; AdamW update direction after one
+  step (sign-like at step 1): cosine >= 0.85.
+Attention-probability dropout is quantised to p = 26/256 = 0.1016 with the matching keep scale 256/230 (unbiased; the reference's
+p = 0.1): tests/test_round3_gpu.py feeds the kernels' own masks to the oracle."""
 import os
 
 import numpy as np

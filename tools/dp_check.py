@@ -60,8 +60,9 @@ def main():
     if wire == "f32":
         assert err < 1e-5, err
     else:
-        rel = float(((red - mean_ref).abs() / (mean_ref.abs() + 1e-3 * mean_ref.abs().max())).max())
-        assert rel < 1.2e-2 and agent.comm.wire_bytes == 2 * S.n_trainable, (rel, agent.comm.wire_bytes)
+        mag = sum(g_.abs() for g_ in gather) / world           # rounding acts on each rank's term, not on the (possibly cancelling) mean
+        rel = float(((red - mean_ref).abs() / (mag + 1e-6 * mag.max())).max())
+        assert rel < 2.0 ** -7 and agent.comm.wire_bytes == 2 * S.n_trainable, (rel, agent.comm.wire_bytes)
     from pytorch_empirical_mvm_amd import kernels as K
     assert K.RESERVE_CUS == 0                                 # back to the whole chip once the reductions have been waited for
     S.grad.zero_()
