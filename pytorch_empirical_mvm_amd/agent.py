@@ -34,6 +34,8 @@ class Agent_Pretrain:
         if D.is_initialized():
             self.world_size, self.rank = D.world_size(), D.rank()
             self.comm = D.GradReducer(self.engine.store, self.engine.device)
+            if getattr(self.engine, "wstream", None) is not None:
+                self.comm.wait_streams.append(self.engine.wstream)      # weight gradients are produced on the engine's second stream
             D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
             self.engine.store.refresh_shadow()
             # DDP also broadcasts the frozen teachers' parameters (they are sub-modules of the wrapped model): without this, ranks

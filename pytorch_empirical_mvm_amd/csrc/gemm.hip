@@ -688,6 +688,9 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // fragments after the LDS read (fp16 builds: the block-input ReLU of the dVAE's residual path, encoder.py:27-28, without a pass
 // over the activation); one v_pk_max_f16 per MFMA, in its shadow.  F & EF_ARGMAX: instead of storing, each 64-column group of a
 // row leaves its (maximum, column) pair in C (f32 [M][ldc], pairs at 2 * (n / 64)) -- the 8192-wide logits are never written.
+#ifndef VMVM_PROBE_EPI
+#define VMVM_PROBE_EPI 0        /* probe builds only (tools/probe/gemm_probe.hip): 1 = no global stores, 2 = no epilogue math, 3 = neither (re-tiled classes) */
+#endif
 template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false, bool FP8 = false, int TM = 1, bool ARELU = false>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
   static_assert(TM == 1 || (TM == 2 && AK && BKM && !FP8 && !(F & EF_COLSUM)), "the 256x64 tile serves k-major x k-major operands");
@@ -1023,8 +1026,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
                           acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
             o[ii][jb] = make_uint4(0, 0, 0, 0); pr[ii][jb] = make_uint4(0, 0, 0, 0);
             if (rvalid[i] && n < N) {
+#if (VMVM_PROBE_EPI & 2)
+              o[ii][jb] = pack8<F16>(v);
+              pr[ii][jb] = make_uint4(gelu_code4(v[0], v[1], v[2], v[3]), gelu_code4(v[4], v[5], v[6], v[7]), 0, 0);
+#else
               if (code8) epi_math8<(F | EF_CODE8), F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
               else epi_math8<F, F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
+#endif
             }
           }
         }
@@ -1063,6 +1071,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma clang loop unroll(full)
             for (int s2 = 0; s2 < 2; ++s2) {
               const int ms = m0 + wm * 64 + hb * 32 + s2 * 16 + c8r, n_c = n0 + wn * 64 + c8g * 16;
+#if (VMVM_PROBE_EPI & 1)
+              asm volatile("" ::"v"(t2[s2].x), "v"(t2[s2].y), "v"(t2[s2].z), "v"(t2[s2].w));
+              continue;
+#endif
               if (ms < M && n_c + 16 <= N)
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)ms * p.ldc2 + n_c) = t2[s2];
               else if (ms < M && n_c + 8 <= N)
@@ -1083,6 +1095,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma clang loop unroll(full)
           for (int s4 = 0; s4 < 4; ++s4) {
             if (!svalid[s4]) continue;
+#if (VMVM_PROBE_EPI & 1)
+            asm volatile("" ::"v"(t[s4].x), "v"(t[s4].y), "v"(t[s4].z), "v"(t[s4].w));
+            continue;
+#endif
             if (pass == 0) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)sdst[s4] * p.ldc + n_s) = t[s4];
             else *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)srow[s4] * p.ldc2 + n_s) = t[s4];
           }

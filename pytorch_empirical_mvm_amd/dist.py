@@ -126,6 +126,7 @@ class GradReducer:
         # (VMVM_COMM_CUS_ANY_BACKEND: test hook -- the shared-GPU gloo test runs the short grids too)
         on = nccl or bool(os.environ.get("VMVM_COMM_CUS_ANY_BACKEND"))
         self.reserve_cus = (comm_cus() if (on and self.cuda) else 0) if reserve_cus is None else int(reserve_cus)
+        self.wait_streams = []                    # further producer streams (the engine's weight-gradient stream) a reduction must wait for
         self.collectives = 0                      # issued so far (tests / profiling)
         self.wire_bytes = 0
 
@@ -156,6 +157,8 @@ class GradReducer:
             return
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
+            for ws in self.wait_streams:
+                self.stream.wait_stream(ws)
             with torch.cuda.stream(self.stream):
                 for a, e in ranges:
                     self._reduce_range(a, e)

@@ -227,9 +227,18 @@ class VioletEngine:
         self.A8_SCALE = 16.0
         if self.fp8:
             self.store.enable_fp8()
+        # Weight-gradient stream: dW = dY^T X (+ the bias column sums) depend on nothing downstream in the backward, so they
+        # are enqueued on a second HIP stream and run NEXT TO the main stream's chain (input-gradient GEMMs, attention / LayerNorm
+        # backward): the tail rounds of the persistent GEMM grids and the memory- / latency-bound kernels between them get filled
+        # with MFMA work.  Joined before the gradient exchange / the optimizer.  VMVM_WGRAD_STREAM=0: everything on one stream.
+        self.wstream = None
+        self._wkeep = []                    # operands of weight-gradient launches still in flight (their memory must not be re-used yet)
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
             K.set_workspace(self.workspace)
+            if bool(cfg.get("wgrad_stream", os.environ.get("VMVM_WGRAD_STREAM", "1") != "0")):
+                self.wstream = torch.cuda.Stream(device=self.device)
+                self.workspace_w = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)  # the side stream's own split-K slabs
 
     # -------------------------------------------------------------- small helpers
     def _next_offset(self, n):
@@ -242,8 +251,25 @@ class VioletEngine:
             self._idx_cache[key] = fn()
         return self._idx_cache[key]
 
+    def _wgrad_launch(self, fn, operands, sync=False):
+        """run fn(workspace) -- weight-gradient launches -- on the side stream behind everything enqueued so far; `operands` stay
+        referenced until the join (the caching allocator would otherwise hand their memory to the main stream's next tensors)"""
+        if self.wstream is None or sync:
+            fn(None)
+            return
+        self.wstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.wstream):
+            fn(self.workspace_w)
+        self._wkeep.append(operands)
+
+    def _wgrad_join(self):
+        """the main stream waits for the weight gradients in flight (before the gradient exchange / norm / AdamW read them)"""
+        if self.wstream is not None and self._wkeep:
+            torch.cuda.current_stream().wait_stream(self.wstream)
+            self._wkeep = []
+
     def _linear_bwd(self, dy, x, wname, bname, *, w=None, gw=None, gb=None, M=None, row_scale=None, rows_per_scale=0,
-                    need_dx=True, dx_kw=None, wN=None, wT=None):
+                    need_dx=True, dx_kw=None, wN=None, wT=None, wsync=False):
         """dW += dy^T x ; db += colsum(dy) ; dx = dy W   (all on the MFMA GEMM, no transposed copies)."""
         S = self.store
         w = S.b(wname) if w is None else w
@@ -254,11 +280,15 @@ class VioletEngine:
         gbias = None
         if bname is not None or gb is not None:
             gbias = S.g(bname) if gb is None else gb
-            if row_scale is not None:                     # DropPath-weighted column sum: separate pass (the fused form is unweighted)
-                K.colsum(dy, gbias, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
-                gbias = None
-        # db = colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
-        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gbias)
+
+        def wgrad(ws):
+            gb_ = gbias
+            if gb_ is not None and row_scale is not None:   # DropPath-weighted column sum: separate pass (the fused form is unweighted)
+                K.colsum(dy, gb_, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
+                gb_ = None
+            # db = colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
+            K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gb_, workspace=ws)
+        self._wgrad_launch(wgrad, (dy, x, row_scale), sync=wsync)
         if not need_dx:
             return None
         wt = S.bt(wname) if (wname is not None and wT is None) else wT
@@ -564,8 +594,10 @@ class VioletEngine:
         n = hd["n"]
         gm = S.p(pm + "transform.LayerNorm.weight")
         Wdec = S.b(pm + "decoder.weight")
-        K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=n, N=Vpad)     # pad columns are zero and land in arena padding
-        K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=n, out=S.g(pm + "decoder.weight"), accumulate=True)
+        def dec_wgrad(ws):
+            K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=n, N=Vpad)     # pad columns are zero and land in arena padding
+            K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=n, out=S.g(pm + "decoder.weight"), accumulate=True, workspace=ws)
+        self._wgrad_launch(dec_wgrad, (hd["dlog"], hd["tn"]))
         # d(tn) = dlog . W over K = the PADDED vocabulary when that is a whole number of 64-wide K tiles (30522 -> 30528): the GEMM
         # then takes the direct-to-LDS kernel instead of the K % 64 != 0 fallback (497 -> 60 us).  Invariants this relies on:
         #  (i) the pad columns [Vv, Vpad) of dlog are exact zeros (vmvm_cross_entropy writes them);
@@ -785,7 +817,7 @@ class VioletEngine:
                 dx_q = K.dropout(dx_q, p_q, self.seed, off_q)
             gWq = torch.zeros((2 * Hd, Hd), device=dev, dtype=F32)
             gbq = torch.zeros(2 * Hd, device=dev, dtype=F32)
-            dr_q = self._linear_bwd(dx_q.view(n_mp, 2 * Hd), r_q, None, None, w=Wq, gw=gWq, gb=gbq)
+            dr_q = self._linear_bwd(dx_q.view(n_mp, 2 * Hd), r_q, None, None, w=Wq, gw=gWq, gb=gbq, wsync=True)    # (gWq / gbq are read right below)
             S.g("decoder_vq.0.weight", (2 * Hd, Hd)).index_add_(0, perm, gWq)          # undo the PixelShuffle row permutation
             S.g("decoder_vq.0.bias").index_add_(0, perm, gbq)
             out1.g.index_add_(0, prow.long(), dr_q)                                     # covered-patch rows (unique) of the fusion output
@@ -812,6 +844,7 @@ class VioletEngine:
             on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward
         while self.tape:
             self.tape.pop()()
+        self._wgrad_join()
         return losses, outs
 
     # -------------------------------------------------------------- downstream: text-to-video retrieval
@@ -874,6 +907,7 @@ class VioletEngine:
         pool.g = K.cast_bf16(dpool)
         while self.tape:
             self.tape.pop()()
+        self._wgrad_join()
         return loss, scores
 
     # -------------------------------------------------------------- downstream: open-ended video QA
@@ -924,6 +958,7 @@ class VioletEngine:
         pool.g = K.cast_bf16(dpool)
         while self.tape:
             self.tape.pop()()
+        self._wgrad_join()
         return loss, logits[:, :NV]
 
     # -------------------------------------------------------------- downstream: multiple-choice video QA, MLM-head form
@@ -967,6 +1002,7 @@ class VioletEngine:
         pool.g = K.cast_bf16(dpool)
         while self.tape:
             self.tape.pop()()
+        self._wgrad_join()
         return loss, lg_[:, :Vv]
 
     def _inverse_rows(self, n_rows, row_lists):

@@ -200,6 +200,7 @@ int main(int argc, char** argv) {
   else if (!strcmp(set, "big")) shapes = {{8192, 8192, 8192}, {4096, 4096, 4096}};
   else if (!strcmp(set, "k8")) shapes = {{8192, 8192, 8192}};
   else if (!strcmp(set, "fc1")) shapes = {{69120, 3072, 768}};
+  else if (!strcmp(set, "roof")) shapes = {{55296, 3072, 768}, {50176, 2048, 512}};
   else if (!strcmp(set, "step2")) shapes = {{55296, 3072, 768}, {55296, 768, 3072}, {55296, 2304, 768}, {55296, 768, 2304}, {55296, 768, 768}, {13824, 3072, 768},
                                             {13824, 768, 3072}, {13824, 2304, 768}, {13824, 768, 768}, {50176, 512, 512}, {12544, 1024, 4096}, {12544, 3072, 1024}};
   else shapes = {{69120, 3072, 768}, {69120, 768, 3072}, {69120, 2304, 768}, {69120, 768, 768}, {50176, 2048, 512}, {50176, 512, 2048}, {50176, 1536, 512},
@@ -242,8 +243,9 @@ int main(int argc, char** argv) {
       memset(&d, 0, sizeof(d));
       d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K; d.ldc = N; d.a_kmajor = 1; d.b_kmajor = 1;
       d.col_scale = 1.f; d.splitk = 1;
-      if (epi == 1) { d.bias = bias; d.act = 1; d.C2 = C2; d.ldc2 = N; }
-      if (epi == 2) { d.act = 3; d.aux = X; d.ldaux = N; }
+      const bool c8 = getenv("PROBE_CODE8") != nullptr;      // 8-bit GELU' codes: C2 / aux are byte tensors (the act-3 reference below does not apply then)
+      if (epi == 1) { d.bias = bias; d.act = 1; d.C2 = C2; d.ldc2 = N; d.aux_code8 = c8; }
+      if (epi == 2) { d.act = 3; d.aux = X; d.ldaux = N; d.aux_code8 = c8; }
       if (epi == 3) { d.bias = bias; d.resid = X; d.ldr = N; }
       std::vector<Variant> vs = epi == 0 ? variants<0>() : epi == 1 ? variants<(EF_BIAS | EF_ACT1 | EF_RS)>() : epi == 2 ? variants<(EF_ACT3 | EF_RS)>()
                                                                                                  : variants<(EF_BIAS | EF_RESID | EF_DROP | EF_RS | EF_MAP)>();
