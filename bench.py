@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x 3 (C2/C3)
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
 
 
 def pmc_traffic_bytes():
@@ -69,7 +69,7 @@ def synth_batch(args, B, device, seed):
 
 class InStepTimers:
     """HIP events (on the launching stream) around the roofline kernels INSIDE a real training step: the fusion FFN fc1 GEMM
-    (bias + GELU + saved 8-bit GELU' code; M = B*4*432 rows of the VTM pass, N = 3072, K = 768) and the AdamW launches."""
+    (bias + GELU + saved 8-bit GELU' code; M = B*(1+O)*432 rows: the B sequences of pass 1 and the B*O of the VTM pass in one batch, N = 3072, K = 768) and the AdamW launches."""
 
     def __init__(self, M):
         self.M, self.gemm, self.adamw = M, [], []
@@ -235,7 +235,7 @@ def main():
     # step is the same work).  EVERY rank runs it: the step holds the gradient collectives.
     O = min(B, 4)
     Lq = a.frames * (1 + (a.img // 32) ** 2) + 32
-    with InStepTimers(B * O * Lq) as tm:
+    with InStepTimers(B * (1 + O) * Lq) as tm:
         one_step(a.steps)
     torch.cuda.synchronize()
     if rank != 0:
@@ -246,7 +246,7 @@ def main():
     clips = B * world * a.steps
     value = clips / dt
     kt, kcalls, adamw_s, adamw_n = tm.results()
-    kflop = 2.0 * (B * O * Lq) * 3072 * 768
+    kflop = 2.0 * (B * (1 + O) * Lq) * 3072 * 768
     headline = a.size == "base" and a.frames == 8 and a.img == 224
     window = "(8,12,12)" if (a.size == "large" and a.img == 384) else "(8,7,7)"
     if headline:
@@ -268,10 +268,10 @@ def main():
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
-                     "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * O * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
+                     "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * (1 + O) * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
                                f"gemm_pers_kernel<k-major,k-major,F=bias|GELU|rowscale> 128x128 persistent, two workgroups per CU, re-tiled stores; "
                                f"average of the {kcalls} launches of one real step, HIP events on the launching stream",
-                     "algorithmic_bytes": int((B * O * Lq) * 768 * 2 + 3072 * 768 * 2 + (B * O * Lq) * 3072 * (2 + 1)),      # A + W read, bf16 output + 1-byte codes written
+                     "algorithmic_bytes": int((B * (1 + O) * Lq) * 768 * 2 + 3072 * 768 * 2 + (B * (1 + O) * Lq) * 3072 * (2 + 1)),      # A + W read, bf16 output + 1-byte codes written
                      # the dominant memory-bound kernel of the step, against HBM: fused clip + AdamW over the flat arena
                      # (f32 p, g, m, v read + p, m, v written + bf16 copy written = 30 B per parameter)
                      "hbm": {"bound": "hbm", "kernel": "adamw_kernel (4 launches over the parameter arena: clip coefficient + AdamW + bf16 copy)",

@@ -646,7 +646,7 @@ class VioletEngine:
             for k in range(O - 1):
                 pairs.append((i, int(negatives[i][k])))
         idx2 = np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs])
-        idx1_d, idx2_d = _dev_i32(idx1, dev), _dev_i32(idx2, dev)
+        idx1_d = _dev_i32(idx1, dev) if "smtm" in cfg.get("pretrain_tasks", ()) else None
         km_txt = (mask != 0).to(torch.uint8)
         km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
         tj_h = np.array([j for _, j in pairs], dtype=np.int64)
@@ -658,8 +658,17 @@ class VioletEngine:
             csr_d = _dev_i32(csr, dev)
             txt_off_d, txt_list_d = csr_d[:B + 1], csr_d[B + 1:]
 
-        out1, in1, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train)
-        out2, in2, _ = self.go_cross(pool, idx2_d, km2, B * O, Lq, train)
+        # ONE fusion pass over the B sequences of pass 1 (model.py:204-214 via main_pretrain.py:233) and the B*O sequences of the VTM
+        # pass (:243-259) together: sequences are independent through the encoder, so every layer kernel runs once on (1 + O) * B
+        # sequences instead of twice (the B-sequence launches filled 0.2 - 0.6 of a round of the persistent GEMM grids)
+        n1, n2 = B, B * O
+        idx12_d = _dev_i32(np.concatenate([idx1, idx2]), dev)
+        km12 = torch.cat([km1, km2], 0).contiguous()
+        out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train)
+        out1, out2 = V(out12.t[:n1 * Lq]), V(out12.t[n1 * Lq:])
+        if backward:
+            out12.g = torch.empty_like(out12.t)
+            out1.g, out2.g = out12.g[:n1 * Lq], out12.g[n1 * Lq:]                      # the heads write their halves in place
         use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
         if use_smtm:                            # third pass under the seq2seq mask (main_pretrain.py:238-240)
             out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train, causal_from=Lv)
@@ -809,7 +818,7 @@ class VioletEngine:
             inv3 = self._cached(("inv3", B, Lq, Lv, X), lambda: self._inverse_rows(B * Lq, [txt_rows]))
             out3.g = K.gather_rows(d3, inv3, B * Lq)
         inv1 = self._cached(("inv1", B, T, hw, Lq, Lv, X, use_vis), lambda: self._inverse_rows(B * Lq, [vis_rows, txt_rows] if use_vis else [txt_rows]))
-        out1.g = K.gather_rows(dcat, inv1, B * Lq)
+        K.gather_rows(dcat, inv1, B * Lq, out=out1.g)
         if use_vq and n_mp > 0:
             dh_q = self._linear_bwd(dlg_q, h_q, "fc_mvm.3.weight", "fc_mvm.3.bias", dx_kw=dict(act=4, aux=h_q))     # ReLU' folded into the dgrad
             dx_q = self._linear_bwd(dh_q, x_qd, "fc_mvm.1.weight", "fc_mvm.1.bias")
@@ -832,13 +841,14 @@ class VioletEngine:
         if p_fc > 0:
             dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
         inv2 = self._cached(("inv2", B * O, Lq, Lv), lambda: self._inverse_rows(B * O * Lq, [cls_rows]))
-        out2.g = K.gather_rows(dr_v, inv2, B * O * Lq)
+        K.gather_rows(dr_v, inv2, B * O * Lq, out=out2.g)
 
-        # encoders (tape holds: encode, pass-1 layers, pass-2 layers) -> run pass 2 and pass 1, then scatter into the pool
+        # encoders (tape holds: encode, the merged pass' layers (, the smtm pass' layers)) -> run them back, then gather into the pool
         n_layers = cfg["bert_layers"]
-        for _ in range((3 if use_smtm else 2) * n_layers):
+        for _ in range((2 if use_smtm else 1) * n_layers):
             self.tape.pop()()
-        pool.g = K.pool_grad(in1.g, in2.g, in3.g if use_smtm else None, B, O, Lv, X, txt_off_d, txt_list_d)
+        g12 = in12.g
+        pool.g = K.pool_grad(g12[:n1 * Lq], g12[n1 * Lq:], in3.g if use_smtm else None, B, O, Lv, X, txt_off_d, txt_list_d)
         self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
         if on_other_grads_ready is not None:
             on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward

@@ -329,9 +329,9 @@ def add_bf16(a, b, out=None):
     return out
 
 
-def gather_rows(src, idx, M, rows_out_per_batch=0, rows_in_per_batch=0):
+def gather_rows(src, idx, M, rows_out_per_batch=0, rows_in_per_batch=0, out=None):
     Cc = src.shape[1]
-    dst = torch.empty((M, Cc), device=src.device, dtype=BF16)
+    dst = torch.empty((M, Cc), device=src.device, dtype=BF16) if out is None else out
     L.check(L.load().vmvm_gather_rows_bf16(src.data_ptr(), _ld(src), idx.data_ptr(), dst.data_ptr(), Cc, M, Cc, rows_out_per_batch,
                                            rows_in_per_batch, L.stream()), "gather_rows")
     return dst

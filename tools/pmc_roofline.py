@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Launch the bench.py roofline kernels for rocprofv3 passes: the fusion FFN fc1 GEMM (bias + GELU + saved 8-bit GELU' code;
-M = 32 clips x 4 VTM sequences x 432 tokens = 55296, N = 3072, K = 768) and fused clip + AdamW over a 225 M parameter arena."""
+M = 32 clips x (1 + 4) sequences x 432 tokens = 69120, N = 3072, K = 768) and fused clip + AdamW over a 225 M parameter arena."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_empirical_mvm_amd import kernels as K
-M, N, Kd = 32 * 4 * 432, 3072, 768
+M, N, Kd = 32 * 5 * 432, 3072, 768
 A = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
 B = torch.randn(N, Kd, device="cuda").to(torch.bfloat16)
 bias = torch.randn(N, device="cuda")
