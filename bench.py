@@ -209,6 +209,7 @@ def main():
     mask_in_step = not a.host_masking
     gen = torch.Generator(device=device).manual_seed(88 + rank)
 
+
     def one_step(i):
         if mask_in_step:
             return agent.step(agent.masking_device(*raw[i % len(raw)], generator=gen), is_train=True, sync=False)

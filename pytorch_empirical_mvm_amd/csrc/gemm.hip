@@ -1392,6 +1392,34 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // the main loop of the other one on the CU, and since its stores are re-tiled it beats the ping-pong kernel's exposed store tail at
     // K < 2048 (55296 x 3072 x 768: 367 -> 348 us, tools/scratch/no_pp_compare.sh)
     if ((epi_need(dd) & EF_ACT1) && dd.C2 && dd.K < 2048) pays = false;
+    // Round quantisation of the one-workgroup-per-CU grid: 69120 x 768 is 810 tiles = 3.16 rounds of 256, i.e. a fourth round for 54
+    // tiles.  For long reductions the rows that fill WHOLE rounds go to the ping-pong kernel and the remaining rows (a short second
+    // launch) to the 128x128 kernel, whose 512 slots take them in one partial round of quarter-size tiles.  Measured
+    // (tools/scratch/msplit_probe.py): 69120 x 768 x 3072 404 -> 361 us, x 2304 280 -> 265 us; a loss at K = 768 and when the
+    // remainder is more than ~a quarter of a round (50176 x 512: 1.53 rounds).  Row-indexed epilogue operands move with the rows;
+    // the dropout stream is indexed by the absolute element (8-element blocks), so its offset moves by m_split * N / 8.
+    if (pays && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > 256 && !(dd.N & 7)) {
+      const int nbn_ = (dd.N + 255) / 256, nbm_ = (dd.M + 255) / 256;
+      const int tm_split = (int)(((tiles / 256) * 256) / nbn_);
+      const long rem_tiles = (long)(nbm_ - tm_split) * nbn_;
+      if (tm_split > 0 && tm_split < nbm_ && rem_tiles <= 64) {
+        const int m_split = tm_split * 256;
+        vmvm_gemm_desc d1 = dd;
+        d1.M = m_split;
+        const int rc1 = vmvm_gemm_pp(d1, epi_need(d1), st);
+        if (rc1 == VMVM_OK) {
+          vmvm_gemm_desc d2 = dd;
+          d2.M = dd.M - m_split;
+          d2.A = reinterpret_cast<const char*>(dd.A) + (size_t)m_split * dd.lda * 2;
+          d2.C = reinterpret_cast<char*>(dd.C) + (size_t)m_split * dd.ldc * 2;
+          if (dd.resid) d2.resid = reinterpret_cast<const char*>(dd.resid) + (size_t)m_split * dd.ldr * 2;
+          d2.offset = dd.offset + (uint64_t)m_split * (uint64_t)dd.N / 8;
+          d2.variant = 6;
+          return vmvm_gemm_bf16(&d2, stream);
+        }
+        if (rc1 != VMVM_ENOSUPPORT) return rc1;
+      }
+    }
     if (pays || dd.variant == 7) {
       const int rc_ = vmvm_gemm_pp(dd, epi_need(dd), st);
       if (rc_ != VMVM_ENOSUPPORT) return rc_;

@@ -237,7 +237,7 @@ class VioletEngine:
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
             K.set_workspace(self.workspace)
             if bool(cfg.get("wgrad_stream", os.environ.get("VMVM_WGRAD_STREAM", "1") != "0")):
-                self.wstream = torch.cuda.Stream(device=self.device)
+                self.wstream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("VMVM_WGRAD_PRIO", "0")))
                 self.workspace_w = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)  # the side stream's own split-K slabs
 
     # -------------------------------------------------------------- small helpers

@@ -308,6 +308,28 @@ def check_gemm_epilogues():
     RESULTS.append(("gemm dropout deterministic", 0, 1, not torch.equal(o, o2) or abs(frac - 0.1) > 0.01))
 
 
+def check_gemm_round_split():
+    """vmvm_gemm_bf16's whole-round split (rows that fill whole rounds of the 256-workgroup grid on the ping-pong kernel, the rest on
+    the 128x128 kernel): the output -- dropout mask, bias, residual included -- equals the one-launch result of the ping-pong kernel
+    (variant 7) at a shape that takes the split: 69120 x 768 x 2048 = 810 tiles = 3.16 rounds."""
+    M, N, K_ = 69120, 768, 2048
+    A, B = rnd(M, K_), rnd(N, K_, scale=0.05)
+    bias = torch.randn(N, device=dev)
+    r = rnd(M, N)
+    kw = dict(bias=bias, resid=r, dropout_p=0.1, seed=99, offset=4242)
+    one = K.gemm(A, B, variant=7, **kw)
+    two = K.gemm(A, B, **kw)
+    d1, d2 = K.gemm(A, B, variant=7, dropout_p=0.1, seed=99, offset=4242), K.gemm(A, B, dropout_p=0.1, seed=99, offset=4242)
+    same_mask = torch.equal(d1 == 0, d2 == 0) and abs(float((d2[65536:] == 0).float().mean()) - 0.1) < 0.01      # (no bias / residual: zero <=> dropped)
+    RESULTS.append(("gemm round split: dropout mask identical to the one-launch result", 0, 1, not same_mask))
+    rep("gemm round split vs one launch (bias + dropout + resid)", two, one.float())
+    idx = torch.tensor([0, 1, 65535, 65536, 65537, 69119], device=dev)
+    ref = (A[idx].float() @ B.float().t() + bias)
+    keep = ((one[idx].float() - r[idx].float()).abs() > 1e-6).float()
+    rep("gemm round split rows around the split vs fp32", two[idx], ref * keep / 0.9 + r[idx].float())
+    rep("gemm round split plain", K.gemm(A, B), K.gemm(A, B, variant=7).float())
+
+
 # ------------------------------------------------------------------ layernorm
 def check_ln():
     for C_, with_ws in ((96, False), (128, True), (256, True), (256, False), (512, False), (512, True), (768, True), (768, False), (1024, True), (2048, True), (3072, False), (3072, True)):
