@@ -107,7 +107,7 @@ class InStepTimers:
         return (sum(g) / len(g) if g else None), len(g), ad, n
 
 
-def cpu_baseline_worker(size, frames, threads, B=4, timed=2):
+def cpu_baseline_worker(size, frames, threads, B=4, timed=2, warmup=1):
     """CPU oracle ('port' of the reference algorithm, validated against the reference's own outputs) on this host: full train
     steps (fwd + loss + bwd + clip + AdamW, fp32) on a BOUNDED sample of the same workload: B = 4 clips (so that every clip runs its
     1 + O = 5 fusion sequences as at B = 32), one warm-up step + `timed` timed steps, `threads` torch threads."""
@@ -123,29 +123,38 @@ def cpu_baseline_worker(size, frames, threads, B=4, timed=2):
     mask = torch.ones_like(txt)
     mb = R.default_masking(cfg, img, txt, mask, seed=0)
     st, times = {}, []
-    for i in range(1 + timed):
+    for i in range(warmup + timed):
         t0 = time.time()
         R.train_step(sd, cfg, mb, st, i + 1, 100, negatives=R.vtm_negatives_default(B))
         times.append(time.time() - t0)
-    dt = sum(times[1:]) / timed
+    dt = sum(times[warmup:]) / timed
+    wtxt = f"after {warmup} warm-up of {times[0]:.1f} s" if warmup else "no warm-up step"
     print(json.dumps(dict(value=round(B / dt, 5), unit="clips/s", cores=threads, kind="port", s_per_step=round(dt, 2),
-                          sample=f"{timed} timed full fp32 train steps (after 1 warm-up of {times[0]:.1f} s) of oracle/violet_ref.py (fwd+loss+bwd+clip+AdamW), "
+                          sample=f"{timed} timed full fp32 train steps ({wtxt}) of oracle/violet_ref.py (fwd+loss+bwd+clip+AdamW), "
                                  f"Swin-{size} T={cfg['T']} 224^2, B={B} (5 fusion sequences per clip as in the GPU run), {threads} torch threads: "
                                  f"{dt:.1f} s/step")), flush=True)
 
 
 def cpu_baseline(size, frames, timeout_s=420):
-    """Runs the worker in a CHILD process (bounded by a timeout so the default bench run stays within minutes)."""
+    """Runs the worker in CHILD processes (bounded by a timeout so the default bench run stays within minutes): the figure at up to 32
+    threads (1 warm-up + 2 timed steps) and, beside it, ONE timed step at 8 threads -- the thread count of the survey's probe of the
+    reference itself (SURVEY 8d / BASELINE.md 3: 0.047 clips/s on 8 cores)."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 32)
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--size", size, "--frames", str(frames),
-                            "--threads", str(threads)], capture_output=True, text=True, timeout=timeout_s,
-                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
-    except Exception as e:
-        return {"value": None, "unit": "clips/s", "cores": threads, "kind": "port", "sample": f"not completed within {timeout_s}s: {type(e).__name__}"}
+
+    def run(threads, extra):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--size", size, "--frames", str(frames),
+                                "--threads", str(threads)] + extra, capture_output=True, text=True, timeout=timeout_s,
+                               env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            return json.loads(line)
+        except Exception as e:
+            return {"value": None, "unit": "clips/s", "cores": threads, "kind": "port", "sample": f"not completed within {timeout_s}s: {type(e).__name__}"}
+    res = run(min(os.cpu_count() or 1, 32), [])
+    if (os.cpu_count() or 1) > 8:
+        r8 = run(8, ["--cpu-timed", "1", "--cpu-warmup", "0"])
+        res["threads_8"] = {k: r8.get(k) for k in ("value", "unit", "cores", "s_per_step", "sample")}
+    return res
 
 
 def main():
@@ -164,9 +173,11 @@ def main():
                     "default: frozen HF Swin-B teacher) or 3d_feature (frozen VideoSwin-B teacher)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--cpu-timed", type=int, default=2)
+    ap.add_argument("--cpu-warmup", type=int, default=1)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
-        cpu_baseline_worker(a.size, a.frames, a.threads)
+        cpu_baseline_worker(a.size, a.frames, a.threads, timed=a.cpu_timed, warmup=a.cpu_warmup)
         return
 
     from pytorch_empirical_mvm_amd import config as CFG

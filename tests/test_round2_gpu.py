@@ -232,16 +232,17 @@ def test_dvae_native_tokenizer_vs_oracle_encoder():
 
 
 @pytest.mark.timeout(900)
-def test_rccl_world1_reducer_equals_no_reducer():
+@pytest.mark.parametrize("wire", ["bf16", "f32"])
+def test_rccl_world1_reducer_equals_no_reducer(wire):
     """RCCL (torch.distributed backend "nccl") initialised at world size 1 with the gradient reducer forced on (side-stream
     all-reduces hooked into the backward at the C2 shapes, B = 4): the reduced gradient equals the one of the run without a reducer,
     and three optimizer steps run through the whole path."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VMVM_FORCE_DIST="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VMVM_GRAD_WIRE=wire)
     p = subprocess.run([sys.executable, "tools/rccl_smoke.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "rccl world-1: identical=True" in p.stdout, p.stdout[-2000:]
+    assert f"rccl world-1: wire={wire} identical=True" in p.stdout, p.stdout[-2000:]
 
 
 def test_evaluate_and_eval_step_with_smtm_accuracy(tmp_path):
