@@ -184,6 +184,8 @@ static std::vector<Variant> variants() {
   v.push_back({"pp2_32x4", launch_pp_f<true, true, F, 2, 32, 4>});
   v.push_back({"pp2_64x2", launch_pp_f<true, true, F, 2, 64, 2>});
   v.push_back({"pp2_64x2_ne", launch_pp_f<true, true, F, 2, 64, 2, 1>});
+  v.push_back({"pp2_q64", launch_pp_f<true, true, F, 2, 64, 2, 8>});            // a quarter of the CUs (grid 64): per-tile time against the full grid's
+  v.push_back({"pp2_q64_ne", launch_pp_f<true, true, F, 2, 64, 2, 9>});
   return v;
 }
 
@@ -201,6 +203,7 @@ int main(int argc, char** argv) {
   else if (!strcmp(set, "k8")) shapes = {{8192, 8192, 8192}};
   else if (!strcmp(set, "fc1")) shapes = {{69120, 3072, 768}};
   else if (!strcmp(set, "roof")) shapes = {{55296, 3072, 768}, {50176, 2048, 512}};
+  else if (!strcmp(set, "stag")) shapes = {{69120, 3072, 768}, {69120, 2304, 768}, {65536, 768, 3072}, {50176, 1536, 512}};
   else if (!strcmp(set, "step2")) shapes = {{55296, 3072, 768}, {55296, 768, 3072}, {55296, 2304, 768}, {55296, 768, 2304}, {55296, 768, 768}, {13824, 3072, 768},
                                             {13824, 768, 3072}, {13824, 2304, 768}, {13824, 768, 768}, {50176, 512, 512}, {12544, 1024, 4096}, {12544, 3072, 1024}};
   else shapes = {{69120, 3072, 768}, {69120, 768, 3072}, {69120, 2304, 768}, {69120, 768, 768}, {50176, 2048, 512}, {50176, 512, 2048}, {50176, 1536, 512},
