@@ -1,0 +1,40 @@
+"""Race screen for the relaxed first-step wait of the 128x128 kernel (stores of the previous tile allowed in flight): the re-tiled epilogue
+classes at step shapes, 40 launches each, every output compared BITWISE with the first one and against an fp32 reference on sampled rows;
+a second process-wide pass runs them back to back with a memory-hungry kernel in between (uneven load)."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from pytorch_empirical_mvm_amd import kernels as K
+BF = torch.bfloat16
+torch.manual_seed(0)
+bad = 0
+for (M, N, Kd) in [(69120, 3072, 768), (50176, 2048, 512), (200704, 1024, 256), (802816, 512, 128), (4096 + 128, 768, 192)]:
+    A = (torch.randn(M, Kd, device="cuda") * 0.5).to(BF); W = (torch.randn(N, Kd, device="cuda") * 0.05).to(BF)
+    bias = torch.randn(N, device="cuda")
+    idx = torch.randint(0, M, (256,), device="cuda")
+    ref = A[idx].float() @ W.float().t() + bias
+    junk = torch.empty(256 << 20, device="cuda", dtype=torch.uint8)
+    for name, kw, refv in (("bias (qkv class)", dict(bias=bias, col_scale=0.5, col_scale_n=N // 3 // 8 * 8), None),
+                           ("fc1 + code8", dict(bias=bias, act=1, code8=True), torch.nn.functional.gelu(ref)),
+                           ("fc1 + bf16 pre", dict(bias=bias, act=1, code8=False), torch.nn.functional.gelu(ref))):
+        first = first2 = None
+        for it in range(40):
+            kw2 = dict(kw)
+            pre = None
+            if "act" in kw:
+                pre = torch.empty(M, N, device="cuda", dtype=torch.uint8 if kw["code8"] else BF)
+                kw2["out_preact"] = pre
+            out = K.gemm(A, W, variant=6, **kw2)
+            if it % 3 == 1:
+                junk.fill_(it)                      # uneven memory load between launches
+            if first is None:
+                first, first2 = out.clone(), (None if pre is None else pre.clone())
+                if refv is not None:
+                    err = float((out[idx].float() - refv).abs().max() / refv.abs().max())
+                    if err > 2e-2: bad += 1; print("MISMATCH vs fp32", M, N, Kd, name, err)
+            else:
+                if not torch.equal(out, first) or (pre is not None and not torch.equal(pre, first2)):
+                    bad += 1
+                    print("RACE?", M, N, Kd, name, "iteration", it, int((out != first).sum()))
+        print(f"ok   {M}x{N}x{Kd} {name}: 40 launches bit-identical" if bad == 0 else f"bad so far {bad}", flush=True)
+print("RACE SCREEN", "PASS" if bad == 0 else f"FAIL ({bad})")
+sys.exit(1 if bad else 0)
