@@ -793,7 +793,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   if (w >= x_cnt) return;
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
-  int prev_nst = 0;                                     // store instructions of the previous tile's epilogue still allowed in flight (see the K loop)
+#ifdef VMVM_PROBE_STAGGER   /* probe builds only: workgroup i of an XCD starts (i % P) / P of an estimated tile time late (are the two workgroups of a CU in lockstep?) */
+  {
+    const int tile64 = (nk - kt0) * 17 + 100;           // estimated tile time in 64-cycle units
+    const int wait64 = (li % VMVM_PROBE_STAGGER) * tile64 / VMVM_PROBE_STAGGER;
+    for (int t = 0; t < wait64; t += 100) __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
   unsigned voA[NA], voB[NB], nvoA[NA], nvoB[NB];
   int pyA[NA], pxA[NA], npyA[NA], npxA[NA];
@@ -854,14 +860,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       }
     }
     for (int kt = kt0; kt < nk; ++kt) {
-      // The first K step of a tile waits for its stage -- requested BEFORE the previous tile's epilogue -- not for that epilogue's
-      // stores: vmcnt retires in order, so "at most prev_nst outstanding" means the DMA pieces (older than the stores) have landed while
-      // the stores' write acknowledgements (2-3 k cycles) arrive under this step's MFMAs.  prev_nst is exact only for interior tiles
-      // of the re-tiled classes (every store instruction executes); 0 = wait for everything, as every later step does.
-      if (kt == kt0 && prev_nst == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (kt == kt0 && prev_nst == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (kt == kt0 && prev_nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // K tile `kt` landed for everyone; everyone left the other buffer
       const int cur = it & 1;
       const unsigned char* la = smem + cur * STAGE_BYTES;
@@ -1013,13 +1012,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     // are main-loop bound and the LDS round trip only adds latency), so they keep the direct stores.
     constexpr bool RT = TM == 1 && !F16 && !FP8 &&
                         (F == (EF_BIAS | EF_COLSCALE | EF_RS) || F == (EF_BIAS | EF_ACT1 | EF_RS) || F == (EF_ACT3 | EF_RS));
-    prev_nst = 0;
     if constexpr (RT) {
       unsigned char* stg = smem + 2 * STAGE_BYTES + wave * 4096;
       const int sr = lane >> 3, sg = lane & 7;             // store layout: row inside an 8-row group, 16-byte column group
       const bool has_pre = (F & EF_ACT1) && p.act == 1 && p.C2;
-      if (m0 + BM <= M && n0 + BN <= N && (nk - kt0) >= 2)  // interior tile: every store below executes (8 / 12 / 16 per wave)
-        prev_nst = 8 + (has_pre ? ((p.aux_code8 != 0) ? 4 : 8) : 0);
       const bool code8 = (F & (EF_ACT1 | EF_ACT3)) && p.aux_code8 != 0;     // 8-bit GELU' codes in C2 (act 1) / aux (act 3)
       const bool c8 = has_pre && code8;
       const int n_s = n0 + wn * 64 + sg * 8;

@@ -36,5 +36,28 @@ for (M, N, Kd) in [(69120, 3072, 768), (50176, 2048, 512), (200704, 1024, 256), 
                     bad += 1
                     print("RACE?", M, N, Kd, name, "iteration", it, int((out != first).sum()))
         print(f"ok   {M}x{N}x{Kd} {name}: 40 launches bit-identical" if bad == 0 else f"bad so far {bad}", flush=True)
+# the 256x256 ping-pong kernel (variant 7): plain / bias / fc1 + code8 / bias + dropout + residual
+for (M, N, Kd) in [(69120, 2304, 768), (65536, 768, 3072), (50176, 1536, 512), (4096 + 256, 768, 768)]:
+    A = (torch.randn(M, Kd, device="cuda") * 0.5).to(BF); W = (torch.randn(N, Kd, device="cuda") * 0.05).to(BF)
+    bias = torch.randn(N, device="cuda"); R = torch.randn(M, N, device="cuda").to(BF)
+    idx = torch.randint(0, M, (256,), device="cuda")
+    ref = A[idx].float() @ W.float().t()
+    for name, kw, refv in (("pp plain", dict(), ref), ("pp bias", dict(bias=bias), ref + bias), ("pp fc1 + code8", dict(bias=bias, act=1, code8=True), torch.nn.functional.gelu(ref + bias)),
+                           ("pp bias + drop + resid", dict(bias=bias, resid=R, dropout_p=0.1, seed=5, offset=77), None)):
+        first = first2 = None
+        for it in range(40):
+            kw2 = dict(kw); pre = None
+            if "act" in kw:
+                pre = torch.empty(M, N, device="cuda", dtype=torch.uint8); kw2["out_preact"] = pre
+            out = K.gemm(A, W, variant=7, **kw2)
+            if it % 3 == 1: junk.fill_(it)
+            if first is None:
+                first, first2 = out.clone(), (None if pre is None else pre.clone())
+                if refv is not None:
+                    err = float((out[idx].float() - refv).abs().max() / refv.abs().max())
+                    if err > 2e-2: bad += 1; print("MISMATCH vs fp32", M, N, Kd, name, err)
+            elif not torch.equal(out, first) or (pre is not None and not torch.equal(pre, first2)):
+                bad += 1; print("RACE?", M, N, Kd, name, "iteration", it, int((out != first).sum()))
+        print(f"ok   {M}x{N}x{Kd} {name}: 40 launches bit-identical" if bad == 0 else f"bad so far {bad}", flush=True)
 print("RACE SCREEN", "PASS" if bad == 0 else f"FAIL ({bad})")
 sys.exit(1 if bad else 0)
