@@ -282,17 +282,42 @@ class Agent_Pretrain:
         if self.args.max_grad_norm > 0:
             K.sumsq(S.grad[:S.n_trainable], self._sumsq)
         lrs = self.current_lrs()
-        for gi in range(4):
-            a, e = S.segments[gi]
-            if e > a:
-                K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
-                        beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
-                        grad_scale=gscale)
-        S.refresh_transposed()
-        if getattr(S, "shadow8", None) is not None:          # fp8 forward (config 5): the e4m3 weight copy follows the updated bf16 copy
-            K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE, out=S.shadow8[:S.total8])
+
+        def update(groups):
+            for gi in groups:
+                a, e = S.segments[gi]
+                if e > a:
+                    K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
+                            beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
+                            grad_scale=gscale)
+        eng = self.engine
+        split = getattr(eng, "wstream", None) is not None and getattr(S, "shadow8", None) is None and os.environ.get("VMVM_OPT_OVERLAP", "1") != "0"
+        if split:
+            # The next forward starts with the Video-Swin backbone, which reads Swin parameters only: the update of the other 137 M parameters
+            # (fusion encoder, heads, embeddings), their W^T copies and the zeroing of their gradients run on the engine's second stream
+            # beside it; engine.encode() waits for `other_ready` before the first non-Swin parameter is read.  (The clip coefficient is
+            # read from _sumsq by both halves: the side stream starts behind the norm.)
+            eng.wstream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(eng.wstream):
+                update((1, 3))
+                S.refresh_transposed("other")
+                for gi in (1, 3):
+                    a, e = S.segments[gi]
+                    S.grad[a:e].zero_()
+                eng.other_ready = torch.cuda.Event()
+                eng.other_ready.record()
+            update((0, 2))
+            S.refresh_transposed("swin")
+            for gi in (0, 2):
+                a, e = S.segments[gi]
+                S.grad[a:e].zero_()
+        else:
+            update(range(4))
+            S.refresh_transposed()
+            if getattr(S, "shadow8", None) is not None:      # fp8 forward (config 5): the e4m3 weight copy follows the updated bf16 copy
+                K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE, out=S.shadow8[:S.total8])
+            S.grad.zero_()
         self.sched_step += 1
-        S.grad.zero_()
 
     def grad_norm(self):
         return float(torch.sqrt(self._sumsq).item()) / self.world_size

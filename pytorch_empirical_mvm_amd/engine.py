@@ -153,14 +153,24 @@ class ParamStore:
                 for tc in range(-(-K_ // 64)):
                     ents.append((o, N_, K_, (tr << 16) | tc))
         self.ttable = torch.tensor(ents, dtype=torch.int32, device=self.device).contiguous() if ents else None
+        # the same table split by optimizer group family (swin = segments 0 / 2, other = 1 / 3): the two halves of the optimizer tail
+        # can then run on different streams (agent.backward_step)
+        def in_swin(o):
+            return any(a <= o < e for a, e in (self.segments[0], self.segments[2]))
+        sw = [e_ for e_ in ents if in_swin(e_[0])]
+        ot = [e_ for e_ in ents if not in_swin(e_[0])]
+        self.ttable_part = {"swin": torch.tensor(sw, dtype=torch.int32, device=self.device).contiguous() if sw else None,
+                            "other": torch.tensor(ot, dtype=torch.int32, device=self.device).contiguous() if ot else None}
 
-    def refresh_transposed(self):
+    def refresh_transposed(self, which=None):
+        """W^T copies from the bf16 shadow; which = None (all) / "swin" / "other" (one optimizer group family)"""
         if self.device.type != "cuda" or self.frozen:
             return
         if self.ttable is None and not self.tmap:
             self.build_transpose_table()
-        if self.ttable is not None:
-            K.transpose_batched(self.shadow, self.shadowT, self.ttable)
+        t = self.ttable if which is None else self.ttable_part[which]
+        if t is not None:
+            K.transpose_batched(self.shadow, self.shadowT, t)
 
     def bt(self, n):
         """W^T view [K,N] (or None when the weight has no transposed copy)."""
@@ -170,12 +180,16 @@ class ParamStore:
         return self.shadowT[o:o + N_ * K_].view(K_, N_)
 
     def load_state(self, sd):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)          # (an optimizer tail may still be updating part of the arena on the second stream)
         for n, (o, c, s) in self.index.items():
             if n in sd:
                 self.flat[o:o + c].copy_(sd[n].reshape(-1).to(self.device, F32))
         self.refresh_shadow()
 
     def state_dict(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)          # (part of the optimizer tail may still be running on the engine's second stream)
         return OrderedDict((n, self.p(n).detach().clone()) for n in self.index)
 
 
@@ -232,6 +246,7 @@ class VioletEngine:
         # backward): the tail rounds of the persistent GEMM grids and the memory- / latency-bound kernels between them get filled
         # with MFMA work.  Joined before the gradient exchange / the optimizer.  VMVM_WGRAD_STREAM=0: everything on one stream.
         self.wstream = None
+        self.other_ready = None             # event: the non-Swin half of the previous optimizer step (agent.backward_step) has finished on wstream
         self._wkeep = []                    # operands of weight-gradient launches still in flight (their memory must not be re-used yet)
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
@@ -435,6 +450,9 @@ class VioletEngine:
         X = txt.shape[1]
         Hd = cfg["hidden"]
         sw, dims, C8 = self.swin_forward(img, cov, dp_all)
+        if self.other_ready is not None:    # everything below reads non-Swin parameters: their AdamW update ran beside the Swin forward
+            torch.cuda.current_stream().wait_event(self.other_ready)
+            self.other_ready = None
         hw = dims[1] * dims[2]
         assert dims[1] == H // 32 and dims[2] == W // 32                       # model.py:34 hard-codes //32
         Lv = T * (1 + hw)

@@ -160,6 +160,9 @@ class VIOLET_Pretrain(torch.nn.Module):
         return feat_img, torch.ones(B, Lv, dtype=torch.long, device=dev), feat_txt, mask.to(dev)
 
     def state_dict(self, *a, **k):
+        ev = getattr(self.engine, "other_ready", None)       # the non-Swin half of the last optimizer step may still be running on the second stream
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         sd = super().state_dict(*a, **k)
         key = "fc_mtm.predictions.bias"
         prefix = k.get("prefix", "")

@@ -11,6 +11,6 @@ wait
 for rd in 1 2; do
   for e in 0 1 2 3; do
     echo "== VMVM_PROBE_EPI=$e (1 = no stores, 2 = no math) round $rd"
-    PROBE_CODE8=1 /tmp/gemm_probe_e$e roof 10 old128 3 2>&1 | grep -A1 "epi=plain\|epi=bias+gelu\|epi=act3"
+    PROBE_CODE8=1 /tmp/gemm_probe_e$e ${SET:-roof} 10 old128 3 2>&1 | grep -A1 "epi=plain\|epi=bias+gelu\|epi=act3"
   done
 done
