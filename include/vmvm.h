@@ -346,6 +346,21 @@ typedef struct {
 } vmvm_adamw_desc;
 int vmvm_adamw(const vmvm_adamw_desc* d, void* stream);
 
+/* Self-attention of ONE query position per sequence (HF BertSelfAttention, call site model.py:213, restricted to a single query row).
+ * The VTM pass reads the fusion encoder's output at the text [CLS] position only (main_pretrain.py:260), so in its last layer every other
+ * query row is dead code while K / V of all positions are still needed.  q: bf16 [nseq][ld_q] (head h at column h * head_dim); kv: bf16
+ * [nseq * L][ld_kv] with K of head h at column k_off + h * head_dim and V at v_off + h * head_dim; keymask u8 [nseq][L] or NULL;
+ * out: bf16 [nseq][ld_out]; probs / probs_drop: f32 [nseq][heads][L], the softmax before and after dropout (saved for the backward).
+ * Dropout: the Philox stream of the GEMM epilogues (element = ((seq * heads + h) * L + key), 8-element blocks from `offset`).
+ * bwd: dq bf16 [nseq][ld_dq]; dkv bf16 [nseq * L][ld_dkv], same column layout as kv, EVERY K / V element written (masked keys: zeros).
+ * head_dim 32 or 64, L <= 8192. */
+int vmvm_attn_query_row_fwd(const void* q, int32_t ld_q, const void* kv, int32_t ld_kv, int32_t k_off, int32_t v_off, const uint8_t* keymask,
+                            void* out, int32_t ld_out, float* probs, float* probs_drop, int32_t nseq, int32_t L, int32_t heads, int32_t head_dim,
+                            float scale, float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+int vmvm_attn_query_row_bwd(const void* dout, int32_t ld_dout, const void* q, int32_t ld_q, const void* kv, int32_t ld_kv, int32_t k_off, int32_t v_off,
+                            const float* probs, const float* probs_drop, void* dq, int32_t ld_dq, void* dkv, int32_t ld_dkv, int32_t nseq, int32_t L,
+                            int32_t heads, int32_t head_dim, float scale, void* stream);
+
 /* hardware probe used by tests: dumps the lane mapping of ds_read_b64_tr_b16 (out: 64*4 int32) */
 int vmvm_probe_tr16(int32_t* out, void* stream);
 

@@ -500,6 +500,145 @@ __global__ __launch_bounds__(256) void cast_fp8_kernel(const u16* __restrict__ s
   }
 }
 
+
+// ---------------------------------------------------------------- self-attention of ONE query position per sequence
+// HF BertSelfAttention (call site model.py:213) restricted to a single query row: the VTM pass (main_pretrain.py:243-262) reads the
+// fusion encoder's output at the text [CLS] position only, so in its LAST layer every other query row is dead code; K and V of all
+// positions are still needed.  One workgroup per (sequence, head): scores of the L keys against the one query (f32), softmax, dropout
+// on the probabilities (Philox stream of the GEMM epilogues: 8-element blocks, 16 bits per element), P V.  The probabilities before
+// (p) and after (pd = mask * p / keep) dropout are saved for the backward (L floats each per (sequence, head): nothing is recomputed).
+// HBM-bound by the K / V rows (read once, whole 128-byte lines for head_dim 64).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_qrow_fwd_kernel(const u16* __restrict__ q, int ld_q, const u16* __restrict__ kv, int ld_kv, int k_off, int v_off,
+                                                            const uint8_t* __restrict__ keymask, u16* __restrict__ out, int ld_out,
+                                                            float* __restrict__ probs, float* __restrict__ probs_drop, int L, int heads, float scale,
+                                                            float dropout_p, uint64_t seed, uint64_t offset) {
+  extern __shared__ float qsm[];                         // [HD] query, [L] pd, [4][HD] partial outputs
+  __shared__ float sh[4];
+  float* pdsm = qsm + HD;
+  float* part = pdsm + ((L + 3) & ~3);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads, tid = threadIdx.x;
+  if (tid < HD) qsm[tid] = bf2f(q[(size_t)seq * ld_q + h * HD + tid]);
+  __syncthreads();
+  const u16* kb = kv + (size_t)seq * L * ld_kv + k_off + h * HD;
+  const u16* vb = kv + (size_t)seq * L * ld_kv + v_off + h * HD;
+  // scores: thread-per-key, kept in LDS (pdsm doubles as the score row until the probabilities replace it)
+  float mx = -__builtin_inff();
+  for (int j = tid; j < L; j += 256) {
+    float a = 0.f;
+    const uint4* kr = reinterpret_cast<const uint4*>(kb + (size_t)j * ld_kv);
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      float f[8];
+      unpack_bf8(kr[c], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a = fmaf(f[e], qsm[c * 8 + e], a);
+    }
+    const bool ok = !keymask || keymask[(size_t)seq * L + j] != 0;
+    const float sj = ok ? a * scale : -__builtin_inff();
+    pdsm[j] = sj;                                        // (each thread re-reads only its own entries below: no barrier needed)
+    mx = fmaxf(mx, sj);
+  }
+  mx = block_max(mx, sh);
+  float sum = 0.f;
+  for (int j = tid; j < L; j += 256) { const float sj = pdsm[j]; const float e_ = (sj == -__builtin_inff()) ? 0.f : __expf(sj - mx); pdsm[j] = e_; sum += e_; }
+  sum = block_sum(sum, sh);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  const bool has_drop = dropout_p > 0.f;
+  const uint32_t thr = dropout_threshold(dropout_p);
+  const float keep = has_drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  for (int j = tid; j < L; j += 256) {
+    const float pj = pdsm[j] * inv;
+    float pd = pj;
+    if (has_drop) {
+      const uint64_t el = ((uint64_t)seq * heads + h) * (uint64_t)L + j;
+      uint32_t bits[8];
+      dropout_bits8(seed, offset, el >> 3, bits);
+      pd = bits[el & 7] < thr ? 0.f : pj * keep;
+    }
+    probs[((size_t)seq * heads + h) * L + j] = pj;
+    probs_drop[((size_t)seq * heads + h) * L + j] = pd;
+    pdsm[j] = pd;
+  }
+  __syncthreads();
+  // out[d] = sum_j pd[j] * v[j][d]: 4 groups of 64 threads take interleaved keys, lane = d (coalesced 128-byte rows)
+  {
+    const int grp = tid >> 6, d = tid & 63;
+    float acc = 0.f;
+    if (d < HD)
+      for (int j = grp; j < L; j += 4) acc = fmaf(pdsm[j], bf2f(vb[(size_t)j * ld_kv + d]), acc);
+    if (d < HD) part[grp * HD + d] = acc;
+  }
+  __syncthreads();
+  if (tid < HD) out[(size_t)seq * ld_out + h * HD + tid] = f2bf(part[tid] + part[HD + tid] + part[2 * HD + tid] + part[3 * HD + tid]);
+}
+
+// backward of the above: given d(out) of the one query row -> dq (that row), dK / dV of every position (written whole: masked keys get zeros)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_qrow_bwd_kernel(const u16* __restrict__ dout, int ld_dout, const u16* __restrict__ q, int ld_q,
+                                                            const u16* __restrict__ kv, int ld_kv, int k_off, int v_off,
+                                                            const float* __restrict__ probs, const float* __restrict__ probs_drop,
+                                                            u16* __restrict__ dq, int ld_dq, u16* __restrict__ dkv, int ld_dkv, int L, int heads, float scale) {
+  extern __shared__ float sm_[];                         // [HD] dout, [HD] q, [L] ds, [4][HD] partial dq
+  __shared__ float sh[4];
+  float* dosm = sm_;
+  float* qsm = sm_ + HD;
+  float* dssm = qsm + HD;
+  float* part = dssm + ((L + 3) & ~3);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads, tid = threadIdx.x;
+  if (tid < HD) { dosm[tid] = bf2f(dout[(size_t)seq * ld_dout + h * HD + tid]); qsm[tid] = bf2f(q[(size_t)seq * ld_q + h * HD + tid]); }
+  __syncthreads();
+  const u16* kb = kv + (size_t)seq * L * ld_kv + k_off + h * HD;
+  const u16* vb = kv + (size_t)seq * L * ld_kv + v_off + h * HD;
+  u16* dkb = dkv + (size_t)seq * L * ld_dkv + k_off + h * HD;
+  u16* dvb = dkv + (size_t)seq * L * ld_dkv + v_off + h * HD;
+  const float* pr = probs + ((size_t)seq * heads + h) * L;
+  const float* pdr = probs_drop + ((size_t)seq * heads + h) * L;
+  // dpd[j] = dout . v[j] ; dp[j] = dpd[j] * (pd[j] / p[j]) ; delta = sum_j pd[j] * dpd[j] ; ds[j] = p[j] * (dp[j] - delta) ; dv[j] = pd[j] * dout
+  float delta = 0.f;
+  for (int j = tid; j < L; j += 256) {
+    const uint4* vr = reinterpret_cast<const uint4*>(vb + (size_t)j * ld_kv);
+    float a = 0.f;
+    const float pdj = pdr[j];
+    uint4* dvr = reinterpret_cast<uint4*>(dvb + (size_t)j * ld_dkv);
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      float f[8], o[8];
+      unpack_bf8(vr[c], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a = fmaf(f[e], dosm[c * 8 + e], a); o[e] = pdj * dosm[c * 8 + e]; }
+      dvr[c] = pack_bf8(o);
+    }
+    dssm[j] = a;                                         // dpd[j] for now (own entries only)
+    delta = fmaf(pdj, a, delta);
+  }
+  delta = block_sum(delta, sh);
+  for (int j = tid; j < L; j += 256) {
+    const float pj = pr[j], pdj = pdr[j];
+    const float m = pj > 0.f ? pdj / pj : 0.f;           // dropout multiplier (0 or 1 / keep)
+    const float ds = pj * (dssm[j] * m - delta) * scale;
+    dssm[j] = ds;
+    uint4* dkr = reinterpret_cast<uint4*>(dkb + (size_t)j * ld_dkv);
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = ds * qsm[c * 8 + e];
+      dkr[c] = pack_bf8(o);
+    }
+  }
+  __syncthreads();
+  {
+    const int grp = tid >> 6, d = tid & 63;
+    float acc = 0.f;
+    if (d < HD)
+      for (int j = grp; j < L; j += 4) acc = fmaf(dssm[j], bf2f(kb[(size_t)j * ld_kv + d]), acc);
+    if (d < HD) part[grp * HD + d] = acc;
+  }
+  __syncthreads();
+  if (tid < HD) dq[(size_t)seq * ld_dq + h * HD + tid] = f2bf(part[tid] + part[HD + tid] + part[2 * HD + tid] + part[3 * HD + tid]);
+}
+
 // ---------------------------------------------------------------- optimizer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ partial) {
   __shared__ float sh[4];
@@ -817,6 +956,41 @@ extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int
   if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;
   hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst),
                      reinterpret_cast<const int4*>(table));
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_attn_query_row_fwd(const void* q, int32_t ld_q, const void* kv, int32_t ld_kv, int32_t k_off, int32_t v_off, const uint8_t* keymask,
+                                       void* out, int32_t ld_out, float* probs, float* probs_drop, int32_t nseq, int32_t L, int32_t heads, int32_t head_dim,
+                                       float scale, float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
+  if (!q || !kv || !out || !probs || !probs_drop || nseq <= 0 || L <= 0 || heads <= 0) return VMVM_EINVAL;
+  if (head_dim != 64 && head_dim != 32) return VMVM_ENOSUPPORT;
+  if (L > 8192 || (ld_kv & 7) || (k_off & 7) || (v_off & 7)) return VMVM_ENOSUPPORT;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return VMVM_EINVAL;
+  const size_t sm = (size_t)(head_dim + ((L + 3) & ~3) + 4 * head_dim) * sizeof(float);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(attn_qrow_fwd_kernel<64>, dim3(nseq * heads), dim3(256), sm, ST, reinterpret_cast<const u16*>(q), ld_q, reinterpret_cast<const u16*>(kv), ld_kv,
+                       k_off, v_off, keymask, reinterpret_cast<u16*>(out), ld_out, probs, probs_drop, L, heads, scale, dropout_p, seed, offset);
+  else
+    hipLaunchKernelGGL(attn_qrow_fwd_kernel<32>, dim3(nseq * heads), dim3(256), sm, ST, reinterpret_cast<const u16*>(q), ld_q, reinterpret_cast<const u16*>(kv), ld_kv,
+                       k_off, v_off, keymask, reinterpret_cast<u16*>(out), ld_out, probs, probs_drop, L, heads, scale, dropout_p, seed, offset);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_attn_query_row_bwd(const void* dout, int32_t ld_dout, const void* q, int32_t ld_q, const void* kv, int32_t ld_kv, int32_t k_off, int32_t v_off,
+                                       const float* probs, const float* probs_drop, void* dq, int32_t ld_dq, void* dkv, int32_t ld_dkv, int32_t nseq, int32_t L,
+                                       int32_t heads, int32_t head_dim, float scale, void* stream) {
+  if (!dout || !q || !kv || !probs || !probs_drop || !dq || !dkv || nseq <= 0 || L <= 0 || heads <= 0) return VMVM_EINVAL;
+  if (head_dim != 64 && head_dim != 32) return VMVM_ENOSUPPORT;
+  if (L > 8192 || (ld_kv & 7) || (ld_dkv & 7) || (k_off & 7) || (v_off & 7)) return VMVM_ENOSUPPORT;
+  const size_t sm = (size_t)(2 * head_dim + ((L + 3) & ~3) + 4 * head_dim) * sizeof(float);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(attn_qrow_bwd_kernel<64>, dim3(nseq * heads), dim3(256), sm, ST, reinterpret_cast<const u16*>(dout), ld_dout, reinterpret_cast<const u16*>(q), ld_q,
+                       reinterpret_cast<const u16*>(kv), ld_kv, k_off, v_off, probs, probs_drop, reinterpret_cast<u16*>(dq), ld_dq, reinterpret_cast<u16*>(dkv), ld_dkv,
+                       L, heads, scale);
+  else
+    hipLaunchKernelGGL(attn_qrow_bwd_kernel<32>, dim3(nseq * heads), dim3(256), sm, ST, reinterpret_cast<const u16*>(dout), ld_dout, reinterpret_cast<const u16*>(q), ld_q,
+                       reinterpret_cast<const u16*>(kv), ld_kv, k_off, v_off, probs, probs_drop, reinterpret_cast<u16*>(dq), ld_dq, reinterpret_cast<u16*>(dkv), ld_dkv,
+                       L, heads, scale);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

@@ -552,16 +552,88 @@ class VioletEngine:
         self.tape.append(bwd)
         return out
 
-    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0, att_out=None):
+    def _bert_layer_qrow(self, xv, nseq, Lq, qpos, keymask, l, train):
+        """HF BertLayer `l` for sequences of which ONLY the output at position `qpos` is read -- the VTM pass reads the encoder's last
+        hidden state at the text [CLS] position (main_pretrain.py:260: out[:, T*(1+hw), :]), so in the LAST fusion layer every other
+        query row of those sequences is dead code, forward and backward (their d(out) is zero).  K and V of every position are still
+        computed (one GEMM on the key / value rows of the fused QKV weight); the query, the attention row (`vmvm_attn_query_row_*`),
+        both dense layers, the FFN and both LayerNorms run on nseq rows instead of nseq * Lq.  Same arithmetic per row as
+        `_bert_layer`; returns V([nseq, H])."""
+        S, dev = self.store, self.device
+        pre = f"trsfr.layer.{l}."
+        Hd, nh = self.cfg["hidden"], CFG.BERT["heads"]
+        hd = Hd // nh
+        qn = [pre + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+        bn = [pre + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+        Wqkv, Gqkv = S.fused(S.shadow, qn, (3 * Hd, Hd)), S.fused(S.grad, qn, (3 * Hd, Hd))
+        bqkv, gbqkv = S.fused(S.flat, bn, (3 * Hd,)), S.fused(S.grad, bn, (3 * Hd,))
+        WT = S.bt(qn[0])                                                  # fused W^T [H, 3H] (or None)
+        p_h = CFG.BERT["hidden_dropout"] if train else 0.0
+        p_a = CFG.BERT["attn_dropout"] if train else 0.0
+        scale = 1.0 / math.sqrt(hd)
+        x = xv.t                                                          # [nseq * Lq, H]
+        rows = self._cached(("qrow", nseq, Lq, qpos), lambda: _dev_i32(np.arange(nseq) * Lq + qpos, dev))
+        kv = K.gemm(x, Wqkv[Hd:], bias=bqkv[Hd:])                         # K | V of every position  [nseq * Lq, 2H]
+        xc = K.gather_rows(x, rows, nseq)                                 # the query rows  [nseq, H]
+        q = K.gemm(xc, Wqkv[:Hd], bias=bqkv[:Hd])
+        o_att = self._next_offset(nseq * nh * Lq)
+        ctx, pr, prd = K.attn_query_row_fwd(q, kv, nseq, Lq, nh, hd, scale, k_off=0, v_off=Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att)
+        o1 = self._next_offset(nseq * Hd)
+        a = K.gemm(ctx, S.b(pre + "attention.output.dense.weight"), bias=S.p(pre + "attention.output.dense.bias"), resid=xc,
+                   dropout_p=p_h, seed=self.seed, offset=o1)
+        g1, b1 = S.p(pre + "attention.output.LayerNorm.weight"), S.p(pre + "attention.output.LayerNorm.bias")
+        x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
+        u = torch.empty((nseq, CFG.BERT["ffn"]), device=dev, dtype=BF16)
+        h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u)
+        o2 = self._next_offset(nseq * Hd)
+        f = K.gemm(h, S.b(pre + "output.dense.weight"), bias=S.p(pre + "output.dense.bias"), resid=x1, dropout_p=p_h, seed=self.seed, offset=o2)
+        g2, b2 = S.p(pre + "output.LayerNorm.weight"), S.p(pre + "output.LayerNorm.bias")
+        x2, mean2, rstd2 = K.layernorm_fwd(f, g2, b2, CFG.BERT["eps"])
+        out = V(x2)
+
+        def bwd():
+            df, dfm = K.layernorm_bwd(out.g, f, g2, mean2, rstd2, S.g(pre + "output.LayerNorm.weight"), S.g(pre + "output.LayerNorm.bias"),
+                                      want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o2)
+            dfm = df if dfm is None else dfm
+            du = self._linear_bwd(dfm, h, pre + "output.dense.weight", pre + "output.dense.bias", dx_kw=dict(act=3, aux=u))
+            dx1 = self._linear_bwd(du, x1, pre + "intermediate.dense.weight", pre + "intermediate.dense.bias", dx_kw=dict(resid=df))
+            da, dam = K.layernorm_bwd(dx1, a, g1, mean1, rstd1, S.g(pre + "attention.output.LayerNorm.weight"),
+                                      S.g(pre + "attention.output.LayerNorm.bias"), want_dX2=p_h > 0, dropout_p=p_h, seed=self.seed, offset=o1)
+            dam = da if dam is None else dam
+            dctx = self._linear_bwd(dam, ctx, pre + "attention.output.dense.weight", pre + "attention.output.dense.bias")
+            dq, dkv = K.attn_query_row_bwd(dctx, q, kv, pr, prd, nseq, Lq, nh, hd, scale, k_off=0, v_off=Hd)
+            # query projection: d(xc) = dq Wq + da (the residual of the attention block); key / value projection: d(x) = dkv Wkv
+            dxc = self._linear_bwd(dq, xc, None, None, w=Wqkv[:Hd], gw=Gqkv[:Hd], gb=gbqkv[:Hd], dx_kw=dict(resid=da),
+                                   wT=None if WT is None else WT[:, :Hd])
+            dx = self._linear_bwd(dkv, x, None, None, w=Wqkv[Hd:], gw=Gqkv[Hd:], gb=gbqkv[Hd:], wT=None if WT is None else WT[:, Hd:])
+            dx.index_add_(0, rows.long(), dxc)                            # (nseq rows; plumbing)
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out
+
+    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0, att_out=None, qrow_split=None):
         """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214).
         causal_from = Lv: the seq2seq mask of the smtm pass (main_pretrain.py:217-224, model.py:191-199)."""
         Hd = self.cfg["hidden"]
         x = K.gather_rows(pool.t, idx, nseq * Lq)
         xv = V(x)
         cur = xv
-        for l in range(self.cfg["bert_layers"]):
+        nl = self.cfg["bert_layers"]
+        for l in range(nl - 1 if qrow_split is not None else nl):
             cur = self._bert_layer(cur, nseq, Lq, keymask, l, train, causal_from, att_out)
-        return cur, xv, idx
+        if qrow_split is None:
+            return cur, xv, idx
+        # last layer: the first n1 sequences in full, of the others only the row at `qpos` (see _bert_layer_qrow)
+        n1, qpos = qrow_split
+        xa, xb = V(cur.t[:n1 * Lq]), V(cur.t[n1 * Lq:])
+        prev = cur
+
+        def join():                               # runs AFTER the two halves' backward closures: d(layer input) = their rows side by side
+            _acc(prev, torch.cat([xa.g, xb.g], 0))
+        self.tape.append(join)
+        out_a = self._bert_layer(xa, n1, Lq, keymask[:n1], nl - 1, train, causal_from, att_out)
+        out_b = self._bert_layer_qrow(xb, nseq - n1, Lq, qpos, keymask[n1:], nl - 1, train)
+        return (out_a, out_b), xv, idx
 
     @torch.no_grad()
     def get_att(self, img, txt, mask, train=True, dp_all=None, cov=None):
@@ -682,11 +754,22 @@ class VioletEngine:
         n1, n2 = B, B * O
         idx12_d = _dev_i32(np.concatenate([idx1, idx2]), dev)
         km12 = torch.cat([km1, km2], 0).contiguous()
-        out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train)
-        out1, out2 = V(out12.t[:n1 * Lq]), V(out12.t[n1 * Lq:])
-        if backward:
-            out12.g = torch.empty_like(out12.t)
-            out1.g, out2.g = out12.g[:n1 * Lq], out12.g[n1 * Lq:]                      # the heads write their halves in place
+        # In the LAST layer only the text [CLS] row of the VTM sequences is alive (the VTM head reads nothing else, :260): it runs as
+        # `_bert_layer_qrow` on n2 rows instead of n2 * Lq (`go_cross(qrow_split=...)`); results are those of the full layer.
+        ntape = len(self.tape)
+        qrow = os.environ.get("VMVM_QROW", "1") != "0"                             # (0: the whole last layer for every sequence, for A/B runs)
+        if qrow:
+            (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train, qrow_split=(n1, Lv))
+            if backward:
+                out1.g = torch.empty_like(out1.t)                                  # the heads write it in place
+        else:
+            out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train)
+            cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
+            out1, out2c = V(out12.t[:n1 * Lq]), V(K.gather_rows(out12.t[n1 * Lq:], cls_rows, n2))
+            if backward:
+                out12.g = torch.empty_like(out12.t)
+                out1.g = out12.g[:n1 * Lq]
+        n_fusion_closures = len(self.tape) - ntape
         use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
         if use_smtm:                            # third pass under the seq2seq mask (main_pretrain.py:238-240)
             out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train, causal_from=Lv)
@@ -712,8 +795,7 @@ class VioletEngine:
                 outs["out_smtm"] = h_smtm["logits"][:, :Vv].reshape(B, X, Vv)
 
         # ---- VTM head (main_pretrain.py:146-147,260-262,561)
-        cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
-        r_v = K.gather_rows(out2.t, cls_rows, B * O)
+        r_v = out2c.t                                    # [B*O, H]: the text [CLS] states of the VTM sequences
         p_fc = 0.1 if train else 0.0
         off_fc = self._next_offset(r_v.numel())
         r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
@@ -858,12 +940,14 @@ class VioletEngine:
         dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
         if p_fc > 0:
             dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
-        inv2 = self._cached(("inv2", B * O, Lq, Lv), lambda: self._inverse_rows(B * O * Lq, [cls_rows]))
-        K.gather_rows(dr_v, inv2, B * O * Lq, out=out2.g)
+        out2c.g = dr_v
+        if not qrow:
+            inv2 = self._cached(("inv2", B * O, Lq, Lv), lambda: self._inverse_rows(B * O * Lq, [cls_rows]))
+            K.gather_rows(dr_v, inv2, B * O * Lq, out=out12.g[n1 * Lq:])
 
         # encoders (tape holds: encode, the merged pass' layers (, the smtm pass' layers)) -> run them back, then gather into the pool
         n_layers = cfg["bert_layers"]
-        for _ in range((2 if use_smtm else 1) * n_layers):
+        for _ in range((n_layers if use_smtm else 0) + n_fusion_closures):
             self.tape.pop()()
         g12 = in12.g
         pool.g = K.pool_grad(g12[:n1 * Lq], g12[n1 * Lq:], in3.g if use_smtm else None, B, O, Lv, X, txt_off_d, txt_list_d)

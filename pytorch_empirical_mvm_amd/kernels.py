@@ -198,6 +198,28 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     return dqkv
 
 
+def attn_query_row_fwd(q, kv, nseq, Lq, heads, hd, scale, *, k_off, v_off, keymask=None, dropout_p=0.0, seed=0, offset=0):
+    """self-attention of ONE query position per sequence (see include/vmvm.h): q [nseq, heads*hd], kv [nseq*Lq, ld] -> (out [nseq, heads*hd],
+    probs, probs_drop f32 [nseq, heads, Lq])"""
+    out = torch.empty((nseq, heads * hd), device=q.device, dtype=BF16)
+    probs = torch.empty((nseq, heads, Lq), device=q.device, dtype=F32)
+    pdrop = torch.empty((nseq, heads, Lq), device=q.device, dtype=F32)
+    L.check(L.load().vmvm_attn_query_row_fwd(q.data_ptr(), _ld(q), kv.data_ptr(), _ld(kv), k_off, v_off, L.ptr(keymask), out.data_ptr(), _ld(out),
+                                             probs.data_ptr(), pdrop.data_ptr(), nseq, Lq, heads, hd, float(scale), float(dropout_p), seed, offset, L.stream()),
+            "attn_query_row_fwd")
+    return out, probs, pdrop
+
+
+def attn_query_row_bwd(dout, q, kv, probs, pdrop, nseq, Lq, heads, hd, scale, *, k_off, v_off):
+    """-> (dq [nseq, heads*hd], dkv [nseq*Lq, kv.shape[1]] with every K / V column of the layout written)"""
+    dq = torch.empty((nseq, heads * hd), device=q.device, dtype=BF16)
+    dkv = torch.empty((nseq * Lq, kv.shape[1]), device=q.device, dtype=BF16)
+    L.check(L.load().vmvm_attn_query_row_bwd(dout.data_ptr(), _ld(dout), q.data_ptr(), _ld(q), kv.data_ptr(), _ld(kv), k_off, v_off, probs.data_ptr(),
+                                             pdrop.data_ptr(), dq.data_ptr(), _ld(dq), dkv.data_ptr(), _ld(dkv), nseq, Lq, heads, hd, float(scale), L.stream()),
+            "attn_query_row_bwd")
+    return dq, dkv
+
+
 def masking(txt, u_type, u_txt, u_rm, u_bm, types, T, h, w, p, tokens):
     """vmvm_masking: txt (B,X) i64 on the device is updated in place; returns (ans_mtm i64 (B,X), cov u8 (B,T,h,w))."""
     B, X = txt.shape

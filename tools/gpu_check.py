@@ -517,6 +517,43 @@ def check_attn_bert():
     rep("bert attn dropout bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
 
 
+def check_attn_query_row():
+    """vmvm_attn_query_row_fwd / bwd (one query position per sequence: the VTM pass' last fusion layer) against torch fp32 with the
+    kernel's own dropout mask (probs_drop / probs): ragged key masks, head_dim 64 and 32, L = 432 and an odd 77"""
+    for (nseq, Lq, heads, hd, p) in [(5, 432, 12, 64, 0.1), (3, 77, 4, 32, 0.0), (2, 512, 2, 64, 0.25), (2, 2352, 12, 64, 0.1)]:
+        Hd = heads * hd
+        q = rnd(nseq, Hd)
+        kv = rnd(nseq * Lq, 2 * Hd + 64)[:, 32:32 + 2 * Hd + 8]          # a row pitch that is not the width (ld_kv != 2H), offset columns
+        k_off, v_off = 8, 8 + Hd
+        km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+        for s_ in range(nseq):
+            km[s_, Lq - 3 * s_ - 1:] = 0
+        scale = hd ** -0.5
+        out, pr, prd = K.attn_query_row_fwd(q, kv, nseq, Lq, heads, hd, scale, k_off=k_off, v_off=v_off, keymask=km, dropout_p=p, seed=7, offset=123)
+        qf = q.float().view(nseq, heads, hd).requires_grad_(True)
+        kvf = kv.float().clone().requires_grad_(True)
+        kf = kvf[:, k_off:k_off + Hd].reshape(nseq, Lq, heads, hd).permute(0, 2, 1, 3)
+        vf = kvf[:, v_off:v_off + Hd].reshape(nseq, Lq, heads, hd).permute(0, 2, 1, 3)
+        sc = torch.einsum("shd,shjd->shj", qf, kf) * scale
+        sc = sc.masked_fill(~km.bool()[:, None, :], float("-inf"))
+        pref = torch.softmax(sc, -1)
+        mult = torch.where(pr > 0, prd / pr.clamp_min(1e-30), torch.zeros_like(pr))      # the kernel's dropout multiplier (0 or 1 / keep)
+        tag = f"attn query-row nseq={nseq} L={Lq} h={heads} hd={hd} p={p}"
+        rep(tag + " probs", pr, pref.detach(), tol=2e-3)
+        if p > 0:
+            frac = float((mult[pr > 1e-12] == 0).float().mean())
+            RESULTS.append((tag + " drop fraction", frac, p, abs(frac - p) > 0.03))
+            RESULTS.append((tag + " kept scale", 0, 1, bool(((mult > 0) & ((mult - 1 / (1 - p)).abs() > 1e-3)).any())))
+        o_ref = torch.einsum("shj,shjd->shd", pref * mult, vf).reshape(nseq, Hd)
+        rep(tag + " out", out, o_ref.detach())
+        dout = rnd(nseq, Hd)
+        o_ref.backward(dout.float())
+        dq, dkv = K.attn_query_row_bwd(dout, q, kv, pr, prd, nseq, Lq, heads, hd, scale, k_off=k_off, v_off=v_off)
+        rep(tag + " dq", dq, qf.grad.reshape(nseq, Hd))
+        rep(tag + " dk", dkv[:, k_off:k_off + Hd], kvf.grad[:, k_off:k_off + Hd])
+        rep(tag + " dv", dkv[:, v_off:v_off + Hd], kvf.grad[:, v_off:v_off + Hd])
+
+
 def check_attn_stream():
     """Streaming attention kernels (L > 448, SURVEY C5 shapes): Swin-L-384 windows (8,12,12) = 1152 tokens with the 15x23x23 bias
     table and shift mask; fusion sequences of 16 x 384^2 clips (2352 tokens) and a ragged 600; and -- the dropout stream being a
