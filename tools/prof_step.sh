@@ -13,3 +13,4 @@ python3 $GRAFT_REPO_ROOT/tools/prof_neighbors.py $DB copyBuffer > $GRAFT_REPO_RO
 # the roofline kernel's instantiation also serves the Swin fc1 shapes: one duration cluster per shape (the fusion FFN fc1 of the VTM pass = the 12 per step around 350-390 us)
 python3 $GRAFT_REPO_ROOT/tools/prof_hist.py $DB gemm_pers_kernelILb1ELb1ELi37E > $GRAFT_REPO_ROOT/gpurun_out/step_roofline_kernel_clusters.txt 2>&1
 head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
+python3 $GRAFT_REPO_ROOT/tools/prof_streams.py $DB 400 > $GRAFT_REPO_ROOT/gpurun_out/step_streams.txt 2>&1
