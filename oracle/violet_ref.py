@@ -414,7 +414,9 @@ def window_attention(sd, p, x, mask, nh, win):
 
 
 def swin_block(sd, p, x, mask_matrix, nh, win_cfg, shift_cfg, dp_scale=None):
-    """SwinTransformerBlock3D.forward video_swin.py:206-263 ; dp_scale: (B,) DropPath scale or None (eval)."""
+    """SwinTransformerBlock3D.forward video_swin.py:206-263 ; dp_scale: None (eval), one (B,) DropPath scale vector used by both
+    branches, or a pair ((B,), (B,)) -- the reference calls drop_path twice per block with independent draws (:256 attention, :248 MLP)."""
+    dp_a, dp_m = (dp_scale if isinstance(dp_scale, (tuple, list)) else (dp_scale, dp_scale))
     B, D, H, W, C = x.shape
     ws, ss = get_window_size((D, H, W), win_cfg, shift_cfg)
     shortcut = x
@@ -437,15 +439,15 @@ def swin_block(sd, p, x, mask_matrix, nh, win_cfg, shift_cfg, dp_scale=None):
     else:
         x = sx
     x = x[:, :D, :H, :W, :]
-    if dp_scale is not None:
-        x = x * dp_scale.view(B, 1, 1, 1, 1)
+    if dp_a is not None:
+        x = x * dp_a.view(B, 1, 1, 1, 1)
     x = shortcut + x
     y = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
     y = F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
     y = F.gelu(y)
     y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
-    if dp_scale is not None:
-        y = y * dp_scale.view(B, 1, 1, 1, 1)
+    if dp_m is not None:
+        y = y * dp_m.view(B, 1, 1, 1, 1)
     return x + y
 
 

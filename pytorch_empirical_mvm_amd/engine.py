@@ -349,6 +349,9 @@ class VioletEngine:
         rc_np, rc0 = SI.rc_codes(N, win)
         rc = self._cached(("rc", N, win), lambda: _dev_i32(rc_np, dev))
         scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
+        # DropPath (video_swin.py:46-63): the block calls it TWICE -- on the attention branch (:256) and on the MLP branch (:248) -- with
+        # independent per-sample draws; `dp` = (scale vector of the attention branch, scale vector of the MLP branch), or one vector for both
+        dp, dp2 = (dp if isinstance(dp, (tuple, list)) else (dp, dp))
         x = xv.t
         g1, b1 = S.p(pre + "norm1.weight"), S.p(pre + "norm1.bias")
         xw, mean1, rstd1 = K.layernorm_fwd(x, g1, b1, 1e-5, M=B * Lp, C_=C, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0)
@@ -364,15 +367,15 @@ class VioletEngine:
         # whole-K-tile staging applies, the bf16 pre-activation otherwise
         c8 = getattr(self, "gelu_code8", True) and C % 64 == 0 and not S.frozen
         u = None if S.frozen else torch.empty((B * L, 4 * C), device=dev, dtype=torch.uint8 if c8 else BF16)      # frozen teacher: no backward, nothing saved
-        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp, rows_per_scale=L, code8=c8)
-        x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dp, rows_per_scale=L,
+        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp2, rows_per_scale=L, code8=c8)
+        x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dp2, rows_per_scale=L,
                     scale_bias_only=True, resid=x1)
         out = V(x2)
 
         def bwd():
             dx2 = out.g
-            du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dp, rows_per_scale=L,
-                                  dx_kw=dict(act=3, aux=u, row_scale=dp, rows_per_scale=L, code8=c8))
+            du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dp2, rows_per_scale=L,
+                                  dx_kw=dict(act=3, aux=u, row_scale=dp2, rows_per_scale=L, code8=c8))
             dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
             dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
             dx1w = K.gather_rows(dx1, src, B * Lp, Lp, L)
@@ -1134,11 +1137,13 @@ class VioletEngine:
         return np.stack([rng.permutation([j for j in range(B) if j != i])[:O - 1] for i in range(B)]) if O > 1 else np.zeros((B, 0), np.int64)
 
     def sample_drop_path(self, B, rng=None):
-        """video_swin.py:46-54 : per-sample keep mask floor(keep + U), scaled by 1/keep; one (B,) f32 vector per block."""
+        """video_swin.py:46-54 : per-sample keep mask floor(keep + U), scaled by 1/keep.  A block draws twice, in the order the reference's
+        forward calls drop_path (:256 attention branch, then :248 MLP branch): one ((B,), (B,)) pair of f32 vectors per block."""
         rng = rng or np.random
         rows = []
         for p in self.dpr:
             keep = 1.0 - p
-            rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
+            for _ in range(2):
+                rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
         t = _h2d(torch.from_numpy(np.stack(rows).astype(np.float32)), self.device)
-        return [t[i] for i in range(t.shape[0])]
+        return [(t[2 * i], t[2 * i + 1]) for i in range(t.shape[0] // 2)]

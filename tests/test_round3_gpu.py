@@ -66,17 +66,20 @@ def test_train_mode_step_vs_oracle():
     rng = np.random.RandomState(7)
     n_blk = sum(cfg["depths"])
     dpr = np.linspace(0, 0.2, n_blk)
-    scales = []
+    scales = []                                               # [block][branch: attention, MLP][clip] -- the block draws twice (:256, :248)
     for blk in range(n_blk):
         keep = 1.0 - dpr[blk]
-        u = rng.rand(B)
-        if blk in (1, 3, 5, 11, 20, 23):                      # forced drops, one clip each, alternating (stages 1,2,3,3,3,4)
-            u[blk % B] = 0.0
-        scales.append(np.floor(keep + u) / keep if dpr[blk] > 0 else np.ones(B))
-    scales = np.stack(scales).astype(np.float32)
-    assert (scales == 0).sum() >= 6 and (scales > 1).sum() >= 20
-    dp_ref = [torch.from_numpy(scales[i]) for i in range(n_blk)]
-    dp_dev = [torch.from_numpy(scales[i]).cuda() for i in range(n_blk)]
+        pair = []
+        for br in range(2):
+            u = rng.rand(B)
+            if blk in (1, 3, 5, 11, 20, 23) and br == blk % 2:    # forced drops, one clip and one branch each (stages 1,2,3,3,3,4)
+                u[(blk // 2) % B] = 0.0
+            pair.append(np.floor(keep + u) / keep if dpr[blk] > 0 else np.ones(B))
+        scales.append(pair)
+    scales = np.asarray(scales, dtype=np.float32)
+    assert (scales == 0).sum() >= 6 and (scales > 1).sum() >= 40 and not np.array_equal(scales[:, 0], scales[:, 1])
+    dp_ref = [(torch.from_numpy(scales[i, 0]), torch.from_numpy(scales[i, 1])) for i in range(n_blk)]
+    dp_dev = [(torch.from_numpy(scales[i, 0]).cuda(), torch.from_numpy(scales[i, 1]).cuda()) for i in range(n_blk)]
 
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ls = R.pretrain_losses(params, cfg, mb, negatives=neg, dp_scales=dp_ref)
