@@ -628,6 +628,8 @@ class VioletEngine:
             return cur, xv, idx
         # last layer: the first n1 sequences in full, of the others only the row at `qpos` (see _bert_layer_qrow)
         n1, qpos = qrow_split
+        if n1 == 0:                               # every sequence: only the row at `qpos` (retrieval / open-ended QA read the text [CLS] state only)
+            return (None, self._bert_layer_qrow(cur, nseq, Lq, qpos, keymask, nl - 1, train)), xv, idx
         xa, xb = V(cur.t[:n1 * Lq]), V(cur.t[n1 * Lq:])
         prev = cur
 
@@ -986,9 +988,10 @@ class VioletEngine:
         km_txt = (mask != 0).to(torch.uint8)
         tj = _h2d(torch.tensor([j for _, j in pairs]), dev)
         km = torch.cat([torch.ones(B * B, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
-        out, inn, _ = self.go_cross(pool, idx_d, km, B * B, Lq, train)
-        cls_rows = self._cached(("ret_cls", B, Lq, Lv), lambda: _dev_i32(np.arange(B * B) * Lq + Lv, dev))
-        r_v = K.gather_rows(out.t, cls_rows, B * B)
+        ntape = len(self.tape)
+        (_, outc), inn, _ = self.go_cross(pool, idx_d, km, B * B, Lq, train, qrow_split=(0, Lv))     # only the text [CLS] row of the last layer is read (:76)
+        n_closures = len(self.tape) - ntape
+        r_v = outc.t
         p_fc = 0.1 if train else 0.0
         off_fc = self._next_offset(r_v.numel())
         r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
@@ -1013,9 +1016,8 @@ class VioletEngine:
         dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
         if p_fc > 0:
             dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
-        inv = self._cached(("ret_inv", B, Lq, Lv), lambda: self._inverse_rows(B * B * Lq, [cls_rows]))
-        out.g = K.gather_rows(dr_v, inv, B * B * Lq)
-        for _ in range(cfg["bert_layers"]):
+        outc.g = dr_v
+        for _ in range(n_closures):
             self.tape.pop()()
         dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
         K.scatter_add_rows(inn.g, idx_d, dpool)
@@ -1043,9 +1045,10 @@ class VioletEngine:
         idx_d = self._cached(("qa_idx", B, Lv, X), lambda: _dev_i32(
             np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)]), dev))
         km = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), (mask != 0).to(torch.uint8)], 1).contiguous()
-        out, inn, _ = self.go_cross(pool, idx_d, km, B, Lq, train)
-        cls_rows = self._cached(("qa_cls", B, Lq, Lv), lambda: _dev_i32(np.arange(B) * Lq + Lv, dev))
-        r_v = K.gather_rows(out.t, cls_rows, B)
+        ntape = len(self.tape)
+        (_, outc), inn, _ = self.go_cross(pool, idx_d, km, B, Lq, train, qrow_split=(0, Lv))         # only the text [CLS] row of the last layer is read
+        n_closures = len(self.tape) - ntape
+        r_v = outc.t
         p_fc = 0.1 if train else 0.0
         off_fc = self._next_offset(r_v.numel())
         r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
@@ -1064,9 +1067,8 @@ class VioletEngine:
         dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
         if p_fc > 0:
             dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
-        inv = self._cached(("qa_inv", B, Lq, Lv), lambda: self._inverse_rows(B * Lq, [cls_rows]))
-        out.g = K.gather_rows(dr_v, inv, B * Lq)
-        for _ in range(cfg["bert_layers"]):
+        outc.g = dr_v
+        for _ in range(n_closures):
             self.tape.pop()()
         dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
         K.scatter_add_rows(inn.g, idx_d, dpool)
