@@ -346,6 +346,14 @@ typedef struct {
 } vmvm_adamw_desc;
 int vmvm_adamw(const vmvm_adamw_desc* d, void* stream);
 
+/* DropPath dead-clip elimination (video_swin.py:46-63,250-263: a clip whose stochastic-depth draw is 0 contributes nothing through that
+ * branch, forward or backward).  vmvm_expand_batch_map: out[j*len + t] = map[t] < 0 ? -1 : map[t] + list[j]*stride -- the per-clip window map
+ * of vmvm_layernorm_fwd / the proj GEMM's row_map turned into the absolute row map of the KEPT clips `list`, so the branch runs on them
+ * only.  vmvm_copy_batches_bf16: dst rows of the listed (dropped) clips = src rows (their identity path); rows_per_batch rows of C each. */
+int vmvm_expand_batch_map(const int32_t* map, int32_t len, const int32_t* list, int32_t n, int32_t stride, int32_t* out, void* stream);
+int vmvm_copy_batches_bf16(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, const int32_t* list, int32_t n, int32_t rows_per_batch,
+                           int32_t C, void* stream);
+
 /* Self-attention of ONE query position per sequence (HF BertSelfAttention, call site model.py:213, restricted to a single query row).
  * The VTM pass reads the fusion encoder's output at the text [CLS] position only (main_pretrain.py:260), so in its last layer every other
  * query row is dead code while K / V of all positions are still needed.  q: bf16 [nseq][ld_q] (head h at column h * head_dim); kv: bf16

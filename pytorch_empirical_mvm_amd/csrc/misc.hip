@@ -328,6 +328,28 @@ __global__ void gather_rows_kernel(const u16* __restrict__ src, int ld_src, cons
   *reinterpret_cast<uint4*>(dst + m * ld_dst + ch * 8) = v;
 }
 
+// ---- index plumbing of the DropPath dead-clip elimination (engine._swin_block): the attention branch of a Swin block runs on the clips
+// whose stochastic-depth draw kept them (video_swin.py:46-54: a dropped clip's branch output is multiplied by 0).
+// expand: out[j * len + t] = map[t] < 0 ? -1 : map[t] + list[j] * stride   (per-clip window map -> absolute row map of the kept clips)
+__global__ void expand_batch_map_kernel(const int32_t* __restrict__ map, int len, const int32_t* __restrict__ list, int n, int stride, int32_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * len) return;
+  const int j = (int)(i / len), t = (int)(i - (long)j * len);
+  const int v = map[t];
+  out[i] = v < 0 ? -1 : v + list[j] * stride;
+}
+// copy: dst rows of the listed clips = src rows of the same clips (identity path of the dropped clips); C % 8 == 0
+__global__ void copy_batches_kernel(const u16* __restrict__ src, int ld_src, u16* __restrict__ dst, int ld_dst, const int32_t* __restrict__ list, int n,
+                                    int rows, int C) {
+  const int nch = C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * rows * nch) return;
+  const int ch = (int)(i % nch);
+  const long r = i / nch;
+  const long row = (long)list[r / rows] * rows + (r % rows);
+  *reinterpret_cast<uint4*>(dst + row * ld_dst + ch * 8) = *reinterpret_cast<const uint4*>(src + row * ld_src + ch * 8);
+}
+
 __global__ void scatter_add_rows_kernel(const u16* __restrict__ src, int ld_src, const int32_t* __restrict__ idx, float* __restrict__ dst,
                                         int ld_dst, long M, int C) {
   const int nch = C / 8;
@@ -956,6 +978,20 @@ extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int
   if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;
   hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst),
                      reinterpret_cast<const int4*>(table));
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_expand_batch_map(const int32_t* map, int32_t len, const int32_t* list, int32_t n, int32_t stride, int32_t* out, void* stream) {
+  if (!map || !list || !out || len <= 0 || n <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(expand_batch_map_kernel, dim3(nblk((long)n * len, 256)), dim3(256), 0, ST, map, len, list, n, stride, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_copy_batches_bf16(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, const int32_t* list, int32_t n, int32_t rows_per_batch,
+                                      int32_t C, void* stream) {
+  if (!src || !dst || !list || n <= 0 || rows_per_batch <= 0 || C <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7)) return VMVM_EINVAL;
+  hipLaunchKernelGGL(copy_batches_kernel, dim3(nblk((long)n * rows_per_batch * (C / 8), 256)), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), ld_src,
+                     reinterpret_cast<u16*>(dst), ld_dst, list, n, rows_per_batch, C);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

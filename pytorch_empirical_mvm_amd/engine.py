@@ -201,6 +201,24 @@ class V:
         self.t, self.g = t, None
 
 
+class DropScale:
+    """One DropPath draw of a Swin block branch (video_swin.py:46-54): dev = f32 (B,) scales (0 or 1 / keep) on the device; host = the same
+    on the host (which clips were dropped is known WITHOUT a device round trip: the draw happens on the host); kept / dropped = int32 device
+    lists of clip indices; dev_kept = the kept clips' scales, compact."""
+    __slots__ = ("dev", "host", "kept", "dropped", "dev_kept", "n_kept")
+
+    def __init__(self, dev, host=None, kept=None, dropped=None, dev_kept=None):
+        self.dev = dev
+        self.host = dev.detach().float().cpu().numpy() if host is None else host       # (explicit tensors from tests: one small D2H)
+        self.n_kept = int((self.host != 0).sum())
+        if kept is None:
+            k = np.flatnonzero(self.host != 0).astype(np.int32)
+            d = np.flatnonzero(self.host == 0).astype(np.int32)
+            kept, dropped = _dev_i32(k, dev.device) if k.size else None, _dev_i32(d, dev.device) if d.size else None
+            dev_kept = dev[torch.from_numpy(k).long().to(dev.device)].contiguous() if k.size else None
+        self.kept, self.dropped, self.dev_kept = kept, dropped, dev_kept
+
+
 def _acc(v, g):
     v.g = g if v.g is None else K.add_bf16(v.g, g)
 
@@ -352,15 +370,41 @@ class VioletEngine:
         # DropPath (video_swin.py:46-63): the block calls it TWICE -- on the attention branch (:256) and on the MLP branch (:248) -- with
         # independent per-sample draws; `dp` = (scale vector of the attention branch, scale vector of the MLP branch), or one vector for both
         dp, dp2 = (dp if isinstance(dp, (tuple, list)) else (dp, dp))
+        # Dead clips of the attention branch: a clip whose DropPath draw is 0 gets x1 = x -- its LayerNorm, qkv, window attention and
+        # projection contribute nothing, forward or backward.  The draw is known on the host, so the branch runs on the KEPT clips only:
+        # the per-clip window map becomes the absolute row map of the kept clips (vmvm_expand_batch_map) for the gather-LayerNorm, the
+        # projection's un-gather epilogue and the backward's gather; the dropped clips' rows are copied (vmvm_copy_batches_bf16).
+        ds = dp if (isinstance(dp, DropScale) or dp is None) else DropScale(dp)
+        dpv = None if ds is None else ds.dev
+        dp2 = dp2.dev if isinstance(dp2, DropScale) else dp2
+        Bk = B if ds is None else ds.n_kept                    # clips the attention branch runs on
+        compact = ds is not None and Bk < B and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0"
+        if not compact:
+            Bk = B                                             # (VMVM_DROPPATH_DCE=0: every clip goes through the branch, dropped ones scaled by 0)
         x = xv.t
         g1, b1 = S.p(pre + "norm1.weight"), S.p(pre + "norm1.bias")
-        xw, mean1, rstd1 = K.layernorm_fwd(x, g1, b1, 1e-5, M=B * Lp, C_=C, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0)
-        qkv = K.gemm(xw, S.b(pre + "attn.qkv.weight"), bias=S.p(pre + "attn.qkv.bias"), col_scale=scale, col_scale_n=C)
         table = S.p(pre + "attn.relative_position_bias_table")
-        akw = dict(q_off=0, k_off=C, v_off=2 * C, bias_table=table, rc=rc, rc0=rc0, region=reg, n_win=nW, seq_scale=dp, seqs_per_scale=nW)
-        ao, lse = K.attention_fwd(qkv, B * nW, N, nh, C // nh, 0, scale, **akw)
-        x1 = K.gemm(ao, S.b(pre + "attn.proj.weight"), bias=S.p(pre + "attn.proj.bias"), row_scale=dp, rows_per_scale=Lp,
-                    scale_bias_only=True, resid=x, row_map=src, map_len=Lp, map_stride=L, out_rows=B * L)
+        if compact and Bk == 0:                                # every clip dropped: the branch is the identity
+            x1, src_k = x, None
+        else:
+            if compact:
+                src_k = K.expand_batch_map(src, ds.kept, Bk, L)        # [Bk * Lp] absolute rows (pads stay -1)
+                lnkw = dict(M=Bk * Lp, C_=C, nseg=1, src=src_k, rows_out_per_batch=Bk * Lp, rows_in_per_batch=B * L, pad_mode=0)
+                mapkw = dict(row_map=src_k, map_len=Bk * Lp, map_stride=0)
+                dpk = ds.dev_kept
+            else:
+                src_k = None
+                lnkw = dict(M=B * Lp, C_=C, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0)
+                mapkw = dict(row_map=src, map_len=Lp, map_stride=L)
+                dpk = dpv
+            xw, mean1, rstd1 = K.layernorm_fwd(x, g1, b1, 1e-5, **lnkw)
+            qkv = K.gemm(xw, S.b(pre + "attn.qkv.weight"), bias=S.p(pre + "attn.qkv.bias"), col_scale=scale, col_scale_n=C)
+            akw = dict(q_off=0, k_off=C, v_off=2 * C, bias_table=table, rc=rc, rc0=rc0, region=reg, n_win=nW, seq_scale=dpk, seqs_per_scale=nW)
+            ao, lse = K.attention_fwd(qkv, Bk * nW, N, nh, C // nh, 0, scale, **akw)
+            x1 = K.gemm(ao, S.b(pre + "attn.proj.weight"), bias=S.p(pre + "attn.proj.bias"), row_scale=dpk, rows_per_scale=Lp,
+                        scale_bias_only=True, resid=x, out_rows=B * L, **mapkw)
+            if compact:
+                K.copy_batches(x, x1, ds.dropped, B - Bk, L)          # identity path of the dropped clips
         g2, b2 = S.p(pre + "norm2.weight"), S.p(pre + "norm2.bias")
         y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5)
         # saved for the GELU backward: an 8-bit code of GELU'(fc1 output) (vmvm_gemm_desc.aux_code8) where the persistent kernel's
@@ -378,13 +422,19 @@ class VioletEngine:
                                   dx_kw=dict(act=3, aux=u, row_scale=dp2, rows_per_scale=L, code8=c8))
             dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
             dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
-            dx1w = K.gather_rows(dx1, src, B * Lp, Lp, L)
-            dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dp, rows_per_scale=Lp)
-            dqkv = K.attention_bwd(dao, qkv, ao, lse, B * nW, N, nh, C // nh, 0, scale,
+            if compact and Bk == 0:
+                _acc(xv, dx1)
+                return
+            dx1w = K.gather_rows(dx1, src_k, Bk * Lp) if compact else K.gather_rows(dx1, src, B * Lp, Lp, L)
+            dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp)
+            dqkv = K.attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, 0, scale,
                                    dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
             dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
+            bkw = dict(src=src_k, rows_out_per_batch=Bk * Lp, rows_in_per_batch=B * L) if compact else dict(src=src, rows_out_per_batch=Lp, rows_in_per_batch=L)
             dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
-                                    src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0, dX_add=dx1)
+                                    pad_mode=0, dX_add=dx1, **bkw)
+            if compact:
+                K.copy_batches(dx1, dx, ds.dropped, B - Bk, L)        # d(x) of the dropped clips = d(x1)
             _acc(xv, dx)
         self.tape.append(bwd)
         return out
@@ -1147,5 +1197,21 @@ class VioletEngine:
             keep = 1.0 - p
             for _ in range(2):
                 rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
-        t = _h2d(torch.from_numpy(np.stack(rows).astype(np.float32)), self.device)
-        return [(t[2 * i], t[2 * i + 1]) for i in range(t.shape[0] // 2)]
+        host = np.stack(rows).astype(np.float32)                       # [2 * blocks, B]
+        # one upload: the scales, the kept clips' scales (compact), and the kept / dropped clip lists of every draw
+        kept = [np.flatnonzero(r != 0).astype(np.int32) for r in host]
+        drop = [np.flatnonzero(r == 0).astype(np.int32) for r in host]
+        nr = host.shape[0]
+        pack_f = np.zeros((2, nr, B), np.float32)
+        pack_i = np.zeros((2, nr, B), np.int32)
+        pack_f[0] = host
+        for i in range(nr):
+            pack_f[1, i, :kept[i].size] = host[i, kept[i]]
+            pack_i[0, i, :kept[i].size] = kept[i]
+            pack_i[1, i, :drop[i].size] = drop[i]
+        tf = _h2d(torch.from_numpy(pack_f), self.device)
+        ti = _h2d(torch.from_numpy(pack_i), self.device)
+
+        def mk(i):
+            return DropScale(tf[0, i], host[i], ti[0, i], ti[1, i], tf[1, i])
+        return [(mk(2 * i), mk(2 * i + 1)) for i in range(nr // 2)]

@@ -198,6 +198,20 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     return dqkv
 
 
+def expand_batch_map(map_, list_, n, stride):
+    """absolute row map of the clips in `list_` (first n entries) from a per-clip map: out[j*len + t] = map[t] < 0 ? -1 : map[t] + list[j]*stride"""
+    out = torch.empty((n * map_.numel(),), device=map_.device, dtype=torch.int32)
+    L.check(L.load().vmvm_expand_batch_map(map_.data_ptr(), map_.numel(), list_.data_ptr(), n, stride, out.data_ptr(), L.stream()), "expand_batch_map")
+    return out
+
+
+def copy_batches(src, dst, list_, n, rows_per_batch):
+    """dst rows of the clips in `list_` (first n entries) = src rows of the same clips"""
+    L.check(L.load().vmvm_copy_batches_bf16(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), list_.data_ptr(), n, rows_per_batch, src.shape[1], L.stream()),
+            "copy_batches")
+    return dst
+
+
 def attn_query_row_fwd(q, kv, nseq, Lq, heads, hd, scale, *, k_off, v_off, keymask=None, dropout_p=0.0, seed=0, offset=0):
     """self-attention of ONE query position per sequence (see include/vmvm.h): q [nseq, heads*hd], kv [nseq*Lq, ld] -> (out [nseq, heads*hd],
     probs, probs_drop f32 [nseq, heads, Lq])"""

@@ -106,6 +106,8 @@ _PROTOS = {
     "vmvm_cast_f32_to_bf16": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_cast_bf16_to_f32": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_expand_batch_map": ([c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
+    "vmvm_copy_batches_bf16": ([c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_attn_query_row_fwd": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_u64, c_u64, c_void_p], c_int),
     "vmvm_attn_query_row_bwd": ([c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

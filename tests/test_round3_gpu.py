@@ -8,7 +8,8 @@ masks): output cosine >= 0.9995, input / parameter gradients cosine >= 0.995 and
 * `test_train_mode_step_vs_oracle`: config C2 at full width (Swin-B, 8 x 224^2, 432-token fusion sequences), B = 2, train mode with
   EXPLICIT DropPath scales (video_swin.py:46-63,250-263) handed to both sides, hidden / attention dropout forced off: the only test
   that runs the row-scale GEMM epilogue classes, the DropPath-weighted bias-gradient column sums and the per-clip scale of the
-  window-attention output end to end.
+  window-attention output end to end -- and, since the attention branch of a block runs on the kept clips only (dropped clips are
+  dead code there), the compact path with one clip kept and with none.
 * `test_fusion_layer_train_mode_dropout_vs_oracle`: one HF BertLayer (model.py:211-214) in train mode with dropout ON: the three
   Philox masks the kernels apply (attention probabilities, both dense outputs) are recovered from the kernels themselves
   (V = identity slices for the attention mask, a zero-operand GEMM with unit bias for the epilogue masks) and fed to the oracle's
@@ -74,6 +75,8 @@ def test_train_mode_step_vs_oracle():
             u = rng.rand(B)
             if blk in (1, 3, 5, 11, 20, 23) and br == blk % 2:    # forced drops, one clip and one branch each (stages 1,2,3,3,3,4)
                 u[(blk // 2) % B] = 0.0
+            if blk == 14 and br == 0:                             # ... and one attention branch with EVERY clip dropped (the branch is the identity)
+                u[:] = 0.0
             pair.append(np.floor(keep + u) / keep if dpr[blk] > 0 else np.ones(B))
         scales.append(pair)
     scales = np.asarray(scales, dtype=np.float32)
