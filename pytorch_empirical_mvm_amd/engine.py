@@ -376,7 +376,8 @@ class VioletEngine:
         # projection's un-gather epilogue and the backward's gather; the dropped clips' rows are copied (vmvm_copy_batches_bf16).
         ds = dp if (isinstance(dp, DropScale) or dp is None) else DropScale(dp)
         dpv = None if ds is None else ds.dev
-        dp2 = dp2.dev if isinstance(dp2, DropScale) else dp2
+        ds2 = dp2 if (isinstance(dp2, DropScale) or dp2 is None) else DropScale(dp2)
+        dp2 = None if ds2 is None else ds2.dev
         Bk = B if ds is None else ds.n_kept                    # clips the attention branch runs on
         compact = ds is not None and Bk < B and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0"
         if not compact:
@@ -406,22 +407,51 @@ class VioletEngine:
             if compact:
                 K.copy_batches(x, x1, ds.dropped, B - Bk, L)          # identity path of the dropped clips
         g2, b2 = S.p(pre + "norm2.weight"), S.p(pre + "norm2.bias")
-        y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5)
         # saved for the GELU backward: an 8-bit code of GELU'(fc1 output) (vmvm_gemm_desc.aux_code8) where the persistent kernel's
         # whole-K-tile staging applies, the bf16 pre-activation otherwise
         c8 = getattr(self, "gelu_code8", True) and C % 64 == 0 and not S.frozen
-        u = None if S.frozen else torch.empty((B * L, 4 * C), device=dev, dtype=torch.uint8 if c8 else BF16)      # frozen teacher: no backward, nothing saved
-        h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dp2, rows_per_scale=L, code8=c8)
-        x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dp2, rows_per_scale=L,
-                    scale_bias_only=True, resid=x1)
+        # the MLP branch on ITS kept clips (the second, independent draw): LayerNorm through an absolute identity map of the kept clips'
+        # rows, fc1 compact, fc2 scattering back through the same map (+ residual); one extra gather of d(x2) in the backward
+        Bm = B if ds2 is None else ds2.n_kept
+        compact2 = ds2 is not None and Bm < B and os.environ.get("VMVM_DROPPATH_DCE", "1") not in ("0", "attn")
+        if not compact2:
+            Bm = B
+        if compact2 and Bm == 0:
+            x2 = x1
+        else:
+            if compact2:
+                idm = self._cached(("idmap", L), lambda: _dev_i32(np.arange(L), dev))
+                map_m = K.expand_batch_map(idm, ds2.kept, Bm, L)
+                dpm = ds2.dev_kept
+                y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5, M=Bm * L, C_=C, nseg=1, src=map_m, rows_out_per_batch=Bm * L, rows_in_per_batch=B * L,
+                                                   pad_mode=0)
+                mkw = dict(row_map=map_m, map_len=Bm * L, map_stride=0, out_rows=B * L)
+            else:
+                map_m, dpm, mkw = None, dp2, {}
+                y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5)
+            u = None if S.frozen else torch.empty((Bm * L, 4 * C), device=dev, dtype=torch.uint8 if c8 else BF16)     # frozen teacher: no backward, nothing saved
+            h = K.gemm(y2, S.b(pre + "mlp.fc1.weight"), bias=S.p(pre + "mlp.fc1.bias"), act=1, out_preact=u, row_scale=dpm, rows_per_scale=L, code8=c8)
+            x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dpm, rows_per_scale=L,
+                        scale_bias_only=True, resid=x1, **mkw)
+            if compact2:
+                K.copy_batches(x1, x2, ds2.dropped, B - Bm, L)
         out = V(x2)
 
         def bwd():
             dx2 = out.g
-            du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dp2, rows_per_scale=L,
-                                  dx_kw=dict(act=3, aux=u, row_scale=dp2, rows_per_scale=L, code8=c8))
-            dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
-            dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
+            if compact2 and Bm == 0:
+                dx1 = dx2
+            else:
+                dx2c = K.gather_rows(dx2, map_m, Bm * L) if compact2 else dx2
+                du = self._linear_bwd(dx2c, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dpm, rows_per_scale=L,
+                                      dx_kw=dict(act=3, aux=u, row_scale=dpm, rows_per_scale=L, code8=c8))
+                dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
+                if compact2:
+                    dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), rows_in=B * L, nseg=1,
+                                             src=map_m, rows_out_per_batch=Bm * L, rows_in_per_batch=B * L, pad_mode=0, dX_add=dx2)
+                    K.copy_batches(dx2, dx1, ds2.dropped, B - Bm, L)
+                else:
+                    dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
             if compact and Bk == 0:
                 _acc(xv, dx1)
                 return

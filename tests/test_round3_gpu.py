@@ -75,7 +75,7 @@ def test_train_mode_step_vs_oracle():
             u = rng.rand(B)
             if blk in (1, 3, 5, 11, 20, 23) and br == blk % 2:    # forced drops, one clip and one branch each (stages 1,2,3,3,3,4)
                 u[(blk // 2) % B] = 0.0
-            if blk == 14 and br == 0:                             # ... and one attention branch with EVERY clip dropped (the branch is the identity)
+            if (blk == 14 and br == 0) or (blk == 17 and br == 1):  # ... and one attention / one MLP branch with EVERY clip dropped (identity)
                 u[:] = 0.0
             pair.append(np.floor(keep + u) / keep if dpr[blk] > 0 else np.ones(B))
         scales.append(pair)
