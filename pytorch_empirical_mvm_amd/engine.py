@@ -203,20 +203,27 @@ class V:
 
 class DropScale:
     """One DropPath draw of a Swin block branch (video_swin.py:46-54): dev = f32 (B,) scales (0 or 1 / keep) on the device; host = the same
-    on the host (which clips were dropped is known WITHOUT a device round trip: the draw happens on the host); kept / dropped = int32 device
-    lists of clip indices; dev_kept = the kept clips' scales, compact."""
-    __slots__ = ("dev", "host", "kept", "dropped", "dev_kept", "n_kept")
+    on the host (which clips were dropped is known WITHOUT a device round trip: the draw happens on the host); perm = int32 device list of
+    the clip indices, kept clips first, then the dropped ones; dev_perm = the scales in that order (zeros behind the kept ones)."""
+    __slots__ = ("dev", "host", "perm", "dev_perm", "n_kept")
 
-    def __init__(self, dev, host=None, kept=None, dropped=None, dev_kept=None):
+    def __init__(self, dev, host=None, perm=None, dev_perm=None):
         self.dev = dev
         self.host = dev.detach().float().cpu().numpy() if host is None else host       # (explicit tensors from tests: one small D2H)
         self.n_kept = int((self.host != 0).sum())
-        if kept is None:
-            k = np.flatnonzero(self.host != 0).astype(np.int32)
-            d = np.flatnonzero(self.host == 0).astype(np.int32)
-            kept, dropped = _dev_i32(k, dev.device) if k.size else None, _dev_i32(d, dev.device) if d.size else None
-            dev_kept = dev[torch.from_numpy(k).long().to(dev.device)].contiguous() if k.size else None
-        self.kept, self.dropped, self.dev_kept = kept, dropped, dev_kept
+        if perm is None:
+            order = np.concatenate([np.flatnonzero(self.host != 0), np.flatnonzero(self.host == 0)]).astype(np.int32)
+            perm = _dev_i32(order, dev.device)
+            dev_perm = dev[torch.from_numpy(order).long().to(dev.device)].contiguous()
+        self.perm, self.dev_perm = perm, dev_perm
+
+    def take(self, rows_per_clip, B):
+        """-> (n, kept list, their scales, dropped list, n_dropped): the clips a branch runs on -- the kept ones, rounded UP with dropped
+        clips (scale 0: computed and multiplied by zero, as every dropped clip is without the elimination) until n * rows_per_clip is a
+        multiple of 64: the row count is the K dimension of the branch's weight-gradient GEMMs, whose direct-to-LDS kernels need whole K tiles."""
+        need = 64 // math.gcd(rows_per_clip, 64)
+        n = min(B, -(-self.n_kept // need) * need)
+        return n, self.perm, self.dev_perm, self.perm[n:], B - n
 
 
 def _acc(v, g):
@@ -378,10 +385,12 @@ class VioletEngine:
         dpv = None if ds is None else ds.dev
         ds2 = dp2 if (isinstance(dp2, DropScale) or dp2 is None) else DropScale(dp2)
         dp2 = None if ds2 is None else ds2.dev
-        Bk = B if ds is None else ds.n_kept                    # clips the attention branch runs on
-        compact = ds is not None and Bk < B and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0"
-        if not compact:
-            Bk = B                                             # (VMVM_DROPPATH_DCE=0: every clip goes through the branch, dropped ones scaled by 0)
+        Bk, compact = B, False                                 # clips the attention branch runs on
+        if ds is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0":
+            Bk, kept_a, dpk_a, drop_a, nd_a = ds.take(math.gcd(L, Lp), B)                 # (both row counts, Bk * L and Bk * Lp, in whole K tiles)
+            compact = Bk < B
+            if not compact:
+                Bk = B                                         # (nothing to eliminate / VMVM_DROPPATH_DCE=0: dropped clips are scaled by 0)
         x = xv.t
         g1, b1 = S.p(pre + "norm1.weight"), S.p(pre + "norm1.bias")
         table = S.p(pre + "attn.relative_position_bias_table")
@@ -389,10 +398,10 @@ class VioletEngine:
             x1, src_k = x, None
         else:
             if compact:
-                src_k = K.expand_batch_map(src, ds.kept, Bk, L)        # [Bk * Lp] absolute rows (pads stay -1)
+                src_k = K.expand_batch_map(src, kept_a, Bk, L)         # [Bk * Lp] absolute rows (pads stay -1)
                 lnkw = dict(M=Bk * Lp, C_=C, nseg=1, src=src_k, rows_out_per_batch=Bk * Lp, rows_in_per_batch=B * L, pad_mode=0)
                 mapkw = dict(row_map=src_k, map_len=Bk * Lp, map_stride=0)
-                dpk = ds.dev_kept
+                dpk = dpk_a
             else:
                 src_k = None
                 lnkw = dict(M=B * Lp, C_=C, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L, pad_mode=0)
@@ -405,24 +414,26 @@ class VioletEngine:
             x1 = K.gemm(ao, S.b(pre + "attn.proj.weight"), bias=S.p(pre + "attn.proj.bias"), row_scale=dpk, rows_per_scale=Lp,
                         scale_bias_only=True, resid=x, out_rows=B * L, **mapkw)
             if compact:
-                K.copy_batches(x, x1, ds.dropped, B - Bk, L)          # identity path of the dropped clips
+                K.copy_batches(x, x1, drop_a, nd_a, L)                # identity path of the dropped clips
         g2, b2 = S.p(pre + "norm2.weight"), S.p(pre + "norm2.bias")
         # saved for the GELU backward: an 8-bit code of GELU'(fc1 output) (vmvm_gemm_desc.aux_code8) where the persistent kernel's
         # whole-K-tile staging applies, the bf16 pre-activation otherwise
         c8 = getattr(self, "gelu_code8", True) and C % 64 == 0 and not S.frozen
         # the MLP branch on ITS kept clips (the second, independent draw): LayerNorm through an absolute identity map of the kept clips'
         # rows, fc1 compact, fc2 scattering back through the same map (+ residual); one extra gather of d(x2) in the backward
-        Bm = B if ds2 is None else ds2.n_kept
-        compact2 = ds2 is not None and Bm < B and os.environ.get("VMVM_DROPPATH_DCE", "1") not in ("0", "attn")
-        if not compact2:
-            Bm = B
+        Bm, compact2 = B, False
+        if ds2 is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") not in ("0", "attn"):
+            Bm, kept_m, dpk_m, drop_m, nd_m = ds2.take(L, B)
+            compact2 = Bm < B
+            if not compact2:
+                Bm = B
         if compact2 and Bm == 0:
             x2 = x1
         else:
             if compact2:
                 idm = self._cached(("idmap", L), lambda: _dev_i32(np.arange(L), dev))
-                map_m = K.expand_batch_map(idm, ds2.kept, Bm, L)
-                dpm = ds2.dev_kept
+                map_m = K.expand_batch_map(idm, kept_m, Bm, L)
+                dpm = dpk_m
                 y2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, 1e-5, M=Bm * L, C_=C, nseg=1, src=map_m, rows_out_per_batch=Bm * L, rows_in_per_batch=B * L,
                                                    pad_mode=0)
                 mkw = dict(row_map=map_m, map_len=Bm * L, map_stride=0, out_rows=B * L)
@@ -434,7 +445,7 @@ class VioletEngine:
             x2 = K.gemm(h, S.b(pre + "mlp.fc2.weight"), bias=S.p(pre + "mlp.fc2.bias"), row_scale=dpm, rows_per_scale=L,
                         scale_bias_only=True, resid=x1, **mkw)
             if compact2:
-                K.copy_batches(x1, x2, ds2.dropped, B - Bm, L)
+                K.copy_batches(x1, x2, drop_m, nd_m, L)
         out = V(x2)
 
         def bwd():
@@ -449,7 +460,7 @@ class VioletEngine:
                 if compact2:
                     dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), rows_in=B * L, nseg=1,
                                              src=map_m, rows_out_per_batch=Bm * L, rows_in_per_batch=B * L, pad_mode=0, dX_add=dx2)
-                    K.copy_batches(dx2, dx1, ds2.dropped, B - Bm, L)
+                    K.copy_batches(dx2, dx1, drop_m, nd_m, L)
                 else:
                     dx1, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2)
             if compact and Bk == 0:
@@ -464,7 +475,7 @@ class VioletEngine:
             dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
                                     pad_mode=0, dX_add=dx1, **bkw)
             if compact:
-                K.copy_batches(dx1, dx, ds.dropped, B - Bk, L)        # d(x) of the dropped clips = d(x1)
+                K.copy_batches(dx1, dx, drop_a, nd_a, L)              # d(x) of the dropped clips = d(x1)
             _acc(xv, dx)
         self.tape.append(bwd)
         return out
@@ -1228,20 +1239,18 @@ class VioletEngine:
             for _ in range(2):
                 rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
         host = np.stack(rows).astype(np.float32)                       # [2 * blocks, B]
-        # one upload: the scales, the kept clips' scales (compact), and the kept / dropped clip lists of every draw
-        kept = [np.flatnonzero(r != 0).astype(np.int32) for r in host]
-        drop = [np.flatnonzero(r == 0).astype(np.int32) for r in host]
+        # one upload: the scales, and per draw the clip permutation (kept clips first) with the scales in that order
         nr = host.shape[0]
         pack_f = np.zeros((2, nr, B), np.float32)
-        pack_i = np.zeros((2, nr, B), np.int32)
+        pack_i = np.zeros((nr, B), np.int32)
         pack_f[0] = host
         for i in range(nr):
-            pack_f[1, i, :kept[i].size] = host[i, kept[i]]
-            pack_i[0, i, :kept[i].size] = kept[i]
-            pack_i[1, i, :drop[i].size] = drop[i]
+            order = np.concatenate([np.flatnonzero(host[i] != 0), np.flatnonzero(host[i] == 0)])
+            pack_i[i] = order
+            pack_f[1, i] = host[i, order]
         tf = _h2d(torch.from_numpy(pack_f), self.device)
         ti = _h2d(torch.from_numpy(pack_i), self.device)
 
         def mk(i):
-            return DropScale(tf[0, i], host[i], ti[0, i], ti[1, i], tf[1, i])
+            return DropScale(tf[0, i], host[i], ti[i], tf[1, i])
         return [(mk(2 * i), mk(2 * i + 1)) for i in range(nr // 2)]
