@@ -100,6 +100,10 @@ typedef struct {
    * persistent workgroups -- which split the tiles statically -- are all resident at once.  0: the whole chip.  Changes grid
    * sizes only, never results of the bf16-output classes; f32 split-K plans do not depend on it either. */
   int32_t reserve_cus;
+  /* with `colsum`: the column sums are accumulated as colsum[m] += colsum_scale * sum_k A(m,k); 0 is read as 1.  (A Swin branch that runs on
+   * its kept clips only has ONE DropPath scale for all its rows -- video_swin.py:46-54: 1 / keep_prob -- so its bias gradient, the
+   * scale-weighted column sum of dY, stays on the weight-gradient GEMM instead of a vmvm_colsum_bf16 pass with per-clip weights.) */
+  float colsum_scale;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 /* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never

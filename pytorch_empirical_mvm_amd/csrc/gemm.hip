@@ -15,6 +15,7 @@
 #include "common.h"
 #include "gemm_epi.h"
 
+int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* stream);      // misc.hip
 int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st);
 int vmvm_gemm_pp_fp8(const vmvm_gemm_desc& d, int need, hipStream_t st);      // gemm_pp.hip: 256x256 ping-pong main loop
 
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r;
-        if (m < M) atomicAdd(p.colsum + m, cs[i][0]);
+        if (m < M) atomicAdd(p.colsum + m, p.colsum_scale != 0.f ? cs[i][0] * p.colsum_scale : cs[i][0]);
       }
     }
     if constexpr ((F & EF_ARGMAX) != 0) {
@@ -1380,7 +1381,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     const bool plain_wgrad = !dd.b_kmajor && dd.out_fp32 && !dd.bias && !dd.col_scale_n && !dd.act && !dd.row_scale && dd.dropout_p <= 0.f &&
                              !dd.resid && !dd.row_map && !(dd.N & 7);
     if (!(pers && plain_wgrad)) {                        // not the fused build: one separate pass over A (= X of the column sum)
-      const int rc_ = vmvm_colsum_bf16(dd.A, dd.K, dd.M, dd.lda, nullptr, 0, dd.colsum, 1, stream);
+      const int rc_ = vmvm_colsum_scaled(dd.A, dd.K, dd.M, dd.lda, dd.colsum_scale != 0.f ? dd.colsum_scale : 1.f, dd.colsum, stream);
       if (rc_) return rc_;
       dd.colsum = nullptr;
     }

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
     if ((F & EF_COLSUM) && do_cs) {              // lanes l and l + 32 hold the two k-halves of column m = ... + (l & 31)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        const float t = csum[mb] + __shfl_xor(csum[mb], 32, 64);
+        float t = csum[mb] + __shfl_xor(csum[mb], 32, 64);
+        if (p.colsum_scale != 0.f) t *= p.colsum_scale;
         const int m = m0 + wr * 128 + mb * 32 + l31;
         if (hh == 0 && m < M) atomicAdd(p.colsum + m, t);
       }

@@ -336,7 +336,8 @@ __global__ void expand_batch_map_kernel(const int32_t* __restrict__ map, int len
   if (i >= (long)n * len) return;
   const int j = (int)(i / len), t = (int)(i - (long)j * len);
   const int v = map[t];
-  out[i] = v < 0 ? -1 : v + list[j] * stride;
+  const int b = list[j];                                   // (a negative entry is a padding clip: all its rows are -1)
+  out[i] = (v < 0 || b < 0) ? -1 : v + b * stride;
 }
 // copy: dst rows of the listed clips = src rows of the same clips (identity path of the dropped clips); C % 8 == 0
 __global__ void copy_batches_kernel(const u16* __restrict__ src, int ld_src, u16* __restrict__ dst, int ld_dst, const int32_t* __restrict__ list, int n,
@@ -424,7 +425,7 @@ __global__ void dropout_kernel(const u16* __restrict__ x, u16* __restrict__ y, l
 
 // column sums: block = 8 column-chunks (64 cols) x 32 row lanes ; grid.y splits the rows
 __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, int M, int N, int ldx, const float* __restrict__ row_scale,
-                                                     int rows_per_scale, float* __restrict__ out) {
+                                                     int rows_per_scale, float all_scale, float* __restrict__ out) {
   __shared__ float sh[32][65];
   const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int col = blockIdx.x * 64 + cc * 8;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
 #pragma unroll 8
     for (int k = 0; k < 32; ++k) s += sh[k][threadIdx.x];
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < N) atomicAdd(out + c, s);
+    if (c < N) atomicAdd(out + c, s * all_scale);
   }
 }
 
@@ -963,16 +964,25 @@ extern "C" int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uin
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
-extern "C" int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
-                                int32_t accumulate, void* stream) {
+static int colsum_launch(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float all_scale, float* out,
+                         int32_t accumulate, void* stream) {
   if (!X || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return VMVM_EINVAL;
   if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, ST) != hipSuccess) return VMVM_EHIP;
   int gy = (M + 32 * 16 - 1) / (32 * 16);
   if (gy > 256) gy = 256;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, ST, reinterpret_cast<const u16*>(X), M, N, ldx, row_scale, rows_per_scale, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, ST, reinterpret_cast<const u16*>(X), M, N, ldx, row_scale, rows_per_scale,
+                     all_scale, out);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
+}
+extern "C" int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
+                                int32_t accumulate, void* stream) {
+  return colsum_launch(X, M, N, ldx, row_scale, rows_per_scale, 1.f, out, accumulate, stream);
+}
+// out[n] += scale * sum_m X[m][n]: the separate-pass form of vmvm_gemm_desc.colsum / colsum_scale (gemm.hip, shapes off the fused build)
+int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* stream) {
+  return colsum_launch(X, M, N, ldx, nullptr, 0, scale, out, 1, stream);
 }
 extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream) {
   if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;

@@ -203,27 +203,34 @@ class V:
 
 class DropScale:
     """One DropPath draw of a Swin block branch (video_swin.py:46-54): dev = f32 (B,) scales (0 or 1 / keep) on the device; host = the same
-    on the host (which clips were dropped is known WITHOUT a device round trip: the draw happens on the host); perm = int32 device list of
-    the clip indices, kept clips first, then the dropped ones; dev_perm = the scales in that order (zeros behind the kept ones)."""
-    __slots__ = ("dev", "host", "perm", "dev_perm", "n_kept")
+    on the host (which clips were dropped is known WITHOUT a device round trip: the draw happens on the host); kept / dropped = int32
+    device lists of the kept (then -1 up to B entries) and of the dropped clip indices; dev_kept = the kept clips' scales, then zeros."""
+    __slots__ = ("dev", "host", "kept", "dropped", "dev_kept", "n_kept", "scale")
 
-    def __init__(self, dev, host=None, perm=None, dev_perm=None):
+    def __init__(self, dev, host=None, kept=None, dropped=None, dev_kept=None):
         self.dev = dev
         self.host = dev.detach().float().cpu().numpy() if host is None else host       # (explicit tensors from tests: one small D2H)
-        self.n_kept = int((self.host != 0).sum())
-        if perm is None:
-            order = np.concatenate([np.flatnonzero(self.host != 0), np.flatnonzero(self.host == 0)]).astype(np.int32)
-            perm = _dev_i32(order, dev.device)
-            dev_perm = dev[torch.from_numpy(order).long().to(dev.device)].contiguous()
-        self.perm, self.dev_perm = perm, dev_perm
+        nz = np.flatnonzero(self.host != 0)
+        self.n_kept = int(nz.size)
+        self.scale = float(self.host[nz[0]]) if nz.size and np.all(self.host[nz] == self.host[nz[0]]) else None      # the ONE scale of the kept clips
+        if kept is None:
+            B = self.host.size
+            lists = np.full((2, B), -1, np.int32)
+            lists[0, :nz.size] = nz
+            lists[1, :B - nz.size] = np.flatnonzero(self.host == 0)
+            t = _dev_i32(lists, dev.device)
+            kept, dropped = t[0], t[1]
+            sc = np.zeros(B, np.float32)
+            sc[:nz.size] = self.host[nz]
+            dev_kept = torch.from_numpy(sc).to(dev.device)
+        self.kept, self.dropped, self.dev_kept = kept, dropped, dev_kept
 
     def take(self, rows_per_clip, B):
-        """-> (n, kept list, their scales, dropped list, n_dropped): the clips a branch runs on -- the kept ones, rounded UP with dropped
-        clips (scale 0: computed and multiplied by zero, as every dropped clip is without the elimination) until n * rows_per_clip is a
-        multiple of 64: the row count is the K dimension of the branch's weight-gradient GEMMs, whose direct-to-LDS kernels need whole K tiles."""
+        """-> (n, clip list, scales): the clips a branch runs on -- the kept ones, then padding clips (list entry -1: every row of theirs is
+        a -1 entry of the row maps = zeros in, nothing out; scale 0) until n * rows_per_clip is a multiple of 64: the row count is the K
+        dimension of the branch's weight-gradient GEMMs, whose direct-to-LDS kernels need whole K tiles."""
         need = 64 // math.gcd(rows_per_clip, 64)
-        n = min(B, -(-self.n_kept // need) * need)
-        return n, self.perm, self.dev_perm, self.perm[n:], B - n
+        return min(B, -(-self.n_kept // need) * need), self.kept, self.dev_kept
 
 
 def _acc(v, g):
@@ -309,7 +316,7 @@ class VioletEngine:
             self._wkeep = []
 
     def _linear_bwd(self, dy, x, wname, bname, *, w=None, gw=None, gb=None, M=None, row_scale=None, rows_per_scale=0,
-                    need_dx=True, dx_kw=None, wN=None, wT=None, wsync=False):
+                    need_dx=True, dx_kw=None, wN=None, wT=None, wsync=False, cs_scale=None):
         """dW += dy^T x ; db += colsum(dy) ; dx = dy W   (all on the MFMA GEMM, no transposed copies)."""
         S = self.store
         w = S.b(wname) if w is None else w
@@ -323,11 +330,12 @@ class VioletEngine:
 
         def wgrad(ws):
             gb_ = gbias
-            if gb_ is not None and row_scale is not None:   # DropPath-weighted column sum: separate pass (the fused form is unweighted)
+            if gb_ is not None and row_scale is not None and cs_scale is None:   # per-clip DropPath weights: separate pass (the fused form has ONE scale)
                 K.colsum(dy, gb_, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
                 gb_ = None
-            # db = colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
-            K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gb_, workspace=ws)
+            # db = [cs_scale *] colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
+            K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gb_,
+                   colsum_scale=cs_scale or 0.0, workspace=ws)
         self._wgrad_launch(wgrad, (dy, x, row_scale), sync=wsync)
         if not need_dx:
             return None
@@ -387,8 +395,9 @@ class VioletEngine:
         dp2 = None if ds2 is None else ds2.dev
         Bk, compact = B, False                                 # clips the attention branch runs on
         if ds is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0":
-            Bk, kept_a, dpk_a, drop_a, nd_a = ds.take(math.gcd(L, Lp), B)                 # (both row counts, Bk * L and Bk * Lp, in whole K tiles)
-            compact = Bk < B
+            Bk, kept_a, dpk_a = ds.take(math.gcd(L, Lp), B)                   # (both row counts, Bk * L and Bk * Lp, in whole K tiles)
+            drop_a, nd_a = ds.dropped, B - ds.n_kept
+            compact = Bk < B and ds.scale is not None
             if not compact:
                 Bk = B                                         # (nothing to eliminate / VMVM_DROPPATH_DCE=0: dropped clips are scaled by 0)
         x = xv.t
@@ -423,8 +432,9 @@ class VioletEngine:
         # rows, fc1 compact, fc2 scattering back through the same map (+ residual); one extra gather of d(x2) in the backward
         Bm, compact2 = B, False
         if ds2 is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") not in ("0", "attn"):
-            Bm, kept_m, dpk_m, drop_m, nd_m = ds2.take(L, B)
-            compact2 = Bm < B
+            Bm, kept_m, dpk_m = ds2.take(L, B)
+            drop_m, nd_m = ds2.dropped, B - ds2.n_kept
+            compact2 = Bm < B and ds2.scale is not None
             if not compact2:
                 Bm = B
         if compact2 and Bm == 0:
@@ -454,7 +464,8 @@ class VioletEngine:
                 dx1 = dx2
             else:
                 dx2c = K.gather_rows(dx2, map_m, Bm * L) if compact2 else dx2
-                du = self._linear_bwd(dx2c, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dpm, rows_per_scale=L,
+                # (compact: the padding clips' rows of dx2c are zeros and the kept clips share one scale -> the bias gradient stays fused)
+                du = self._linear_bwd(dx2c, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dpm, rows_per_scale=L, cs_scale=ds2.scale if (compact2 or (ds2 is not None and ds2.n_kept == B)) else None,
                                       dx_kw=dict(act=3, aux=u, row_scale=dpm, rows_per_scale=L, code8=c8))
                 dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
                 if compact2:
@@ -467,7 +478,8 @@ class VioletEngine:
                 _acc(xv, dx1)
                 return
             dx1w = K.gather_rows(dx1, src_k, Bk * Lp) if compact else K.gather_rows(dx1, src, B * Lp, Lp, L)
-            dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp)
+            dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp,
+                                   cs_scale=ds.scale if (compact or (ds is not None and ds.n_kept == B)) else None)      # (every clip kept: one scale as well)
             dqkv = K.attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, 0, scale,
                                    dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
             dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
@@ -1239,18 +1251,20 @@ class VioletEngine:
             for _ in range(2):
                 rows.append(np.floor(keep + rng.rand(B)) / keep if p > 0 else np.ones(B))
         host = np.stack(rows).astype(np.float32)                       # [2 * blocks, B]
-        # one upload: the scales, and per draw the clip permutation (kept clips first) with the scales in that order
+        # one upload: the scales, and per draw the kept clips' scales (then zeros) and the kept / dropped clip lists (-1 behind their entries)
         nr = host.shape[0]
         pack_f = np.zeros((2, nr, B), np.float32)
-        pack_i = np.zeros((nr, B), np.int32)
+        pack_i = np.full((2, nr, B), -1, np.int32)
         pack_f[0] = host
         for i in range(nr):
-            order = np.concatenate([np.flatnonzero(host[i] != 0), np.flatnonzero(host[i] == 0)])
-            pack_i[i] = order
-            pack_f[1, i] = host[i, order]
+            k = np.flatnonzero(host[i] != 0)
+            d = np.flatnonzero(host[i] == 0)
+            pack_i[0, i, :k.size] = k
+            pack_i[1, i, :d.size] = d
+            pack_f[1, i, :k.size] = host[i, k]
         tf = _h2d(torch.from_numpy(pack_f), self.device)
         ti = _h2d(torch.from_numpy(pack_i), self.device)
 
         def mk(i):
-            return DropScale(tf[0, i], host[i], ti[i], tf[1, i])
+            return DropScale(tf[0, i], host[i], ti[0, i], ti[1, i], tf[1, i])
         return [(mk(2 * i), mk(2 * i + 1)) for i in range(nr // 2)]

@@ -28,7 +28,7 @@ def _ld(t):
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=None, row_scale=None, rows_per_scale=0,
          scale_bias_only=False, act=0, aux=None, out_preact=None, resid=None, row_map=None, map_len=0, map_stride=0,
          out=None, out_dtype=BF16, accumulate=False, col_scale=1.0, col_scale_n=0, dropout_p=0.0, seed=0, offset=0,
-         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0, a_relu=False, code8=False):
+         variant=0, out_rows=None, splitk=0, workspace=None, colsum=None, fp16=False, conv=None, fp8=False, alpha=1.0, a_relu=False, code8=False, colsum_scale=0.0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/vmvm.h:vmvm_gemm_desc."""
     if M is None:
         M = A.shape[0] if a_kmajor else A.shape[1]
@@ -62,6 +62,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, M=None, N=None, K=None, bias=Non
         workspace = _WORKSPACE.get(A.device)
     d.workspace, d.workspace_bytes = L.ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
     d.colsum = L.ptr(colsum)
+    d.colsum_scale = float(colsum_scale)
     d.in_fp16 = int(fp16)
     d.conv_taps, d.conv_h, d.conv_w = conv if conv is not None else (0, 0, 0)
     d.in_fp8, d.alpha = int(fp8), float(alpha)

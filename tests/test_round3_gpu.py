@@ -119,6 +119,62 @@ def test_train_mode_step_vs_oracle():
     assert checked > 300 and n_bias >= 40 and not bad, (checked, n_bias, bad[:12])
 
 
+@pytest.mark.timeout(900)
+def test_droppath_dead_clip_elimination_equals_the_scaled_path(monkeypatch):
+    """The Swin branches run on their KEPT clips only (engine._swin_block: compact row maps, padding clips up to whole K tiles, the bias
+    gradient's one scale on the weight-gradient GEMM).  Same step, same explicit draws, with the elimination off (VMVM_DROPPATH_DCE=0: every
+    clip runs, dropped ones multiplied by 0 -- the reference's own formulation, video_swin.py:46-54): losses equal to 1e-3, every gradient
+    tensor cos >= 0.999 and norm within 1 %.  B = 5 and drop rates up to 0.5 give odd kept counts (stage 3 pads 1 -> 2, 3 -> 4 clips),
+    all-dropped and all-kept branches."""
+    from oracle import violet_ref as R
+    B = 5
+    cfg = R.make_cfg("base", T=8, temp=1.0)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8, temp=1.0))
+    model.load_state_dict(R.make_state_dict(cfg))
+    eng = model.engine
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    rng = np.random.RandomState(11)
+    n_blk = sum(cfg["depths"])
+    dpr = np.linspace(0, 0.5, n_blk)
+    scales = np.ones((n_blk, 2, B), np.float32)
+    for blk in range(1, n_blk):
+        keep = 1.0 - dpr[blk]
+        scales[blk] = np.floor(keep + rng.rand(2, B)) / keep
+    scales[9, 0] = 0.0                                         # an attention branch and an MLP branch with every clip dropped
+    scales[12, 1] = 0.0
+    kept = (scales != 0).sum(-1)
+    assert {1, 3} & set(kept[4:22].flatten().tolist()) and 0 in kept and B in kept[1:]
+    dp_dev = [(torch.from_numpy(scales[i, 0]).cuda(), torch.from_numpy(scales[i, 1]).cuda()) for i in range(n_blk)]
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+    batch = dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+    S = eng.store
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VMVM_DROPPATH_DCE", mode)
+        S.grad.zero_()
+        losses, _ = eng.forward_backward(batch, negatives=neg, train=True, dp_all=dp_dev, dropout=False, backward=True, want_outputs=True)
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v.item()) for k, v in losses.items() if k in ("mtm", "mvm", "vtm")}, S.grad[:S.n_trainable].clone())
+    for k, v in res["1"][0].items():
+        assert abs(v - res["0"][0][k]) <= 1e-3 * abs(res["0"][0][k]) + 1e-4, (k, v, res["0"][0][k])
+    g1, g0 = res["1"][1].double(), res["0"][1].double()
+    assert abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-3
+    names = [nm for nm in S.index if nm.startswith("enc_img.swin.") and S.index[nm][0] + S.index[nm][1] <= S.n_trainable]
+    part = lambda g, nm: g[S.index[nm][0]:S.index[nm][0] + S.index[nm][1]]
+    gmax = max(float(part(g0, nm).norm()) for nm in names)
+    bad, n = [], 0
+    for nm in names:
+        a, b = part(g1, nm), part(g0, nm)
+        if float(b.norm()) < 1e-3 * gmax:
+            continue
+        n += 1
+        if _cos(a, b) < 0.999 or abs(float(a.norm() / b.norm()) - 1.0) > 1e-2:
+            bad.append((nm, round(_cos(a, b), 5), round(float(a.norm() / b.norm()), 4)))
+    assert n > 150 and not bad, (n, bad[:10])
+
+
 def _recover_attention_mask(K, nseq, Lq, heads, hd, p, seed, offset, keep_scale):
     """The dropout multiplier (0 / keep_scale) of every (sequence, head, query, key) as the attention kernel applies it: q = k = 0 makes
     P uniform (1 / Lq), V = an identity slice per 64-key block exposes the kept entries of that block."""

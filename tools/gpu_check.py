@@ -86,6 +86,11 @@ def check_gemm_colsum():
         K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=n_out, N=k_in, K=rows, out=gw, accumulate=True, colsum=gb)
         rep(f"wgrad+colsum dW rows={rows} {n_out}x{k_in} ws={ws}", gw, gw0 + dy.float().t() @ x.float())
         rep(f"wgrad+colsum db rows={rows} {n_out}x{k_in} ws={ws}", gb, gb0 + dy.float().sum(0))
+        # colsum_scale: the ONE DropPath scale of a compact Swin branch rides on the fused form (and on the separate-pass fallback)
+        gw, gb = gw0.clone(), gb0.clone()
+        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=n_out, N=k_in, K=rows, out=gw, accumulate=True, colsum=gb, colsum_scale=1.25)
+        rep(f"wgrad+colsum*1.25 dW rows={rows} {n_out}x{k_in} ws={ws}", gw, gw0 + dy.float().t() @ x.float())
+        rep(f"wgrad+colsum*1.25 db rows={rows} {n_out}x{k_in} ws={ws}", gb, gb0 + 1.25 * dy.float().sum(0))
     K._WORKSPACE.clear()
 
 
