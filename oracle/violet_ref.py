@@ -507,8 +507,9 @@ def swin_forward(sd, cfg, x, dp_scales=None, prefix="enc_img.swin.", final_norm=
 # ----------------------------------------------------------------------------
 # EncVideo / EncTxt / fusion encoder / heads
 # ----------------------------------------------------------------------------
-def enc_video(sd, cfg, img, dp_scales=None):
-    """EncVideo.forward model.py:32-78 ; img (B,T,3,H,W) -> feat (B,T*(1+hw),768), mask ones"""
+def enc_video(sd, cfg, img, dp_scales=None, odr=None, vt_mask=None):
+    """EncVideo.forward model.py:32-78 ; img (B,T,3,H,W) -> feat (B,T*(1+hw),768), mask (ones, times vt_mask (B,T,1+hw) if given).
+    odr (B x T frame orders, model.py:61-67): frame slot i of clip b gets emb_len[i] when odr[b][i] == i, else emb_odr."""
     B, T, _, H, W = img.shape
     h, w = H // 32, W // 32
     f = swin_forward(sd, cfg, img.transpose(1, 2), dp_scales)          # (B,T,h,w,8E)
@@ -517,10 +518,17 @@ def enc_video(sd, cfg, img, dp_scales=None):
         f = F.linear(f, sd["enc_img.fc.weight"], sd["enc_img.fc.bias"])
     f = torch.cat([sd["enc_img.emb_cls"].expand(B, T, -1, -1), f], dim=2)
     f = f + sd["enc_img.emb_pos"][:, :, :1 + h * w, :]
-    f = f + sd["enc_img.emb_len"][:, :T, :, :]
+    if odr is not None:
+        rows = [torch.cat([sd["enc_img.emb_len"][:, i:i + 1] if i == int(p_) else sd["enc_img.emb_odr"] for i, p_ in enumerate(odr[b])], dim=1)
+                for b in range(B)]
+        f = f + torch.cat(rows, dim=0)
+    else:
+        f = f + sd["enc_img.emb_len"][:, :T, :, :]
     f = layer_norm(f, sd["enc_img.norm.weight"], sd["enc_img.norm.bias"], 1e-5).reshape(B, T * (1 + h * w), -1)
-    m = torch.ones(B, T * (1 + h * w), dtype=torch.long)
-    return f, m
+    m = torch.ones(B, T, 1 + h * w, dtype=torch.long)
+    if vt_mask is not None:
+        m = m * vt_mask
+    return f, m.reshape(B, T * (1 + h * w))
 
 
 def enc_txt(sd, txt):

@@ -689,6 +689,9 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // fragments after the LDS read (fp16 builds: the block-input ReLU of the dVAE's residual path, encoder.py:27-28, without a pass
 // over the activation); one v_pk_max_f16 per MFMA, in its shadow.  F & EF_ARGMAX: instead of storing, each 64-column group of a
 // row leaves its (maximum, column) pair in C (f32 [M][ldc], pairs at 2 * (n / 64)) -- the 8192-wide logits are never written.
+#ifdef VMVM_PROBE_STAGGER_CU
+__device__ unsigned g_probe_cu_arrivals[8 * 256];
+#endif
 #ifndef VMVM_PROBE_EPI
 #define VMVM_PROBE_EPI 0        /* probe builds only (tools/probe/gemm_probe.hip): 1 = no global stores, 2 = no epilogue math, 3 = neither (re-tiled classes) */
 #endif
@@ -794,6 +797,20 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   if (w >= x_cnt) return;
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
+#ifdef VMVM_PROBE_STAGGER_CU   /* probe builds only: the SECOND workgroup to arrive on a compute unit (arrival order per CU through HW_ID) starts a fraction of a tile time late */
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned key = (blockIdx.x & 7) * 256 + ((hw >> 8) & 0xff);
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem) = atomicAdd(&g_probe_cu_arrivals[key], 1u);
+    __syncthreads();
+    const unsigned old = *reinterpret_cast<volatile unsigned*>(smem);
+    __syncthreads();
+    const int tile64 = (nk - kt0) * 17 + 100;           // estimated tile time in 64-cycle units
+    const int wait64 = (old & 1) ? tile64 * VMVM_PROBE_STAGGER_CU / 100 : 0;
+    for (int t = 0; t < wait64; t += 100) __builtin_amdgcn_s_sleep(100);
+  }
+#endif
 #ifdef VMVM_PROBE_STAGGER   /* probe builds only: workgroup i of an XCD starts (i % P) / P of an estimated tile time late (are the two workgroups of a CU in lockstep?) */
   {
     const int tile64 = (nk - kt0) * 17 + 100;           // estimated tile time in 64-cycle units
@@ -1148,6 +1165,14 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
     attr_done = true;
   }
   int grid = 2 * vmvm_usable_cus(d.reserve_cus);        // 2 workgroups per CU (64 KiB LDS each), multiple of 8
+#ifdef VMVM_PROBE_ONE_WG    /* probe builds only: ONE workgroup per CU (an LDS request no second workgroup fits beside): how much of the rate is one workgroup's? */
+  grid = vmvm_usable_cus(d.reserve_cus);
+  if (items < grid) grid = ((items + 7) / 8) * 8;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), 100 << 10, st, d);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+#endif
   if (items < grid) grid = ((items + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();

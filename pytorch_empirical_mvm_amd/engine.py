@@ -548,7 +548,7 @@ class VioletEngine:
         return out, dims, C
 
     # -------------------------------------------------------------- EncVideo / EncTxt  -> one token pool
-    def encode(self, img, cov, txt, dp_all, train):
+    def encode(self, img, cov, txt, dp_all, train, odr=None):
         """returns pool V([B*Lv + NT*X, 768]) : rows [0, B*Lv) = feat_img (model.py:71), rest = feat_txt (model.py:107) of the NT =
         txt.shape[0] text sequences (NT = B in pre-training; B*O option sequences in multiple-choice QA)."""
         cfg, S, dev = self.cfg, self.store, self.device
@@ -568,7 +568,18 @@ class VioletEngine:
         ln_ = S.p("enc_img.emb_len", (cfg["max_size_frame"], Hd))
         if T > cfg["max_size_frame"]:
             raise RuntimeError(f"max_size_frame ({cfg['max_size_frame']}) must be >= T ({T})  (model.py:69)")
-        pre = K.encvideo_assemble(f, S.p("enc_img.emb_cls", (Hd,)), pos, ln_, B, T, hw, Hd)
+        if odr is None:
+            pre = K.encvideo_assemble(f, S.p("enc_img.emb_cls", (Hd,)), pos, ln_, B, T, hw, Hd)
+        else:
+            # frame-order variant (model.py:61-67; no caller in the reference sets it, inference surface only): slot i of clip b adds
+            # emb_len[i] when odr[b][i] == i, else emb_odr -- one frame table per clip, the same kernel on one clip at a time
+            eo = S.p("enc_img.emb_odr", (1, Hd))
+            hit = torch.as_tensor([[int(p_) == i for i, p_ in enumerate(o)] for o in odr], device=dev).view(B, T, 1)
+            tabs = torch.where(hit, ln_[:T].unsqueeze(0), eo.unsqueeze(0)).contiguous()                  # f32 [B, T, Hd]
+            pre = torch.empty((B * T * (1 + hw), Hd), device=dev, dtype=BF16)
+            for b in range(B):
+                K.encvideo_assemble(f[b * T * hw:(b + 1) * T * hw], S.p("enc_img.emb_cls", (Hd,)), pos, tabs[b], 1, T, hw, Hd,
+                                    out=pre[b * T * (1 + hw):(b + 1) * T * (1 + hw)])
         pool = torch.empty((B * Lv + txt.shape[0] * X, Hd), device=dev, dtype=BF16)
         gi, bi = S.p("enc_img.norm.weight"), S.p("enc_img.norm.bias")
         fi, mean_i, rstd_i = K.layernorm_fwd(pre, gi, bi, 1e-5)
@@ -587,6 +598,8 @@ class VioletEngine:
         out = V(pool)
 
         def bwd():
+            if odr is not None:
+                raise RuntimeError("odr is served on the inference surface only (go_feat / EncVideo.forward); no training path of the reference sets it")
             dpool = out.g                                                       # bf16 [B*Lv + B*X, Hd]
             dft = dpool[B * Lv:]
             if p_drop > 0:

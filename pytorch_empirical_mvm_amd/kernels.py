@@ -275,8 +275,8 @@ def patch_embed_fwd(img, cov, w_bf16, bias, gamma, beta, eps):
     return x, z, mean, rstd
 
 
-def encvideo_assemble(fc_out, cls, pos, len_, B, T, hw, Hd):
-    out = torch.empty((B * T * (1 + hw), Hd), device=fc_out.device, dtype=BF16)
+def encvideo_assemble(fc_out, cls, pos, len_, B, T, hw, Hd, out=None):
+    out = torch.empty((B * T * (1 + hw), Hd), device=fc_out.device, dtype=BF16) if out is None else out
     L.check(L.load().vmvm_encvideo_assemble(fc_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), len_.data_ptr(), out.data_ptr(),
                                             B, T, hw, Hd, L.stream()), "encvideo_assemble")
     return out

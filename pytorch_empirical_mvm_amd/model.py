@@ -142,22 +142,26 @@ class VIOLET_Pretrain(torch.nn.Module):
 
     @torch.no_grad()
     def go_feat(self, img, txt, mask, odr=None, vt_mask=None, attn_mask_type="full"):
-        """VIOLET_Base.go_feat (model.py:174-178): (feat_img (B, T*(1+hw), H), mask_img ones, feat_txt (B, X, H), mask_txt).
+        """VIOLET_Base.go_feat (model.py:174-178): (feat_img (B, T*(1+hw), H), mask_img (ones, times vt_mask), feat_txt (B, X, H), mask_txt);
+        odr / vt_mask as EncVideo.forward takes them (model.py:61-67,75).
         Inference surface (eval / feature extraction); the training step assembles the same token pool inside the engine."""
-        if odr is not None or vt_mask is not None:
-            raise NotImplementedError("odr / vt_mask are outside the pretraining path (model.py:61-67)")
         eng, dev = self.engine, self.engine.device
         B, T = img.shape[0], img.shape[1]
         X = txt.shape[1]
+        if odr is not None and (len(odr) != B or any(len(o) != T for o in odr)):
+            raise ValueError(f"odr must hold one frame order of length T={T} per clip")
         saved, eng.tape = eng.tape, []
         train = self.training
         dp_all = eng.sample_drop_path(B) if train else None
-        pool, Lv, hw = eng.encode(img.to(dev, torch.float32).contiguous(), None, txt.to(dev).contiguous(), dp_all, train)
+        pool, Lv, hw = eng.encode(img.to(dev, torch.float32).contiguous(), None, txt.to(dev).contiguous(), dp_all, train, odr=odr)
         eng.tape = saved
         Hd = self.hidden_size
         feat_img = pool.t[:B * Lv].view(B, Lv, Hd)
         feat_txt = pool.t[B * Lv:].view(B, X, Hd)
-        return feat_img, torch.ones(B, Lv, dtype=torch.long, device=dev), feat_txt, mask.to(dev)
+        mask_img = torch.ones(B, T, Lv // T, dtype=torch.long, device=dev)
+        if vt_mask is not None:                                # model.py:75 : (B, T, 1+hw) or broadcastable to it
+            mask_img = mask_img * torch.as_tensor(vt_mask, device=dev).long()
+        return feat_img, mask_img.view(B, Lv), feat_txt, mask.to(dev)
 
     def state_dict(self, *a, **k):
         ev = getattr(self.engine, "other_ready", None)       # the non-Swin half of the last optimizer step may still be running on the second stream

@@ -230,3 +230,33 @@ def test_swinbert_checkpoint_key_renames():
     inv = set(R.param_shapes(R.make_cfg("base", T=8)))
     assert {"enc_img.swin.layers.0.blocks.0.attn.qkv.weight", "trsfr.layer.3.output.dense.bias", "enc_txt.emb_txt.word_embeddings.weight",
             "fc_mtm.predictions.bias", "fc_mtm.predictions.transform.dense.weight"} <= inv
+
+
+def test_2d_to_3d_weight_inflation_matches_reference_outputs():
+    """visbackbone.inflate_2d_state against SwinTransformer3D.inflate_weights' own results (video_swin.py:484-535; inflate2d.npz holds a synthetic
+    image-Swin checkpoint's tensors and what the reference module held after loading it): patch kernel tiled over the temporal taps / tap count,
+    7x7 tables tiled 15x, 6x6 tables resized bicubically to 13x13 first, index / mask buffers dropped, everything else untouched."""
+    import os
+    import numpy as np
+    import torch
+    from pytorch_empirical_mvm_amd.visbackbone import inflate_2d_state
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "inflate2d.npz"))
+    arch = dict(window=(8, 7, 7), patch=(2, 4, 4))
+    for tag in ("w7", "w6"):
+        keys = sorted({k[len(tag) + 4:] for k in d.files if k.startswith(tag + ".in.")})
+        assert len(keys) == 5
+        sd2 = {k: torch.from_numpy(d[f"{tag}.in.{k}"]) for k in keys}
+        sd2["layers.0.blocks.0.attn.relative_position_index"] = torch.zeros(36, 36, dtype=torch.long)
+        sd2["layers.0.blocks.0.attn_mask"] = torch.zeros(4, 49, 49)
+        out = inflate_2d_state(sd2, arch)
+        assert sorted(out) == keys                                         # the two buffers are gone
+        for k in keys:
+            want = d[f"{tag}.out.{k}"]
+            assert tuple(out[k].shape) == want.shape, (tag, k)
+            np.testing.assert_allclose(out[k].numpy(), want, rtol=1e-6, atol=1e-7, err_msg=f"{tag} {k}")
+        assert out["patch_embed.proj.weight"].shape == (32, 3, 2, 4, 4)
+        assert out["layers.2.blocks.1.attn.relative_position_bias_table"].shape == (15 * 169, 4)
+    # a table whose head count differs from the model's stays as it is (the loader skips it by shape)
+    t = torch.randn(169, 3)
+    out = inflate_2d_state({"layers.0.blocks.0.attn.relative_position_bias_table": t}, arch, {"layers.0.blocks.0.attn.relative_position_bias_table": (2535, 1)})
+    assert out["layers.0.blocks.0.attn.relative_position_bias_table"] is t

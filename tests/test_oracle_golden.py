@@ -357,3 +357,19 @@ def test_mlm_qa_variants_forward_loss_and_eval():
     assert R.top_k_acc(out, mask_ans, 1) == d["oe.ac_1"].tolist() and R.top_k_acc(out, mask_ans, 5) == d["oe.ac_5"].tolist()
     lo, an = torch.from_numpy(d["oe.toy_logits"]), torch.from_numpy(d["oe.toy_ans"])
     assert R.top_k_acc(lo, an, 1) == d["oe.toy_ac1"].tolist() and R.top_k_acc(lo, an, 5) == d["oe.toy_ac5"].tolist()
+
+
+def test_encvideo_frame_order_and_visual_token_mask():
+    """EncVideo.forward(img, odr, vt_mask) (model.py:61-67,75; encvideo_odr.npz = the reference module's own outputs): slot i of a clip
+    adds emb_len[i] where the given order has i in place and emb_odr elsewhere; the visual mask is ones times vt_mask."""
+    d = load("encvideo_odr.npz")
+    cfg = R.make_cfg("tiny", T=4)
+    sd = R.make_state_dict(cfg)
+    img, _, _ = R.make_batch(cfg, 3)
+    with torch.no_grad():
+        f, m = R.enc_video(sd, cfg, img, odr=d["odr"].tolist(), vt_mask=torch.from_numpy(d["vt_mask"]))
+        f0, m0 = R.enc_video(sd, cfg, img)
+    check_samp(d, "feat", f)
+    check_samp(d, "feat_plain", f0)
+    assert np.array_equal(m.numpy(), d["mask"]) and np.array_equal(m0.numpy(), d["mask_plain"]) and int((m == 0).sum()) == 95
+    assert torch.equal(f[0], f0[0]) and not torch.equal(f[1], f0[1])             # clip 0 is in order

@@ -351,6 +351,22 @@ def test_standalone_vidswin_and_encvideo_surface(tmp_path):
     with torch.no_grad():
         yr = R.swin_forward(sd, cfg, x).permute(0, 4, 1, 2, 3)    # oracle: channels-last (B,T,h,w,8E) -> (B,8E,T,h,w)
     assert _cos(y.float().cpu(), yr) >= 0.999
+    # vis_backbone_init = "2d": an image-Swin checkpoint ({'model': ...}) inflated along time on the way in (video_swin.py:484-535)
+    sd2 = {k: v.clone() for k, v in swin.items()}
+    sd2["patch_embed.proj.weight"] = swin["patch_embed.proj.weight"].sum(2)                          # (E,3,4,4): tiling / 2 gives both taps = sum / 2
+    for k in [k for k in swin if k.endswith("relative_position_bias_table")]:
+        sd2[k] = swin[k][:169].clone()                                                               # one temporal offset's 13 x 13 table
+    sd2["layers.0.blocks.0.attn.relative_position_index"] = torch.zeros(49, 49, dtype=torch.long)
+    pth2 = os.path.join(str(tmp_path), "swin_2d.pth")
+    torch.save({"model": sd2}, pth2)
+    m2 = VB.get_vidswin_model(CFG.get_args(vis_backbone_size="tiny", size_img=96, arch_override=arch, vis_backbone_init="2d", vis_backbone_pretrained_weight=pth2))
+    got = m2.state_dict()
+    w3 = got["patch_embed.proj.weight"].float().cpu()
+    assert tuple(w3.shape) == tuple(swin["patch_embed.proj.weight"].shape) and torch.allclose(w3[:, :, 0], w3[:, :, 1])
+    assert torch.allclose(w3[:, :, 0], sd2["patch_embed.proj.weight"] / 2, atol=1e-6)
+    tb = got["layers.1.blocks.0.attn.relative_position_bias_table"].float().cpu()
+    assert tuple(tb.shape) == (15 * 169, 2) and torch.allclose(tb.view(15, 169, 2), sd2["layers.1.blocks.0.attn.relative_position_bias_table"].expand(15, -1, -1), atol=1e-6)
+    assert torch.allclose(got["layers.2.blocks.0.mlp.fc1.weight"].float().cpu(), swin["layers.2.blocks.0.mlp.fc1.weight"], atol=1e-6)
     model, _ = _engine(dict(vis_backbone_size="tiny", size_frame=2, max_size_frame=6, arch_override=arch, bert_layers=1, size_img=96))
     model.load_state_dict(sd)
     model.eval()
@@ -360,6 +376,17 @@ def test_standalone_vidswin_and_encvideo_surface(tmp_path):
         fr = R.enc_video(sd, cfg, img)
     fr = fr[0] if isinstance(fr, (tuple, list)) else fr
     assert _cos(feat.float().cpu(), fr.reshape(feat.shape)) >= 0.999
+    # frame-order embedding and visual-token mask (model.py:61-67,75): clip 0 in order, clip 1 with its two frames swapped (-> emb_odr twice)
+    odr = [[0, 1], [1, 0]]
+    vt = torch.ones(2, 2, 10, dtype=torch.long)
+    vt[1, 0, 3:] = 0
+    feat_o, mask_o = VB.EncVideo(model)(img.cuda(), odr=odr, vt_mask=vt.cuda())
+    with torch.no_grad():
+        fo, mo = R.enc_video(sd, cfg, img, odr=odr, vt_mask=vt)
+    assert _cos(feat_o.float().cpu(), fo.reshape(feat_o.shape)) >= 0.999 and torch.equal(mask_o.cpu(), mo)
+    assert torch.equal(feat_o[0], feat[0]) and not torch.equal(feat_o[1], feat[1])                  # only the re-ordered clip changes
+    d_ref = (fo - fr.reshape(fo.shape))[1]
+    assert _cos((feat_o.float() - feat.float())[1].cpu(), d_ref) >= 0.98                              # ... and by what the oracle says
 
 
 def test_edge_cases_single_clip_empty_cover_padded_text_single_frame():

@@ -938,6 +938,62 @@ def gold_mlm_qa(size="tiny", T=4, B=3):
     print("mlm_qa ok", {k: (v.tolist() if v.size < 8 else v.shape) for k, v in d.items() if k.split(".")[-1] in ("loss", "ac", "ac_1", "ac_5", "toy_ac1", "toy_ac5")})
 
 
+def gold_inflate(vs):
+    """SwinTransformer3D.inflate_weights (video_swin.py:484-535) on a synthetic image-Swin checkpoint: one with 7x7-window tables (tiled
+    only) and one with 6x6-window tables (bicubic resize to 13x13, then tiled); the reference module's state_dict afterwards"""
+    import tempfile
+    arch = dict(embed_dim=32, depths=(1, 1, 2, 1), num_heads=(1, 2, 4, 8), window_size=(8, 7, 7), patch_size=(2, 4, 4))
+    d = {}
+    for tag, side in (("w7", 7), ("w6", 6)):
+        g = torch.Generator().manual_seed(31 + side)
+        probe = vs.SwinTransformer3D(pretrained=None, pretrained2d=True, **arch)
+        sd2 = {}
+        for k, v in probe.state_dict().items():
+            if "relative_position_index" in k:
+                sd2[k] = torch.zeros(side * side, side * side, dtype=torch.long)             # a 2-D model's buffer: must be dropped
+            elif "relative_position_bias_table" in k:
+                sd2[k] = torch.randn((2 * side - 1) ** 2, v.shape[1], generator=g) * 0.02
+            elif k == "patch_embed.proj.weight":
+                sd2[k] = torch.randn(v.shape[0], 3, 4, 4, generator=g) * 0.1
+            else:
+                sd2[k] = torch.randn(v.shape, generator=g) * 0.05
+        sd2["layers.0.blocks.0.attn_mask"] = torch.zeros(4, 49, 49)
+        path = os.path.join(tempfile.mkdtemp(), f"swin2d_{tag}.pth")
+        torch.save({"model": sd2}, path)
+        m = vs.SwinTransformer3D(pretrained=path, pretrained2d=True, **arch)
+        m.init_weights()
+        out = m.state_dict()
+        for k in ("patch_embed.proj.weight", "layers.0.blocks.0.attn.relative_position_bias_table", "layers.2.blocks.1.attn.relative_position_bias_table",
+                  "layers.1.blocks.0.mlp.fc1.bias", "norm.weight"):
+            d[f"{tag}.in.{k}"] = sd2[k].numpy().astype(np.float32)          # whole tensors: the test feeds them to the product's inflation
+            d[f"{tag}.out.{k}"] = out[k].numpy().astype(np.float32)
+        d[f"{tag}.dropped"] = np.array(sorted(k for k in sd2 if k not in out or tuple(sd2[k].shape) != tuple(out[k].shape) and "table" not in k and "patch_embed.proj" not in k))
+    np.savez_compressed(os.path.join(OUT, "inflate2d.npz"), **d)
+    print("inflate2d:", len(d), "entries")
+
+
+def gold_encvideo_odr(size="tiny", T=4, B=3):
+    """EncVideo.forward with a frame order and a visual-token mask (model.py:61-67,75): outputs of the reference module itself"""
+    mp, args, model = build_ref_model(size, T)
+    cfg = R.make_cfg(size, T=T)
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd, strict=False)
+    img, txt, mask = R.make_batch(cfg, B)
+    h = w = img.shape[-1] // 32
+    odr = [[0, 1, 2, 3], [1, 0, 2, 3], [3, 2, 1, 0]]
+    vt = torch.ones(B, T, 1 + h * w, dtype=torch.long)
+    vt[1, 2, 5:] = 0
+    vt[2, 0] = 0
+    with torch.no_grad():
+        f, m = model.enc_img(img, odr, vt)
+        f0, m0 = model.enc_img(img)
+    d = {"odr": np.asarray(odr, np.int64), "vt_mask": vt.numpy(), "mask": m.numpy(), "mask_plain": m0.numpy()}
+    put(d, "feat", f, 256)
+    put(d, "feat_plain", f0, 256)
+    np.savez_compressed(os.path.join(OUT, "encvideo_odr.npz"), **d)
+    print("encvideo_odr: feat", tuple(f.shape), "mask zeros", int((m == 0).sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -946,6 +1002,12 @@ if __name__ == "__main__":
     from visbackbone import video_swin as vs
     if "--tsv-only" in sys.argv:
         gold_tsv()
+        sys.exit(0)
+    if "--inflate-only" in sys.argv:
+        gold_inflate(vs)
+        sys.exit(0)
+    if "--encvideo-odr-only" in sys.argv:
+        gold_encvideo_odr()
         sys.exit(0)
     if "--qamc-only" in sys.argv:
         gold_qamc()
@@ -990,4 +1052,6 @@ if __name__ == "__main__":
     gold_qaoe()
     gold_qamc()
     gold_mlm_qa()
+    gold_encvideo_odr()
+    gold_inflate(vs)
     gold_tsv()

@@ -14,6 +14,7 @@
 
 thread_local int g_vmvm_last_hip_error = 0;
 extern "C" int vmvm_colsum_bf16(const void*, int32_t, int32_t, int32_t, const float*, int32_t, float*, int32_t, void*) { return VMVM_ENOSUPPORT; }
+int vmvm_colsum_scaled(const void*, int32_t, int32_t, int32_t, float, float*, void*) { return VMVM_ENOSUPPORT; }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
