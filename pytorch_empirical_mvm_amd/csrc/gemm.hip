@@ -692,6 +692,11 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 #ifdef VMVM_PROBE_STAGGER_CU
 __device__ unsigned g_probe_cu_arrivals[8 * 256];
 #endif
+#ifdef VMVM_PROBE_TIMELINE   /* probe builds only: 100 MHz timestamps of (main loop start, epilogue start, epilogue end) of the first tiles of every workgroup, per CU */
+constexpr int TL_TILES = 24;
+__device__ unsigned g_tl_arrivals[8 * 256];
+__device__ unsigned long long g_tl[8 * 256][2][TL_TILES][4];
+#endif
 #ifndef VMVM_PROBE_EPI
 #define VMVM_PROBE_EPI 0        /* probe builds only (tools/probe/gemm_probe.hip): 1 = no global stores, 2 = no epilogue math, 3 = neither (re-tiled classes) */
 #endif
@@ -797,6 +802,18 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   if (w >= x_cnt) return;
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
+#ifdef VMVM_PROBE_TIMELINE
+  unsigned tl_key, tl_slot; int tl_t = 0;
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    tl_key = (blockIdx.x & 7) * 256 + ((hw >> 8) & 0xff);
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem) = atomicAdd(&g_tl_arrivals[tl_key], 1u);
+    __syncthreads();
+    tl_slot = *reinterpret_cast<volatile unsigned*>(smem) & 1;
+    __syncthreads();
+  }
+#endif
 #ifdef VMVM_PROBE_STAGGER_CU   /* probe builds only: the SECOND workgroup to arrive on a compute unit (arrival order per CU through HW_ID) starts a fraction of a tile time late */
   {
     unsigned hw;
@@ -824,6 +841,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   tile_offsets(m0, n0, voA, voB, pyA, pxA);
   issue(voA, voB, pyA, pxA, kt0, it & 1);
   while (true) {
+#ifdef VMVM_PROBE_TIMELINE
+    if (tid == 0 && tl_t < TL_TILES) { g_tl[tl_key][tl_slot][tl_t][0] = wall_clock64(); g_tl[tl_key][tl_slot][tl_t][3] = clock64(); }
+#endif
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -966,6 +986,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       ++it;
     }
     ec.slice = slice;
+#ifdef VMVM_PROBE_TIMELINE
+    if (tid == 0 && tl_t < TL_TILES) g_tl[tl_key][tl_slot][tl_t][1] = wall_clock64();
+#endif
     // (An LDS-staged, 16-byte-per-lane coalesced epilogue was measured here: correct but 1.4-1.7x SLOWER on every shape --
     //  two extra barriers and an LDS round trip per tile cost more than the 32-byte store fragments; kept direct.)
     if ((F & EF_COLSUM) && do_cs && g == 0) {            // lanes 0-15: column m = m0 + wm*64 + i*16 + r (all 16 rows of the product are equal)
@@ -1147,6 +1170,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     }
     }
     }
+#ifdef VMVM_PROBE_TIMELINE
+    if (tid == 0 && tl_t < TL_TILES) g_tl[tl_key][tl_slot][tl_t][2] = wall_clock64();
+    ++tl_t;
+#endif
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
 #pragma unroll
@@ -1155,6 +1182,35 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     for (int i = 0; i < NB; ++i) voB[i] = nvoB[i];
   }
 }
+
+#ifdef VMVM_PROBE_TIMELINE
+static void probe_timeline_reset() {
+  static unsigned long long z[8 * 256 * 2 * TL_TILES * 4];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof(z));
+}
+static void probe_timeline_dump(int n_cus) {
+  static unsigned long long h[8 * 256][2][TL_TILES][4];
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof(h));
+  int shown = 0;
+  for (int key = 0; key < 8 * 256 && shown < n_cus; ++key) {
+    if (!h[key][0][0][0] || !h[key][1][0][0]) continue;
+    const unsigned long long t0 = h[key][0][0][0] < h[key][1][0][0] ? h[key][0][0][0] : h[key][1][0][0];
+    printf("CU key %d (xcd %d, hw %d): times in us from the first workgroup's start; per tile: main start | epilogue start | epilogue end\n", key, key >> 8, key & 255);
+    for (int sl = 0; sl < 2; ++sl)
+      if (h[key][sl][TL_TILES - 1][0]) printf("   wg%d shader clock over tiles 0..%d: %.0f MHz\n", sl, TL_TILES - 1,
+                                              (double)(h[key][sl][TL_TILES - 1][3] - h[key][sl][0][3]) / ((h[key][sl][TL_TILES - 1][0] - h[key][sl][0][0]) * 0.01));
+    for (int t = 0; t < TL_TILES; ++t) {
+      for (int sl = 0; sl < 2; ++sl) {
+        if (!h[key][sl][t][0]) { printf("   wg%d t%-2d  -                          ", sl, t); continue; }
+        printf("   wg%d t%-2d %7.2f %7.2f %7.2f (main %5.2f epi %5.2f)", sl, t, (h[key][sl][t][0] - t0) * 0.01, (h[key][sl][t][1] - t0) * 0.01, (h[key][sl][t][2] - t0) * 0.01,
+               (h[key][sl][t][1] - h[key][sl][t][0]) * 0.01, (h[key][sl][t][2] - h[key][sl][t][1]) * 0.01);
+      }
+      printf("\n");
+    }
+    ++shown;
+  }
+}
+#endif
 
 template <bool AK, bool BKM, int F>
 int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {

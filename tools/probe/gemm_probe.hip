@@ -248,6 +248,10 @@ int main(int argc, char** argv) {
       memset(&d, 0, sizeof(d));
       d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K; d.ldc = N; d.a_kmajor = 1; d.b_kmajor = 1;
       d.col_scale = 1.f; d.splitk = 1;
+      // PROBE_HOT_A / PROBE_HOT_B: row stride 8 elements -> the operand's rows overlap and the whole operand is ~1 MB, i.e. L2-resident for the
+      // whole launch (results are garbage): what would the kernel do if that operand never missed L2?
+      if (getenv("PROBE_HOT_A")) d.lda = 8;
+      if (getenv("PROBE_HOT_B")) d.ldb = 8;
       const bool c8 = getenv("PROBE_CODE8") != nullptr;      // 8-bit GELU' codes: C2 / aux are byte tensors (the act-3 reference below does not apply then)
       if (epi == 1) { d.bias = bias; d.act = 1; d.C2 = C2; d.ldc2 = N; d.aux_code8 = c8; }
       if (epi == 2) { d.act = 3; d.aux = X; d.ldaux = N; d.aux_code8 = c8; }
@@ -322,6 +326,16 @@ int main(int argc, char** argv) {
         }
       const char* enames[4] = {"plain", "bias+gelu+pre", "act3+aux", "bias+resid"};
       printf("M=%d N=%d K=%d epi=%s\n", M, N, K, enames[epi]);
+#ifdef VMVM_PROBE_TIMELINE
+      for (int v = 0; v < nv; ++v)
+        if (!rc[v] && !strcmp(vs[v].name, "old128") && (epi == 1 || epi == 0)) {
+          CK(hipStreamSynchronize(st));
+          probe_timeline_reset();
+          for (int i = 0; i < 20; ++i) vs[v].fn(d, st);       // warm: the timeline kept is the LAST launch's
+          CK(hipStreamSynchronize(st));
+          probe_timeline_dump(1);
+        }
+#endif
       for (int v = 0; v < nv; ++v) {
         if (rc[v]) { printf("  %-8s rc=%d\n", vs[v].name, rc[v]); continue; }
         std::sort(tms[v].begin(), tms[v].end());
