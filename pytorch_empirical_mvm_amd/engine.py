@@ -1081,6 +1081,62 @@ class VioletEngine:
         return losses, outs
 
     # -------------------------------------------------------------- downstream: text-to-video retrieval
+    # -------------------------------------------------------------- scaffolding shared by the downstream passes
+    def _begin_pass(self, img, txt, train, dp_all):
+        """new tape, DropPath draw, encoders -> (pool, Lv, X, Lq): one token pool of B clips' visual rows, then the text sequences' rows"""
+        self.tape = []
+        if train and dp_all is None:
+            dp_all = self.sample_drop_path(img.shape[0])
+        pool, Lv, _ = self.encode(img, None, txt, dp_all, train)
+        X = txt.shape[1]
+        return pool, Lv, X, Lv + X
+
+    def _fuse_pairs(self, pool, key, pairs, B, mask, Lv, X, train, cls_only):
+        """One fusion pass over the (clip i, text sequence j) pairs: rows gathered from the token pool, key mask = ones over the visual part
+        + the text's mask.  cls_only: the head reads the text [CLS] state alone, so the last layer runs for that query row only
+        (`go_cross(qrow_split=(0, Lv))`).  -> dict(out = V of the full output or of the [CLS] rows, inn, idx, n_closures)."""
+        dev = self.device
+        ar_v, ar_t = np.arange(Lv), np.arange(X)
+        idx_d = self._cached(key, lambda: _dev_i32(np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs]), dev))
+        km_txt = (mask != 0).to(torch.uint8)
+        tj = [j for _, j in pairs]
+        if tj != list(range(km_txt.shape[0])):
+            km_txt = km_txt[_h2d(torch.tensor(tj), dev)]
+        km = torch.cat([torch.ones(len(pairs), Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
+        ntape = len(self.tape)
+        if cls_only:
+            (_, out), inn, _ = self.go_cross(pool, idx_d, km, len(pairs), Lv + X, train, qrow_split=(0, Lv))
+        else:
+            out, inn, _ = self.go_cross(pool, idx_d, km, len(pairs), Lv + X, train)
+        return dict(out=out, inn=inn, idx=idx_d, n_closures=len(self.tape) - ntape)
+
+    def _cls_hidden(self, r_v, train):
+        """first half of the reference's `fc` heads on the [CLS] states (Dropout(0.1), Linear H -> 2H, ReLU; main_retrieval.py:54-56,
+        main_qaoe.py:42-47) -> state for `_cls_hidden_bwd`"""
+        S = self.store
+        p_fc = 0.1 if train else 0.0
+        off_fc = self._next_offset(r_v.numel())
+        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
+        return dict(h=K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2), x=r_vd, p=p_fc, off=off_fc)
+
+    def _cls_hidden_bwd(self, st, dh):
+        """dh = d(loss)/d(hidden) with the ReLU mask already applied -> d(loss)/d([CLS] states); accumulates fc.1's gradients"""
+        dr = self._linear_bwd(dh, st["x"], "fc.1.weight", "fc.1.bias")
+        return K.dropout(dr, st["p"], self.seed, st["off"]) if st["p"] > 0 else dr
+
+    def _finish_pass(self, fz, pool, dout):
+        """backward of the fusion pass (its closures are the newest on the tape), the token pool's gradient through the gather, the encoders"""
+        fz["out"].g = dout
+        for _ in range(fz["n_closures"]):
+            self.tape.pop()()
+        dpool = torch.zeros((pool.t.shape[0], pool.t.shape[1]), device=self.device, dtype=F32)
+        K.scatter_add_rows(fz["inn"].g, fz["idx"], dpool)
+        pool.g = K.cast_bf16(dpool)
+        while self.tape:
+            self.tape.pop()()
+        self._wgrad_join()
+
+    # -------------------------------------------------------------- downstream: text-video retrieval (SURVEY 8f.4)
     def retrieval_forward_backward(self, img, txt, mask, train=True, backward=True, dp_all=None, dlogits=None):
         """VIOLET_Retrieval.forward + NormSoftmaxLoss (main_retrieval.py:63-85, agent.py:34-50): every (video i, text j) pair of the
         batch goes through the fusion encoder (B*B sequences gathered from one token pool), the `fc` head reads the text [CLS]
@@ -1089,31 +1145,12 @@ class VioletEngine:
         the loss gradient itself is a difference of nearly equal terms whenever the scores are close, a poor probe of the
         backward path)."""
         cfg, S, dev = self.cfg, self.store, self.device
-        B, T, _, H, W = img.shape
-        X = txt.shape[1]
-        Hd = cfg["hidden"]
-        self.tape = []
-        if train and dp_all is None:
-            dp_all = self.sample_drop_path(B)
-        pool, Lv, hw = self.encode(img, None, txt, dp_all, train)
-        Lq = Lv + X
-        ar_v, ar_t = np.arange(Lv), np.arange(X)
-        pairs = [(i, j) for i in range(B) for j in range(B)]
-        idx_d = self._cached(("ret_idx", B, Lv, X), lambda: _dev_i32(
-            np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + j * X + ar_t]) for i, j in pairs]), dev))
-        km_txt = (mask != 0).to(torch.uint8)
-        tj = _h2d(torch.tensor([j for _, j in pairs]), dev)
-        km = torch.cat([torch.ones(B * B, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
-        ntape = len(self.tape)
-        (_, outc), inn, _ = self.go_cross(pool, idx_d, km, B * B, Lq, train, qrow_split=(0, Lv))     # only the text [CLS] row of the last layer is read (:76)
-        n_closures = len(self.tape) - ntape
-        r_v = outc.t
-        p_fc = 0.1 if train else 0.0
-        off_fc = self._next_offset(r_v.numel())
-        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
-        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        B, Hd = img.shape[0], cfg["hidden"]
+        pool, Lv, X, Lq = self._begin_pass(img, txt, train, dp_all)
+        fz = self._fuse_pairs(pool, ("ret_idx", B, Lv, X), [(i, j) for i in range(B) for j in range(B)], B, mask, Lv, X, train, cls_only=True)   # (:76 reads [CLS] only)
+        st = self._cls_hidden(fz["out"].t, train)
         inv_temp = 1.0 / cfg["temp"]
-        lg = K.rowdot(h_v, S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp).view(B, B)
+        lg = K.rowdot(st["h"], S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp).view(B, B)
         tgt = torch.arange(B, dtype=torch.int64, device=dev)
         loss = torch.zeros(1, device=dev, dtype=F32)
         K.cross_entropy(lg.contiguous(), B, tgt, loss, want_grad=False)                              # -mean diag log_softmax over rows
@@ -1128,19 +1165,8 @@ class VioletEngine:
         dlg = ((torch.softmax(lg, 1) - eye) / B + (torch.softmax(lg, 0) - eye) / B).reshape(-1).contiguous()
         if dlogits is not None:
             dlg = dlogits.to(dev, F32).reshape(-1).contiguous()
-        dh_v = K.rowdot_bwd(h_v, S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
-        dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
-        if p_fc > 0:
-            dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
-        outc.g = dr_v
-        for _ in range(n_closures):
-            self.tape.pop()()
-        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
-        K.scatter_add_rows(inn.g, idx_d, dpool)
-        pool.g = K.cast_bf16(dpool)
-        while self.tape:
-            self.tape.pop()()
-        self._wgrad_join()
+        dh = K.rowdot_bwd(st["h"], S.p("fc.3.weight", (2 * Hd,)), dlg, inv_temp, S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
+        self._finish_pass(fz, pool, self._cls_hidden_bwd(st, dh))
         return loss, scores
 
     # -------------------------------------------------------------- downstream: open-ended video QA
@@ -1149,26 +1175,11 @@ class VioletEngine:
         fusion pass, `fc` (Dropout, Linear, ReLU, Linear -> answer vocabulary) on the text [CLS] state.  Returns (loss f32[1],
         logits (B, size_vocab) f32)."""
         cfg, S, dev = self.cfg, self.store, self.device
-        B, T, _, H, W = img.shape
-        X = txt.shape[1]
-        Hd, NV = cfg["hidden"], int(cfg["size_vocab"])
-        self.tape = []
-        if train and dp_all is None:
-            dp_all = self.sample_drop_path(B)
-        pool, Lv, hw = self.encode(img, None, txt, dp_all, train)
-        Lq = Lv + X
-        ar_v, ar_t = np.arange(Lv), np.arange(X)
-        idx_d = self._cached(("qa_idx", B, Lv, X), lambda: _dev_i32(
-            np.concatenate([np.concatenate([i * Lv + ar_v, B * Lv + i * X + ar_t]) for i in range(B)]), dev))
-        km = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), (mask != 0).to(torch.uint8)], 1).contiguous()
-        ntape = len(self.tape)
-        (_, outc), inn, _ = self.go_cross(pool, idx_d, km, B, Lq, train, qrow_split=(0, Lv))         # only the text [CLS] row of the last layer is read
-        n_closures = len(self.tape) - ntape
-        r_v = outc.t
-        p_fc = 0.1 if train else 0.0
-        off_fc = self._next_offset(r_v.numel())
-        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
-        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        B, Hd, NV = img.shape[0], cfg["hidden"], int(cfg["size_vocab"])
+        pool, Lv, X, Lq = self._begin_pass(img, txt, train, dp_all)
+        fz = self._fuse_pairs(pool, ("qa_idx", B, Lv, X), [(i, i) for i in range(B)], B, mask, Lv, X, train, cls_only=True)
+        st = self._cls_hidden(fz["out"].t, train)
+        h_v = st["h"]
         NVp = -(-NV // 8) * 8
         logits = torch.zeros((B, NVp), device=dev, dtype=F32)
         K.gemm(h_v, S.b("fc.3.weight"), N=-(-NV // 4) * 4, bias=S.p("fc.3.bias"), out=logits)
@@ -1179,19 +1190,8 @@ class VioletEngine:
             return loss, logits[:, :NV]
         K.colsum(dlog, S.g("fc.3.bias"), accumulate=True, M=B, N=NVp)
         K.gemm(dlog, h_v, a_kmajor=False, b_kmajor=False, M=NV, N=2 * Hd, K=B, out=S.g("fc.3.weight"), accumulate=True)
-        dh_v = K.gemm(dlog, S.b("fc.3.weight"), b_kmajor=False, M=B, N=2 * Hd, K=NV, act=4, aux=h_v)          # ReLU' folded in
-        dr_v = self._linear_bwd(dh_v, r_vd, "fc.1.weight", "fc.1.bias")
-        if p_fc > 0:
-            dr_v = K.dropout(dr_v, p_fc, self.seed, off_fc)
-        outc.g = dr_v
-        for _ in range(n_closures):
-            self.tape.pop()()
-        dpool = torch.zeros((B * Lv + B * X, Hd), device=dev, dtype=F32)
-        K.scatter_add_rows(inn.g, idx_d, dpool)
-        pool.g = K.cast_bf16(dpool)
-        while self.tape:
-            self.tape.pop()()
-        self._wgrad_join()
+        dh = K.gemm(dlog, S.b("fc.3.weight"), b_kmajor=False, M=B, N=2 * Hd, K=NV, act=4, aux=h_v)            # ReLU' folded in
+        self._finish_pass(fz, pool, self._cls_hidden_bwd(st, dh))
         return loss, logits[:, :NV]
 
     # -------------------------------------------------------------- downstream: multiple-choice video QA, MLM-head form
@@ -1201,41 +1201,23 @@ class VioletEngine:
         and -1 elsewhere.  The clip's video tokens are shared by its O sequences (B*O sequences gathered from one token pool, as the
         retrieval head's pairs), the shared MLM head (`fc_mtm`) reads every text position, cross entropy with ignore_index -1.
         Returns (loss f32[1], logits (B*O*X, vocab) f32 view).  Task token / prompt (`enable_task_token`, `enable_prompt`) are off."""
-        cfg, S, dev = self.cfg, self.store, self.device
-        B, T, _, H, W = img.shape
-        O, X = int(txt.shape[1]), int(txt.shape[2])
-        Hd, Vv = cfg["hidden"], cfg["vocab"]
-        self.tape = []
-        if train and dp_all is None:
-            dp_all = self.sample_drop_path(B)
-        txt2, mask2 = txt.reshape(B * O, X).contiguous(), mask.reshape(B * O, X).contiguous()
-        pool, Lv, hw = self.encode(img, None, txt2, dp_all, train)            # pool rows: B*Lv visual, then (B*O)*X text
-        Lq = Lv + X
+        cfg, dev = self.cfg, self.device
+        B, O, Vv = img.shape[0], int(txt.shape[1]), cfg["vocab"]
         n_seq = B * O
-        ar_v, ar_t = np.arange(Lv), np.arange(X)
-        idx_d = self._cached(("qamc_idx", B, O, Lv, X), lambda: _dev_i32(
-            np.concatenate([np.concatenate([(s_ // O) * Lv + ar_v, B * Lv + s_ * X + ar_t]) for s_ in range(n_seq)]), dev))
-        km = torch.cat([torch.ones(n_seq, Lv, dtype=torch.uint8, device=dev), (mask2 != 0).to(torch.uint8)], 1).contiguous()
-        out, inn, _ = self.go_cross(pool, idx_d, km, n_seq, Lq, train)
-        txt_rows = self._cached(("qamc_txt_rows", n_seq, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(n_seq)]), dev))
+        txt2, mask2 = txt.reshape(n_seq, -1).contiguous(), mask.reshape(n_seq, -1).contiguous()
+        pool, Lv, X, Lq = self._begin_pass(img, txt2, train, dp_all)          # pool rows: B*Lv visual, then (B*O)*X text
+        fz = self._fuse_pairs(pool, ("qamc_idx", B, O, Lv, X), [(s_ // O, s_) for s_ in range(n_seq)], B, mask2, Lv, X, train, cls_only=False)
+        txt_rows = self._cached(("qamc_txt_rows", n_seq, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + np.arange(X) for i in range(n_seq)]), dev))
         nr = n_seq * X
         loss = torch.zeros(1, device=dev, dtype=F32)
-        hd = self._mlm_head_fwd(K.gather_rows(out.t, txt_rows, nr), nr, mask_ans.to(dev).reshape(-1).contiguous(), loss, backward)
+        hd = self._mlm_head_fwd(K.gather_rows(fz["out"].t, txt_rows, nr), nr, mask_ans.to(dev).reshape(-1).contiguous(), loss, backward)
         lg_ = hd["logits"]
         if not backward:
             self.tape = []
             return loss, lg_[:, :Vv]
         dtxt = self._mlm_head_bwd(hd)
         inv = self._cached(("qamc_inv", n_seq, Lq, Lv, X), lambda: self._inverse_rows(n_seq * Lq, [txt_rows]))
-        out.g = K.gather_rows(dtxt, inv, n_seq * Lq)
-        for _ in range(cfg["bert_layers"]):
-            self.tape.pop()()
-        dpool = torch.zeros((B * Lv + n_seq * X, Hd), device=dev, dtype=F32)
-        K.scatter_add_rows(inn.g, idx_d, dpool)
-        pool.g = K.cast_bf16(dpool)
-        while self.tape:
-            self.tape.pop()()
-        self._wgrad_join()
+        self._finish_pass(fz, pool, K.gather_rows(dtxt, inv, n_seq * Lq))
         return loss, lg_[:, :Vv]
 
     def _inverse_rows(self, n_rows, row_lists):
