@@ -742,7 +742,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     const int logical = x_start + w;
     slice = logical / nb;
     int tm, tn;
-    raster(logical - slice * nb, nbm, nbn, 8, tm, tn);
+#ifndef VMVM_PROBE_GM
+#define VMVM_PROBE_GM 8          /* probe builds only: M panels per raster group of the 128x128 persistent kernel */
+#endif
+    raster(logical - slice * nb, nbm, nbn, VMVM_PROBE_GM, tm, tn);
     m0 = tm * BM; n0 = tn * BN;
     kt0 = slice * per;
     nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;

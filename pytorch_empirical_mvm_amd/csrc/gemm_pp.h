@@ -104,7 +104,10 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
     const int logical = x_start + w;
     slice = logical / nb;
     int tm, tn;
-    raster(logical - slice * nb, nbm, nbn, 16 / WM, tm, tn);
+#ifndef VMVM_PROBE_GM_PP
+#define VMVM_PROBE_GM_PP (16 / WM)   /* probe builds only: M panels per raster group of the ping-pong kernel */
+#endif
+    raster(logical - slice * nb, nbm, nbn, VMVM_PROBE_GM_PP, tm, tn);
     m0 = tm * TM; n0 = tn * PP_T;
     kt0 = slice * per;
     nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
