@@ -1490,11 +1490,12 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // (tools/scratch/msplit_probe.py): 69120 x 768 x 3072 404 -> 361 us, x 2304 280 -> 265 us; a loss at K = 768 and when the
     // remainder is more than ~a quarter of a round (50176 x 512: 1.53 rounds).  Row-indexed epilogue operands move with the rows;
     // the dropout stream is indexed by the absolute element (8-element blocks), so its offset moves by m_split * N / 8.
-    if (pays && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > 256 && !(dd.N & 7)) {
+    const int cus_ = vmvm_usable_cus(dd.reserve_cus);      // the ping-pong grid: one workgroup per usable CU (fewer while a collective is pending)
+    if (pays && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
       const int nbn_ = (dd.N + 255) / 256, nbm_ = (dd.M + 255) / 256;
-      const int tm_split = (int)(((tiles / 256) * 256) / nbn_);
+      const int tm_split = (int)(((tiles / cus_) * cus_) / nbn_);
       const long rem_tiles = (long)(nbm_ - tm_split) * nbn_;
-      if (tm_split > 0 && tm_split < nbm_ && rem_tiles <= 64) {
+      if (tm_split > 0 && tm_split < nbm_ && rem_tiles <= cus_ / 4) {
         const int m_split = tm_split * 256;
         vmvm_gemm_desc d1 = dd;
         d1.M = m_split;
