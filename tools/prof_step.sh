@@ -16,3 +16,4 @@ python3 $GRAFT_REPO_ROOT/tools/prof_hist.py $DB gemm_pers_kernelILb1ELb1ELi37E >
 python3 $GRAFT_REPO_ROOT/tools/prof_hist.py $DB gemm_pp_kernelILb1ELb1ELi16432E >> $GRAFT_REPO_ROOT/gpurun_out/step_roofline_kernel_clusters.txt 2>&1
 head -40 $GRAFT_REPO_ROOT/gpurun_out/step_trace.txt | cut -c1-170
 python3 $GRAFT_REPO_ROOT/tools/prof_streams.py $DB 400 > $GRAFT_REPO_ROOT/gpurun_out/step_streams.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/prof_window.py $DB patch_embed_fwd 40 6 > $GRAFT_REPO_ROOT/gpurun_out/step_boundary.txt 2>&1
