@@ -260,3 +260,28 @@ def test_2d_to_3d_weight_inflation_matches_reference_outputs():
     t = torch.randn(169, 3)
     out = inflate_2d_state({"layers.0.blocks.0.attn.relative_position_bias_table": t}, arch, {"layers.0.blocks.0.attn.relative_position_bias_table": (2535, 1)})
     assert out["layers.0.blocks.0.attn.relative_position_bias_table"] is t
+
+
+def test_dropscale_kept_lists_padding_and_single_scale():
+    """engine.DropScale (host side of the DropPath dead-clip elimination): kept / dropped clip lists with -1 behind their entries, the kept clips'
+    scales followed by zeros, ONE scale per draw (None for hand-made non-uniform scales), and `take`: the clip count a branch runs on = the kept
+    count rounded up so that count * rows_per_clip is a multiple of 64 (the K tile of the weight-gradient GEMMs), capped at the batch."""
+    import numpy as np
+    import torch
+    from pytorch_empirical_mvm_amd.engine import DropScale
+    s = 1.0 / 0.8
+    d = DropScale(torch.tensor([s, 0, s, s, 0, s, s, 0], dtype=torch.float32))
+    assert d.n_kept == 5 and abs(d.scale - s) < 1e-6
+    assert d.kept.tolist() == [0, 2, 3, 5, 6, -1, -1, -1] and d.dropped.tolist() == [1, 4, 7, -1, -1, -1, -1, -1]
+    np.testing.assert_allclose(d.dev_kept.numpy(), [s] * 5 + [0, 0, 0], rtol=1e-6)
+    assert d.take(6272, 8)[0] == 5            # Swin-B stage 2: 6 272 rows per clip, any count fills whole K tiles
+    assert d.take(1568, 8)[0] == 6            # stage 3: 1 568 = 24.5 x 64 -> even counts (one padding clip)
+    assert d.take(392, 8)[0] == 8             # stage 4: 392 = 6.125 x 64 -> multiples of 8 (here: the whole batch, nothing to eliminate)
+    assert d.take(392, 32)[0] == 8 and d.take(1568, 5)[0] == 5          # ... and never more than the batch
+    for n in range(0, 9):
+        for rows in (25088, 6272, 1568, 392, 4608, 1152, 100):
+            k = DropScale(torch.tensor([s] * n + [0.0] * (8 - n))).take(rows, 8)[0]
+            assert k >= n and (k == 8 or (k * rows) % 64 == 0) and (k - n) * rows < 64 * rows
+    assert DropScale(torch.zeros(4)).n_kept == 0 and DropScale(torch.zeros(4)).scale is None
+    assert DropScale(torch.tensor([1.25, 0.0, 1.5])).scale is None      # hand-made non-uniform scales: the engine keeps the scaled formulation
+    assert DropScale(torch.ones(3)).take(1568, 3)[0] == 3
