@@ -295,7 +295,8 @@ def main():
         # algorithmic FLOPs of the reference's step (2.060 TFLOP per clip).  Executed: 3.3 % fewer -- in the last fusion layer only the
         # text [CLS] query row of the VTM sequences is computed (the only row the VTM head reads; same losses and gradients)
         "step_flop_note": "step_mfma_frac counts the reference's algorithmic 2.060 TFLOP/clip; not executed: 0.068 TFLOP/clip of dead query rows in the VTM pass' last fusion layer and, "
-                          "on average, ~9 % of the Video-Swin block FLOPs (clip-branches whose DropPath draw is 0) -- results are those of the full computation",
+                          "on average, ~9 % of the Video-Swin block FLOPs (clip-branches whose DropPath draw is 0) -- results are those of the full computation; "
+                          "VMVM_QROW=0 VMVM_DROPPATH_DCE=0 executes everything as the reference formulates it (same build, one box: 114.6-115.0 ms against 110.2-110.9)",
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
                      "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * (1 + O) * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "
