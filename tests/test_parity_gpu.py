@@ -5,9 +5,10 @@ Tolerances AS ASSERTED below (bf16 activations / MFMA inputs, f32 accumulation a
 * sampled outputs / gradients against the reference's fixtures (`_check_samples`): cosine >= 0.995 over the samples and every sample
   within 2 * tol of the tensor scale, tol = 5e-2 unless a test states another (1e-1 where an L1 loss makes the gradient a sign);
   the reduced-Swin gradient fixture: every sample within 8e-2 of the tensor scale for all but at most two tensors;
-* per-tensor gradients against the oracle's autograd: cosine >= 0.99 and norm within 5 % for every tensor whose gradient norm is
-  above 1e-3 of the largest (SURVEY.md section 9 suggests 0.999; what 24 bf16 blocks + 12 fusion layers deliver at temp = 0.05 scale
-  is measured per tensor in tests/test_round2_gpu.py: two thirds of the tensors above 0.9995, none below 0.99); global gradient
+* per-tensor gradients against the oracle's autograd: cosine >= 0.997 and norm within 2.5 % for every tensor whose gradient norm is
+  above 1e-3 of the largest.  Measured over the 378 tensors these tests compare (`test_zz_report_margins`, run with -s): cosine min 0.9986,
+  1st percentile 0.9994, median 0.9999 -- 99.5 % of the tensors above the 0.999 that SURVEY.md section 9 suggests --, norm ratio off by at most
+  0.9 % (median 0.2 %); global gradient
   norm within 1 % (6 % at the reference's temp = 0.05, where the VTM branch is amplified 20x);
 * out_vtm: absolute 0.35 at logit scale 1 / temp = 20 (a difference of two bf16-rounded [CLS] states times 20);
 * the VTM head's fc.3.weight gradient (a difference of bf16-rounded activations): cosine >= 0.95; AdamW update direction after one
@@ -21,6 +22,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+_MARGINS = []          # (cosine, |norm ratio - 1|) of every gradient tensor compared in this module; summarised by `test_zz_report_margins`
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -125,7 +127,7 @@ def test_reduced_swin_pad_and_temporal_shift_vs_reference_golden():
 @pytest.mark.parametrize("tasks", [("vtm", "mlm", "mvm"), ("vtm", "mlm", "mvm", "smtm")], ids=["default", "smtm"])
 def test_gradients_per_tensor_vs_oracle(tasks):
     """Every parameter gradient of the full step (Swin + fusion + heads; reduced widths, temp=1.0 so the VTM cancellation
-    noise is not amplified) against the CPU oracle's autograd: cosine >= 0.99 and norm within 5% for every tensor whose
+    noise is not amplified) against the CPU oracle's autograd: cosine >= 0.997 and norm within 2.5% for every tensor whose
     gradient norm is above 1e-3 of the largest one.  `smtm`: with the third (seq2seq-masked) fusion pass."""
     from oracle import violet_ref as R
     arch = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
@@ -159,7 +161,8 @@ def test_gradients_per_tensor_vs_oracle(tasks):
         cos = _cos(got, ref)
         ratio = float(got.norm() / ref.norm())
         checked += 1
-        if cos < 0.99 or abs(ratio - 1.0) > 0.05:
+        _MARGINS.append((cos, abs(ratio - 1.0)))
+        if cos < 0.997 or abs(ratio - 1.0) > 0.025:
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert checked > 100 and not bad, (checked, bad[:12])
 
@@ -318,7 +321,8 @@ def test_c5_window_and_sequence_lengths_vs_oracle():
         cos = _cos(got, ref)
         ratio = float(got.norm() / ref.norm())
         checked += 1
-        if cos < 0.99 or abs(ratio - 1.0) > 0.05:
+        _MARGINS.append((cos, abs(ratio - 1.0)))
+        if cos < 0.997 or abs(ratio - 1.0) > 0.025:
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert checked > 80 and not bad, (checked, bad[:12])
 
@@ -774,3 +778,14 @@ def test_fp8_forward_gemms_stay_close_to_the_oracle():
     assert _cos(outs["out_mvm"].float().cpu(), ref["out"]["out_mvm"]) >= 0.995
     assert _cos(outs["out_mtm"].float().cpu(), ref["out"]["out_mtm"]) >= 0.995
     assert bool(torch.isfinite(eng.store.grad[:eng.store.n_trainable]).all())
+
+
+def test_zz_report_margins():
+    """not a check: prints what the per-tensor gradient comparisons of this module measured (run with -s), so that the asserted tolerances can be
+    read against the margins they leave"""
+    import numpy as np
+    if not _MARGINS:
+        pytest.skip("no gradient comparison ran")
+    c = np.array([m[0] for m in _MARGINS]); r = np.array([m[1] for m in _MARGINS])
+    print(f"\n[{__name__}] {len(c)} gradient tensors compared: cosine min {c.min():.5f}, 1st percentile {np.percentile(c, 1):.5f}, median {np.median(c):.5f}; "
+          f"share above 0.999: {np.mean(c > 0.999):.3f}, above 0.995: {np.mean(c > 0.995):.3f}; |norm ratio - 1| max {r.max():.4f}, median {np.median(r):.4f}")

@@ -1,7 +1,8 @@
 """Round-3 parity cases: the TRAIN-mode path -- the configuration `bench.py` times -- against the CPU oracle.
 
 Tolerances asserted here (bf16 activations / MFMA inputs, f32 accumulation and statistics, against the fp32 oracle):
-losses <= 2e-2 relative; every parameter gradient with norm above 1e-3 of the largest: cosine >= 0.99 and norm within 5 %;
+losses <= 2e-2 relative; every parameter gradient with norm above 1e-3 of the largest: cosine >= 0.998 and norm within 2 % (measured:
+min 0.99957, <= 0.7 %; `test_zz_report_margins` prints them with -s);
 global gradient norm within 1 %.  Layer-level comparisons (one fusion layer on identical inputs and identical dropout
 masks): output cosine >= 0.9995, input / parameter gradients cosine >= 0.995 and norm within 3 %.
 
@@ -24,6 +25,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+_MARGINS = []          # (cosine, |norm ratio - 1|) of every gradient tensor compared in this module; summarised by `test_zz_report_margins`
 
 
 def _cos(a, b):
@@ -113,8 +115,9 @@ def test_train_mode_step_vs_oracle():
         ref = p.grad.double().flatten()
         cos, ratio = _cos(got, ref), float(got.norm() / ref.norm())
         checked += 1
+        _MARGINS.append((cos, abs(ratio - 1.0)))
         n_bias += name.endswith(("mlp.fc2.bias", "attn.proj.bias"))               # the DropPath-weighted column sums
-        if cos < 0.99 or abs(ratio - 1.0) > 0.05:
+        if cos < 0.998 or abs(ratio - 1.0) > 0.02:                                     # (measured: min 0.99957, norm ratio off by <= 0.7 %)
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert checked > 300 and n_bias >= 40 and not bad, (checked, n_bias, bad[:12])
 
@@ -268,6 +271,7 @@ def test_fusion_layer_train_mode_dropout_vs_oracle():
             continue
         cos, ratio = _cos(gg, rr), float(gg.norm() / rr.norm())
         checked += 1
+        _MARGINS.append((cos, abs(ratio - 1.0)))
         if cos < 0.995 or abs(ratio - 1.0) > 0.03:
             bad.append((name, round(cos, 4), round(ratio, 3)))
     assert len(params) == 16 and checked == 15 and not bad, (checked, bad)
@@ -360,3 +364,14 @@ def test_mlm_qa_variants_vs_reference_golden():
         assert np.isfinite(v) and v > 0
         del model, agent
         torch.cuda.empty_cache()
+
+
+def test_zz_report_margins():
+    """not a check: prints what the per-tensor gradient comparisons of this module measured (run with -s), so that the asserted tolerances can be
+    read against the margins they leave"""
+    import numpy as np
+    if not _MARGINS:
+        pytest.skip("no gradient comparison ran")
+    c = np.array([m[0] for m in _MARGINS]); r = np.array([m[1] for m in _MARGINS])
+    print(f"\n[{__name__}] {len(c)} gradient tensors compared: cosine min {c.min():.5f}, 1st percentile {np.percentile(c, 1):.5f}, median {np.median(c):.5f}; "
+          f"share above 0.999: {np.mean(c > 0.999):.3f}, above 0.995: {np.mean(c > 0.995):.3f}; |norm ratio - 1| max {r.max():.4f}, median {np.median(r):.4f}")
