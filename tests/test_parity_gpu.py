@@ -10,9 +10,9 @@ Tolerances AS ASSERTED below (bf16 activations / MFMA inputs, f32 accumulation a
   1st percentile 0.9994, median 0.9999 -- 99.5 % of the tensors above the 0.999 that SURVEY.md section 9 suggests --, norm ratio off by at most
   0.9 % (median 0.2 %); global gradient
   norm within 1 % (6 % at the reference's temp = 0.05, where the VTM branch is amplified 20x);
-* out_vtm: absolute 0.35 at logit scale 1 / temp = 20 (a difference of two bf16-rounded [CLS] states times 20);
-* the VTM head's fc.3.weight gradient (a difference of bf16-rounded activations): cosine >= 0.95; AdamW update direction after one
-  step (sign-like at step 1): cosine >= 0.85.
+* out_vtm: absolute 0.15 at logit scale 1 / temp = 20 (a difference of two bf16-rounded [CLS] states times 20; measured 0.05);
+* the VTM head's fc.3.weight gradient (a difference of bf16-rounded activations): cosine >= 0.97 (measured 0.984), fc.1.*: >= 0.999; AdamW
+  update direction after three steps (sign-like at step 1): cosine >= 0.98 (measured 0.995), update norm within 3 %.
 Attention-probability dropout is quantised to p = 26/256 = 0.1016 with the matching keep scale 256/230 (unbiased; the reference's
 p = 0.1): tests/test_round3_gpu.py feeds the kernels' own masks to the oracle."""
 import os
@@ -74,7 +74,8 @@ def test_c1_losses_outputs_grads_vs_reference_golden():
         # VTM logits are divided by temp=0.05: bf16 rounding of the [CLS] state is amplified 20x -> absolute tolerance
         tol = 5e-2 if k == "vtm" else 2e-2 * abs(float(ref)) + 1e-3
         assert abs(got - float(ref)) <= tol, (k, got, float(ref))
-    np.testing.assert_allclose(outs["out_vtm"].float().cpu().numpy(), d["out_vtm"], atol=0.35, rtol=0.05)      # logits are /temp=0.05
+    print(f"\n[c1 golden] out_vtm max |diff| {np.abs(outs['out_vtm'].float().cpu().numpy() - d['out_vtm']).max():.4f} at logit scale 20")
+    np.testing.assert_allclose(outs["out_vtm"].float().cpu().numpy(), d["out_vtm"], atol=0.15, rtol=0.05)      # logits are /temp=0.05 (measured max |diff| 0.05)
     _check_samples(d, "out_mtm", outs["out_mtm"])
     _check_samples(d, "out_mvm", outs["out_mvm"].float())
     # gradients: global norm and per-tensor sampled entries
@@ -201,8 +202,9 @@ def test_train_step_matches_oracle_adamw_trajectory():
     got = model.state_dict()
     ur = torch.cat([(v - R.closed_form(k, tuple(v.shape))).double().flatten() for k, v in sd.items()])
     ug = torch.cat([(got[k].cpu() - R.closed_form(k, tuple(v.shape))).double().flatten() for k, v in sd.items()])
-    assert float(ur.norm()) > 0 and _cos(ur, ug) > 0.85, _cos(ur, ug)
-    assert abs(float(ug.norm()) / float(ur.norm()) - 1.0) < 0.1
+    print(f"\n[adamw trajectory] update-direction cosine {_cos(ur, ug):.4f}, norm ratio {float(ug.norm()) / float(ur.norm()):.4f}")
+    assert float(ur.norm()) > 0 and _cos(ur, ug) > 0.98, _cos(ur, ug)                    # (measured 0.9954)
+    assert abs(float(ug.norm()) / float(ur.norm()) - 1.0) < 0.03                           # (measured 0.2 %)
 
 
 def test_vq_target_head_loss_and_grads_vs_reference_golden():
@@ -619,7 +621,7 @@ def test_retrieval_pairs_scores_loss_and_step():
     model.eval()
     scores, ans = model(img, txt, mask)
     ref = d["out"]
-    # bf16 rounding of the [CLS] state: the C1 test allows 0.35 on these scores / temp, i.e. 0.0175 here
+    # bf16 rounding of the [CLS] state: 0.35 on these scores / temp, i.e. 0.0175 here (the C1 test, measured at 0.05, asserts 0.15 since round 3)
     assert np.abs(scores.cpu().double().numpy() - ref).max() <= 1.75e-2, (scores, ref)
     eng = model.engine
     loss, _ = eng.retrieval_forward_backward(img.cuda(), txt.cuda(), mask.cuda(), train=False, backward=False)

@@ -65,15 +65,16 @@ def test_full_size_c2_gradients_vs_oracle():
             assert abs(float(losses[k].item()) - float(ls[k].detach())) <= 2e-2 * abs(float(ls[k].detach())) + 1e-3, (temp, k)
         # VTM head on the engine's own [CLS] rows
         # (fc.1.weight as the bf16 copy the GEMM multiplies: which ReLU units sit at the pos / neg boundary decides the gradient's
-        #  direction here; fc.3.weight is a difference of bf16-rounded activations: 0.95; fc.3.bias: analytically zero)
+        #  direction here; fc.3.weight is a difference of bf16-rounded activations: 0.97; fc.3.bias: analytically zero)
         hp = {k: (sd[k].to(torch.bfloat16).float() if k == "fc.1.weight" else sd[k].clone()).requires_grad_(True)
               for k in ("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias")}
         lg = R.vtm_head(hp, outs["vtm_cls"].float().cpu(), temp).view(B, -1)
         torch.nn.functional.cross_entropy(lg, torch.zeros(B, dtype=torch.long)).backward()
-        for k, thr in (("fc.1.weight", 0.99), ("fc.1.bias", 0.99), ("fc.3.weight", 0.95)):
+        for k, thr in (("fc.1.weight", 0.999), ("fc.1.bias", 0.999), ("fc.3.weight", 0.97)):          # (measured: 0.99995, 0.99996, 0.984)
             got = eng.store.g(k).detach().cpu().double().flatten()
             c = _cos(got, hp[k].grad)
-            assert c >= thr and abs(float(got.norm() / hp[k].grad.double().norm()) - 1.0) <= 0.1, (temp, k, c)
+            print(f"\n[vtm head, temp {temp}] {k}: cosine {c:.5f}, norm ratio {float(got.norm() / hp[k].grad.double().norm()):.4f}")
+            assert c >= thr and abs(float(got.norm() / hp[k].grad.double().norm()) - 1.0) <= 0.05, (temp, k, c)
         ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
         S = eng.store
         got_norm = float(torch.sqrt((S.grad[:S.n_trainable].double() ** 2).sum()).item())
