@@ -214,6 +214,14 @@ typedef struct {
    * VIOLET_Pretrain.get_att's `cat([a.mean(dim=1, keepdim=True) ...]).sum(dim=(1, 2))` (main_pretrain.py:211-215), the sampling
    * weights of the attention-guided 'am' masking, without materialising attentions.  Resident kernels only (L <= 448). */
   float* att_colsum; float att_scale;
+  /* mode 0, L = 392 (window (8,7,7), head_dim 32), 0 = off: the caller lays the tokens of a window out in the order of
+   * swin_index.win3_perm -- slot = tile * 16 + l * 8 + d, two (h, w) positions x 8 temporal slices per 16-token tile, the (h, w)
+   * positions region-major for the (0,3,3) shift -- and `rc` / `region` are given in that order.  The relative-position bias of a
+   * score tile is then four 8 x 8 Toeplitz blocks (one 16-byte LDS read per lane and tile from a windowed copy of the head's table
+   * column instead of a register-resident bias block per wave), every tile lies in one mask region of every window, and the
+   * (query tile, key tile) pairs the shift mask (video_swin.py:292-307) zeroes are skipped.  `region` must be tile-uniform (checked on
+   * the host side by the caller); kernels without a win_layout build ignore the flag (they are order-agnostic). */
+  int32_t win_layout;
 } vmvm_attn_fwd_desc;
 int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
 

@@ -61,7 +61,7 @@ class AttnFwdDesc(C.Structure):
                 ("region", c_void_p), ("n_win", c_int),
                 ("keymask", c_void_p),
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
-                ("seq_scale", c_void_p), ("seqs_per_scale", c_int), ("stream_min_len", c_int), ("causal_from", c_int), ("att_colsum", c_void_p), ("att_scale", c_float)]
+                ("seq_scale", c_void_p), ("seqs_per_scale", c_int), ("stream_min_len", c_int), ("causal_from", c_int), ("att_colsum", c_void_p), ("att_scale", c_float), ("win_layout", c_int)]
 
 
 class AttnBwdDesc(C.Structure):

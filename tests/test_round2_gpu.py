@@ -36,7 +36,8 @@ def _engine(cfg_args):
 @pytest.mark.timeout(1500)
 def test_full_size_c2_gradients_vs_oracle():
     """Swin-B, T = 8, 224^2, B = 2: every parameter gradient with norm above 1e-3 of the largest against the CPU oracle's autograd
-    at temp = 1.0 (cosine >= 0.99, norm within 5 %), the global gradient norm within 1 %; then the
+    at temp = 1.0 (cosine >= 0.997, norm within 2.5 %: the bars README and the header of test_parity_gpu.py state;
+    measured minimum 0.9986), the global gradient norm within 1 %; then the
     global gradient norm at the reference's temp = 0.05 (6 %).
     The VTM head `fc.1` / `fc.3`: its gradient is p(neg) * (h(neg) - h(pos)) of two [CLS] states that differ only through the text
     (a difference far below bf16 resolution with closed-form weights), so it is compared with the oracle's head evaluated on the
@@ -91,7 +92,7 @@ def test_full_size_c2_gradients_vs_oracle():
                 ref = p.grad.double().flatten()
                 cos, ratio = _cos(got, ref), float(got.norm() / ref.norm())
                 checked += 1
-                if cos < 0.99 or abs(ratio - 1.0) > 0.05:
+                if cos < 0.997 or abs(ratio - 1.0) > 0.025:
                     bad.append((name, round(cos, 4), round(ratio, 3)))
             assert checked > 300 and not bad, (checked, bad[:12])
         del model, eng, params
@@ -443,7 +444,7 @@ def test_full_size_c4_vq_target_step_vs_oracle():
     """BASELINE config 4 at full width on one GPU (Swin-B, 8 x 224^2 frames, vq target with the full dVAE tokenizer: n_hid 256, 8192
     codes, every pass a libvmvm kernel), B = 2, against the CPU oracle on the same weights and batch: token agreement of the native
     fp16 tokenizer with the oracle's fp32 encoder, then -- with the ORACLE's tokens as targets on both sides, so an arg-max near-tie
-    does not decide the comparison -- the three losses, the vq-head gradients (cosine >= 0.99, norm +-5 %) and the global norm."""
+    does not decide the comparison -- the three losses, the vq-head gradients (cosine >= 0.997, norm +-2.5 %, the bars of the C2 test) and the global norm."""
     from oracle import violet_ref as R
     from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -481,7 +482,8 @@ def test_full_size_c4_vq_target_step_vs_oracle():
         got = eng.store.g(k).detach().cpu().double().flatten()
         ref = params[k].grad.double().flatten()
         c, ratio = _cos(got, ref), float(got.norm() / ref.norm())
-        assert c >= 0.99 and abs(ratio - 1.0) <= 0.05, (k, c, ratio)
+        print(f"\n[c4 vq head] {k}: cosine {c:.5f}, norm ratio {ratio:.4f}")
+        assert c >= 0.997 and abs(ratio - 1.0) <= 0.025, (k, c, ratio)
     ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
     S = eng.store
     got_norm = float(torch.sqrt((S.grad[:S.n_trainable].double() ** 2).sum()).item())

@@ -434,13 +434,19 @@ def check_attn_window():
     for (dims, B, heads) in [((8, 14, 14), 2, 4), ((4, 7, 7), 3, 3), ((12, 24, 20), 1, 2)]:
         D, H, W = dims
         win = (8, 7, 7)
-        for shifted in (False, True):
+        for shifted, layout in ((False, 0), (True, 0), (False, 1), (True, 1)):
             ws, ss = SI.get_window_size(dims, win, (4, 3, 3) if shifted else (0, 0, 0))
+            if layout and not SI.win3_ok(ws, ss):
+                continue
             m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
             N = ws[0] * ws[1] * ws[2]
             nW = m.size // N
             reg = SI.region_ids(Dp, Hp, Wp, ws, ss)
             rc, rc0 = SI.rc_codes(N, win)
+            if layout:                                    # the win_layout = 1 token order: slot tables permuted, the reference below is order-agnostic
+                pm = SI.win3_perm()
+                rc = np.ascontiguousarray(rc[pm])
+                reg = None if reg is None else np.ascontiguousarray(reg[:, pm])
             C_ = heads * 32
             nseq = B * nW
             qkv = rnd(nseq * N, 3 * C_, scale=1.0)
@@ -449,7 +455,7 @@ def check_attn_window():
             reg_t = torch.from_numpy(reg).to(dev) if reg is not None else None
             sscale = (torch.rand(B, device=dev) + 0.5)
             out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t,
-                                       rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW)
+                                       rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW, win_layout=layout)
             qf = qkv.float().requires_grad_(True)
             tf = table.clone().requires_grad_(True)
             x = qf.view(nseq, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
@@ -461,13 +467,13 @@ def check_attn_window():
             o = attn_ref(x[0], x[1], x[2], bias)                                              # (nseq, heads, N, 32)
             sc = sscale.repeat_interleave(nW)[:, None, None, None]
             ref = (o * sc).transpose(1, 2).reshape(nseq * N, C_)
-            tag = f"win attn {dims} shifted={shifted}"
+            tag = f"win attn {dims} shifted={shifted} layout={layout}"
             rep(tag + " fwd", out, ref)
             dout = rnd(nseq * N, C_)
             ref.backward(dout.float())
             dtab = torch.zeros_like(table)
             dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table,
-                                   rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW, dbias_table=dtab)
+                                   rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, seq_scale=sscale, seqs_per_scale=nW, dbias_table=dtab, win_layout=layout)
             gq = qf.grad.clone()
             gq[:, :C_] *= 32 ** -0.5                      # kernel returns d(q_linear) = scale * d(q_scaled)
             rep(tag + " bwd dq", dqkv[:, :C_], gq[:, :C_])
@@ -982,25 +988,38 @@ def bench_gemm():
 def bench_attn():
     print("---- attention timing")
     # the four Swin-B stages of the C2 workload (8 frames, each doubled -> D=8 -> window (8,7,7) = 392 tokens) + a half-depth window
-    for label, B, heads, N, ws, dims in (("stage-1", 32, 4, 392, (8, 7, 7), (8, 56, 56)), ("stage-2", 32, 8, 392, (8, 7, 7), (8, 28, 28)),
-                                         ("stage-3", 32, 16, 392, (8, 7, 7), (8, 14, 14)), ("stage-4", 32, 32, 392, (8, 7, 7), (8, 7, 7)),
-                                         ("stage-3/D=4", 32, 16, 196, (4, 7, 7), (4, 14, 14))):
-        shift = (0, 3, 3) if dims[1] > 7 else (0, 0, 0)
+    cases = [("stage-1", 32, 4, 392, (8, 7, 7), (8, 56, 56), True), ("stage-2", 32, 8, 392, (8, 7, 7), (8, 28, 28), True),
+             ("stage-3", 32, 16, 392, (8, 7, 7), (8, 14, 14), True), ("stage-3 unshifted", 32, 16, 392, (8, 7, 7), (8, 14, 14), False),
+             ("stage-4", 32, 32, 392, (8, 7, 7), (8, 7, 7), False), ("stage-3/D=4", 32, 16, 196, (4, 7, 7), (4, 14, 14), True)]
+    layouts = [int(x) for x in os.environ.get("VMVM_BENCH_LAYOUTS", "0,1").split(",")]
+    only = os.environ.get("VMVM_BENCH_ONLY")
+    if only:
+        cases = [c for c in cases if c[0] in only.split(",")]
+    for (label, B, heads, N, ws, dims, sh), layout in [(c, l) for c in cases for l in layouts]:
+        shift = (0, 3, 3) if sh else (0, 0, 0)
+        if layout and not SI.win3_ok(ws, shift):
+            continue
+        label = label + (" layout=1" if layout else "")
         nW = (dims[1] // 7) * (dims[2] // 7)
         nseq = B * nW
         C_ = heads * 32
         qkv = rnd(nseq * N, 3 * C_)
         rc, rc0 = SI.rc_codes(N, (8, 7, 7))
+        reg_np = SI.region_ids(dims[0], dims[1], dims[2], ws, shift) if any(shift) else None
+        if layout:
+            pm = SI.win3_perm()
+            rc = np.ascontiguousarray(rc[pm])
+            reg_np = None if reg_np is None else np.ascontiguousarray(reg_np[:, pm])
         rc_t = torch.from_numpy(rc).to(dev)
         table = torch.randn(2535, heads, device=dev) * 0.1
-        reg = torch.from_numpy(SI.region_ids(dims[0], dims[1], dims[2], ws, shift)).to(dev) if any(shift) else None
-        f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
+        reg = torch.from_numpy(reg_np).to(dev) if reg_np is not None else None
+        f = lambda: K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, win_layout=layout)
         out, lse = f()
         dout = rnd(nseq * N, C_)
         dtab = torch.zeros_like(table)
-        b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab)
+        b = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=dtab, win_layout=layout)
         fl = 4.0 * nseq * heads * N * N * 32
-        b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None)
+        b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None, win_layout=layout)
         for name, fn, mult in (("win fwd", f, 1), ("win bwd", b, 2.5), ("win bwd (no table grad)", b0, 2.5)):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
