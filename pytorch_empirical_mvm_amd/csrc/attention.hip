@@ -2261,6 +2261,7 @@ inline bool use_stream(const vmvm_attn_fwd_desc* d) { return d->L > 448 || (d->s
 namespace vmvm_w3 {
 bool applicable(const vmvm_attn_fwd_desc* d);
 int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
+int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w3
 
 #define LAUNCH_FWD(HD, MODE, NTM, NW, NX, MASK)                                              \
@@ -2438,7 +2439,11 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     const int tl4 = (d->f.table_len + 3) & ~3, lr4 = (d->f.L + 3) & ~3;
     const int smem2 = 4 * lp32 * 64 + 2 * tl4 * 4 + 2 * (ns - 1) * nq * 64 * 8 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && smem2 <= 160 * 1024;
-    if (pers_ok) {
+    const bool w3 = vmvm_w3::applicable(&d->f) && !getenv("VMVM_NO_WIN3");
+    if (w3 && !getenv("VMVM_NO_WIN3_DQ")) {
+      int rc_ = vmvm_w3::launch_dq(d, st);
+      if (rc_) return rc_;
+    } else if (pers_ok) {
       // nt = 25 (392-token window): 4 query tiles x 2 key splits (8 waves, ~220 VGPRs, no spill); nt = 13: 7 tiles x 1 split.
       // Measured alternatives on MI355X (stage-3 shape, B=32): (5,2)/(6,2) spill, (4,3) is 15% slower.
       const int nqg2 = (s_.nt + nq - 1) / nq;

@@ -14,10 +14,17 @@
 //    live-class set with the masked tiles absent at compile time (49 % of the tile pairs of an edge window, 74 % of a corner window).
 #include "attn_common.h"
 #include "attn_win3.h"
+#include <cstdlib>
 
 namespace {
 
 template <int V> struct IC { static constexpr int value = V; };
+#ifdef W3_TIMELINE
+__device__ unsigned long long w3_dbg[8192];
+#define W3_T(slot) do { if (tl_on) { tl_buf[tl_n++] = ((unsigned long long)(slot) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); } } while (0)
+#else
+#define W3_T(slot) do { } while (0)
+#endif
 #ifndef W3_ABL
 #define W3_ABL 0
 #endif
@@ -69,33 +76,24 @@ __device__ __forceinline__ void tr_read4_2(s16x4& a0, s16x4& a1, s16x4& c0, s16x
 }
 
 // ================================================================================================
-// dK / dV.  A workgroup = (head, key group, chunk of clips): key group 0 = classes A + B (tiles 0-13), 1 = C + D (tiles 14-24); each
-// of its 8 waves owns TWO key tiles of one class (K / V fragments in registers, prefetched per sequence) and walks the LIVE query
-// tiles of the window type in pairs; Q / dO images + lse / delta of the next sequence stream into the other LDS buffer by DMA spread
-// over the walk.  Lane (r, g): key r of the tile, queries 4g..4g+3 of the query tile (S = Q K^T, rows = queries).
+// dK / dV.  Each wave owns TWO key tiles of one class (K / V fragments in registers) and walks the LIVE query tiles of the window
+// type in pairs (a pair = one 32-deep dK / dV MFMA); Q / dO images + lse / delta of the next sequence stream into the other LDS buffer
+// by DMA spread over the walk.  Lane (r, g): key r of the tile, queries 4g..4g+3 of the query tile (S = Q K^T, rows = queries).
+// NWV = 8: a workgroup = (head, key group, chunk of clips), key group 0 = classes A + B (tiles 0-13), 1 = C + D (tiles 14-24).
+// NWV = 12: a workgroup = (head, chunk of clips), three waves per SIMD (<= 168 registers).
 //
-// PING-PONG.  Measured on the first version of this kernel (and on the win2 kernels): a sequence took exactly the SUM of its LDS, VALU
-// and matrix-pipe times -- the two waves of a SIMD run the same instruction stream in lockstep from the sequence barrier on, so both
-// sit in the softmax VALU chain together and then both queue on the matrix pipe.  Here the waves form two groups (waves 0-3 / 4-7: one
-// wave of each per SIMD) that run HALF A STEP APART, separated by raw s_barrier: while one group is in its MFMA-only phase
-// M(c) = [dV / dK products of pair c, score / dP products of pair c + 1] its SIMD partners are in the VALU + LDS phase
-// V(c) = [softmax-side chain of pair c, fragment / bias / lse reads of pair c + 1, transposing reads of pair c, DMA requests].
-// Every wave of the workgroup executes the same number of barriers per sequence (2 NPAD + 2): shorter live lists are padded with
-// empty phases, idle waves only keep the count.  LDS is read-only inside a sequence, so the raw barriers carry no memory ordering.
+// What bounds it (tools/probe/valu_probe.hip, profiles/r04_probe_valu_issue.txt): the softmax-side VALU chain.  One wave issues a
+// packed-f32 / convert / exp instruction every 6-10 cycles whatever its SIMD partner does, two waves together reach 3.3-4 ns per
+// instruction per SIMD and the VALU saturates at ~2.5 ns only with three or more; MFMAs of the same wave do NOT run under its own
+// packed-f32 instructions.  So with two waves per SIMD a sequence costs the SUM of its VALU and matrix time (measured: 9 us), a
+// barrier-separated ping-pong of the two waves (one multiplying, one in the chain) is no faster than letting them run free (built,
+// measured, removed: the lone chain wave is issue-limited), and what helps is fewer chain instructions per score element and a third
+// wave per SIMD.
 // ================================================================================================
-constexpr int w3_npad(int m4) {                          // pairs of the longest live list among the classes that share a workgroup
-  return m4 == 15 ? 13 : (m4 == 3 || m4 == 5 || m4 == 10) ? 7 : m4 == 12 ? 6 : (m4 == 1 || m4 == 2) ? 4 : 3;
-}
-__device__ __forceinline__ void w3_bar() {
-  __builtin_amdgcn_sched_barrier(0);
-#ifdef W3_PINGPONG
-  __builtin_amdgcn_s_barrier();
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <bool MASK>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_bwd_desc pb, const int nch) {
-  constexpr int HD = 32, NWV = 8, KT = 2;
+template <bool MASK, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win3_kernel(const vmvm_attn_bwd_desc pb, const int nch) {
+  constexpr int HD = 32, KT = 2;
+  constexpr int NKG = NWV == 12 ? 1 : 2;                  // key groups per (head, chunk)
   constexpr int ROWS = w3::NT * 16, IMG = ROWS * HD * 2;               // 400 rows, 25 600 bytes per Q or dO image
   constexpr int LV = 512;                                               // floats reserved for lse / delta
   constexpr int BUF = 2 * IMG + 2 * LV * 4;
@@ -103,18 +101,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                             // ping-pong group
   const int r = lane & 15, g = lane >> 4;
   const int L = w3::L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
-  const int logical = xcd_remap(blockIdx.x, heads * nch * 2);
-  const int kg = logical & 1;
-  const int t1 = logical >> 1;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * NKG);
+  const int kg = NKG == 2 ? (logical & 1) : 0;
+  const int t1 = NKG == 2 ? (logical >> 1) : logical;
   const int ch = t1 % nch;
   const int h = t1 / nch;
   unsigned char* TL = smem + 2 * BUF;
   // this wave's key tiles
   const int kt0 = (kg == 0 ? 0 : w3::CB[2]) + 2 * wave;
-  const bool active = kt0 < (kg == 0 ? w3::CB[2] : w3::NT);
+  const bool active = NKG == 1 ? true : kt0 < (kg == 0 ? w3::CB[2] : w3::NT);
   const int kc = kt0 < w3::CB[1] ? 0 : kt0 < w3::CB[2] ? 1 : kt0 < w3::CB[3] ? 2 : 3;      // class of both tiles
   int key[KT]; bool kv[KT];
 #pragma unroll
@@ -123,9 +120,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
   // windowed table of this head (staged through the second buffer, which the first sequence does not use)
   {
     float* stage = reinterpret_cast<float*>(smem + BUF);
-    if (!(W3_ABL & 64)) for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
+    for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
     __syncthreads();
-    if (!(W3_ABL & 64)) w3_build_table<1>(TL, stage, tid, NWV * 64);
+    w3_build_table<1>(TL, stage, tid, NWV * 64);
     __syncthreads();
   }
   // lane bases into the table: row = A(q) - A(k) + 84, window s = 4 (g & 1) - (r & 7) + 7; A(q) = tile immediate + lq * step
@@ -173,10 +170,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
       dma16_one(dst + 2 * IMG + (wave >> 1) * LV * 4 + (wave & 1) * 1024, src, (unsigned)(L * 4), (uint32_t)(((wave & 1) * 64 + lane) * 16));
     }
   };
-  // prefetched K / V fragments of the next sequence.  Loaded by inline asm and waited for by the counted s_waitcnt at the loop top:
-  // as compiler-visible loads their consumer at the loop header made the compiler wait with vmcnt(0) -- i.e. for the previous
-  // sequence's dK / dV stores as well (it cannot count memory instructions across the back edge).  Lanes of padding keys never load
-  // and keep their zeros.
+  // K / V fragments.  The next sequence's are loaded by inline asm into the SAME registers once the walk has multiplied with them for
+  // the last time (no second set), and waited for by the counted s_waitcnt at the loop top: as compiler-visible loads their consumer
+  // at the loop header made the compiler wait with vmcnt(0) -- i.e. for the previous sequence's dK / dV stores as well (it cannot count
+  // memory instructions across the back edge).  Lanes of padding keys never load and keep their zeros.
   f32x4 kf[KT], vf[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t) { kf[t] = f32x4{0.f, 0.f, 0.f, 0.f}; vf[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -203,19 +200,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
     fetch(seq_nx());
     advance();
   }
-  if (grp == 1) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every arbitration otherwise (static form)
+  // memory instructions a wave issues AFTER its last DMA request of a sequence: the next fragment loads (when the walk is long enough
+  // to hold them) and the dK / dV stores -- what the counted wait at the loop top may leave in flight
+  const bool full = active && kt0 + 1 < w3::NT - 1;     // both tiles hold 16 real keys: every load / store below is issued by the wave
 
-  const int nstores = (active && kt0 + 1 < w3::NT - 1) ? 8 : 0;        // both tiles hold 16 real keys: every store below is issued
-  int wprev = -1, w_cu = 0, c_cu = c0, m4 = 15, npad = 13;
+  int wprev = -1, w_cu = 0, c_cu = c0, m4 = 15;
   for (int b = 0; b < total; ++b) {
     const int cur = b & 1;
     const size_t seq = (size_t)c_cu * nWin + w_cu;
-    // This sequence's images must have landed -- but NOT the dK / dV stores of the previous sequence, the youngest 8 memory
-    // instructions of a wave that owns two key tiles (vmcnt counts loads and stores in order; measured: waiting for the stores' write
-    // acknowledgements cost 2.8 us per sequence, a quarter of this kernel).  Raw barrier: LDS is read-only inside a sequence, the
-    // barrier only orders "my DMA landed" / "everyone left the other buffer".
+    // This sequence's images and fragments must have landed -- but NOT the dK / dV stores of the previous sequence, the youngest 8
+    // memory instructions of a wave that owns two full key tiles (vmcnt counts loads and stores in order).  Raw barrier: LDS is
+    // read-only inside a sequence, the barrier only orders "my DMA landed" / "everyone left the other buffer".
     // (ONE operand-carrying wait: with one asm per branch the compiler copied the fragment registers in front of one of them)
-    if (!(b > 0 && nstores == 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(b > 0 && full)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(8)" : "+v"(kf[0]), "+v"(vf[0]), "+v"(kf[1]), "+v"(vf[1]) : : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -223,26 +220,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
     if (++c_cu == c1) { c_cu = c0; ++w_cu; }
     if (MASK && wcur != wprev) {                          // (workgroup-uniform) new window position: which query classes this wave's keys see
       wprev = wcur;
-      const int wt = __builtin_amdgcn_readfirstlane(w3_window_type(p.region, wcur));
-      m4 = w3_live_rt(kc, wt);
-      npad = kg == 0 ? (wt == 0 ? 13 : wt == 3 ? 4 : 7) : (wt == 0 ? 13 : wt == 1 ? 6 : wt == 2 ? 7 : 3);
+      m4 = w3_live_rt(kc, __builtin_amdgcn_readfirstlane(w3_window_type(p.region, wcur)));
     }
-    bf16x8 ckf[KT], cvf[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t) { ckf[t] = __builtin_bit_cast(bf16x8, kf[t]); cvf[t] = __builtin_bit_cast(bf16x8, vf[t]); }
     const float seq_scale = ss_n;
     const bool has_next = b + 1 < total;
     const size_t sq_nx = seq_nx();
-    if (has_next) {
-      if (!(W3_ABL & 512)) fetch(sq_nx);
-      advance();
-    }
-    if (!active) {                                        // idle wave: its share of the DMA requests, and the barrier count
-      if (has_next && !(W3_ABL & 256)) {
+    if (has_next) advance();
+    if (!active) {                                        // idle wave: its share of the DMA requests
+      if (has_next) {
 #pragma unroll
         for (int i = 0; i <= NF; ++i) dma_step(sq_nx, cur ^ 1, i);
       }
-      for (int i = 0; i < 2 * npad + 1; ++i) w3_bar();
       continue;
     }
     const unsigned char* Qs = smem + cur * BUF;
@@ -261,16 +249,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
     const unsigned char* tq1 = Qs + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
     const uint32_t tq0a = lds_addr(tq0), tq1a = lds_addr(tq1);
 
-    // the walk over the live query tiles of class set M4 (compile-time list, pairs of tiles = one 32-deep dK / dV MFMA)
+#ifdef W3_TIMELINE
+    const bool tl_on = blockIdx.x == 8 && b == 2 && lane == 0 && (wave == 0 || wave == 5);
+    unsigned long long* tl_buf = w3_dbg + (wave == 0 ? 0 : 2048);
+    int tl_n = 1;
+#endif
+    // the walk over the live query tiles of class set M4 (compile-time list)
     auto walk = [&](auto m4c) {
       constexpr int M4 = decltype(m4c)::value;
       constexpr w3::TileList QL = w3::list_all(M4);
-      constexpr int NP = (QL.n + 1) / 2, NPAD = w3_npad(M4);
-      static_assert(NP <= NPAD, "padding covers the list");
+      constexpr int NP = (QL.n + 1) / 2;
       typedef __attribute__((ext_vector_type(8))) short s16x8;
-      bf16x8 qf[2], dof[2];                               // fragments of the NEXT pair (read in V, multiplied in M)
+      bf16x8 qf[2], dof[2];                               // fragments of the next pair
       f32x4 l4[2], d4[2], bias[2][KT];
-      f32x4 s4[2][KT], dp4[2][KT];                        // scores / dP of the CURRENT pair (written in M, consumed in V)
+      f32x4 s4[2][KT], dp4[2][KT];                        // scores / dP of the current pair
+      f32x2 nl[2][2], nd[2][2];
       uint32_t pw[KT][4], dw[KT][4];
       s16x4 a0, a1, c0_, c1_, e0, e1, f0, f1;
       auto reads = [&](const int c) {                     // LDS reads for pair c
@@ -289,20 +282,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
           }
         }
       };
-      auto mma1 = [&](const int c) {                      // S = Q K^T + bias, dP = dO V^T of pair c
+      auto mma1 = [&](const int c) {                      // S = Q K^T + bias, dP = dO V^T of pair c; then -lse log2 e, -delta
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (2 * c + u < QL.n) {
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-              s4[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[u], ckf[t], bias[u][t], 0, 0, 0);
-              dp4[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[u], cvf[t], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              s4[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[u], __builtin_bit_cast(bf16x8, kf[t]), bias[u][t], 0, 0, 0);
+              dp4[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[u], __builtin_bit_cast(bf16x8, vf[t]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
           }
         }
-      };
-      f32x2 nl[2][2], nd[2][2];
-      auto prep = [&](const int c) {                      // -lse log2 e, -delta of pair c (their reads were issued a phase ago)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (2 * c + u < QL.n) {
@@ -357,36 +347,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
           dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q1v), dsf, dk[t][1], 0, 0, 0);
         }
       };
-      if (grp == 1) w3_bar();                             // half a step behind group 0
+      W3_T(1);
       reads(0);
       mma1(0);
-      prep(0);
-      if (NP > 1) reads(1);
+      W3_T(2);
 #pragma unroll
-      for (int c = 0; c < NPAD; ++c) {
-        // ---- V(c): VALU + LDS phase
-        if (c < NP) {
-          if (!(W3_ABL & 16)) trreads(c);
-          if (!(W3_ABL & 1)) chain(c);
-        }
-        if (c <= NF && has_next && !(W3_ABL & 256)) dma_step(sq_nx, cur ^ 1, c);
-        w3_bar();
-        // ---- M(c): matrix phase
-        if (c < NP) {
-          if (!(W3_ABL & 2)) mma2();
-          if (c + 1 < NP) {
-            if (!(W3_ABL & 4)) mma1(c + 1);
-            prep(c + 1);
-            if (c + 2 < NP && !(W3_ABL & 8)) reads(c + 2);
-          }
-        }
-        w3_bar();
+      for (int c = 0; c < NP; ++c) {
+        trreads(c);
+        if (c <= NF && has_next) dma_step(sq_nx, cur ^ 1, c);
+        W3_T(10);
+        chain(c);
+        __builtin_amdgcn_sched_barrier(0);                // (the next pair's fragments once the chain has released its registers: asking
+        W3_T(11);                                         //  for them before the chain costs 40 registers and measured the same -- the
+        if (c + 1 < NP) reads(c + 1);                     //  LDS pipe is a co-bound of this loop, the requests queue either way)
+        W3_T(12);
+        mma2();
+        W3_T(13);
+        if (c + 1 < NP) mma1(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        W3_T(14);
       }
-      if (has_next && !(W3_ABL & 256)) {                                     // (short walks: the DMA steps the phases did not cover)
+      if (has_next) {                                     // (short walks: the DMA steps the pairs did not cover)
 #pragma unroll
-        for (int c = NPAD; c <= NF; ++c) dma_step(sq_nx, cur ^ 1, c);
+        for (int c = NP; c <= NF; ++c) dma_step(sq_nx, cur ^ 1, c);
       }
-      if (grp == 0) w3_bar();
     };
     if constexpr (!MASK) {
       walk(IC<15>{});
@@ -403,17 +387,294 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_win3_kernel(const vmvm_attn_
         default: walk(IC<8>{}); break;
       }
     }
+    W3_T(20);
+#ifdef W3_TIMELINE
+    if (tl_on) tl_buf[0] = tl_n;
+#endif
+    const float ssv = seq_scale;
+    if (has_next) fetch(sq_nx);                           // the fragment registers are free: the next sequence's K / V (4 loads, before the 8 stores)
     u16* dbase = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      if (kv[t] && (!(W3_ABL & 128) || dk[t][0][0] == 1234.5f)) {
+      if (kv[t]) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           *reinterpret_cast<uint2*>(dbase + off_dk[t] + p.k_off + dt * 16) = make_uint2(pack_bf2(dk[t][dt][0], dk[t][dt][1]), pack_bf2(dk[t][dt][2], dk[t][dt][3]));
           *reinterpret_cast<uint2*>(dbase + off_dk[t] + p.v_off + dt * 16) =
-              make_uint2(pack_bf2(dv[t][dt][0] * seq_scale, dv[t][dt][1] * seq_scale), pack_bf2(dv[t][dt][2] * seq_scale, dv[t][dt][3] * seq_scale));
+              make_uint2(pack_bf2(dv[t][dt][0] * ssv, dv[t][dt][1] * ssv), pack_bf2(dv[t][dt][2] * ssv, dv[t][dt][3] * ssv));
         }
       }
+    }
+  }
+}
+
+// ================================================================================================
+// dQ (+ the bias-table gradient).  A workgroup = (head, group of 4 query tiles, chunk of clips); wave (ql, kh) owns query tile ql of the
+// group against one HALF of the key tiles -- the halves interleave by class (w3::list_part: 13 / 12 tiles), so whatever classes a
+// window type leaves live are split evenly between the two waves of a query tile; the two dQ partials are combined through LDS at the
+// next loop-top barrier.  K / V of the next sequence stream into the other LDS buffer; the next sequence's Q / dO / O fragments are
+// prefetched into registers.  Lane (r, g): query r of the tile, keys 4g..4g+3 of the key tile (S^T = K Q^T, rows = keys).
+// The running sums of dS (bias-table gradient) stay in registers over the workgroup's whole run, one slot per key tile of the half, and
+// are scattered once at the end: entry (dq - dk + 7) * 169 + A(q) - A(k) + 84 of the head's column.
+// ================================================================================================
+template <bool MASK>
+__global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_bwd_desc pb, const int nqg, const int nch) {
+  constexpr int HD = 32, NQ = 4, NS = 2, NWV = NQ * NS;
+  constexpr int NH = 13;                                                // slots of a half (w3::list_part(15, 0, 2).n)
+  constexpr int ROWS = w3::NT * 16, KV = ROWS * HD * 2;                 // 400 rows, 25 600 bytes per K or V image
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int L = w3::L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nqg);
+  const int qg = logical % nqg;
+  const int t1 = logical / nqg;
+  const int ch = t1 % nch;
+  const int h = t1 / nch;
+  constexpr int XCH = (NS - 1) * NQ * 64 * 8;
+  float* xch = reinterpret_cast<float*>(smem + 4 * KV);                 // [2][NS-1][NQ][64 lanes][8] f32: dQ partials of split 1, double-buffered by sequence parity
+  unsigned char* TL = smem + 4 * KV + 2 * XCH * 4;
+  const bool want_dtab = pb.dbias_table != nullptr;
+  const int ql = wave % NQ, kh = wave / NQ;                             // query tile slot, key half
+  const int qt = qg * NQ + ql;
+  const int q = qt * 16 + r;
+  const bool active = qt < w3::NT;
+  const bool qv = active && (q < L);
+  const int qc = qt < w3::CB[1] ? 0 : qt < w3::CB[2] ? 1 : qt < w3::CB[3] ? 2 : 3;
+
+  {                                                       // windowed table of this head (staged through the second K / V buffer)
+    float* stage = reinterpret_cast<float*>(smem + 2 * KV);
+    for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
+    __syncthreads();
+    w3_build_table<0>(TL, stage, tid, NWV * 64);
+    __syncthreads();
+  }
+  // lane bases into the table: row = A(q) - A(k) + 84, window s = 7 - (r & 7) + 4 (g & 1); A(k) = tile immediate + lk * step
+  const int lq = r >> 3, lk = g >> 1, sw = 7 - (r & 7) + 4 * (g & 1);
+  const int aq = w3_posA_rt(2 * (active ? qt : 0) + lq);
+  const unsigned char* tb1 = TL + (aq - lk) * w3::ROWB + sw * 16;
+  const unsigned char* tb13 = TL + (aq - 13 * lk) * w3::ROWB + sw * 16;
+  const unsigned char* tb24 = lk ? TL + 169 * w3::ROWB + sw * 16 : TL + (aq + 84 - w3::tileA0(w3::NT - 1)) * w3::ROWB + sw * 16;      // key tile 24: second position = padding
+
+  f32x2 racc[NH][2];
+#pragma unroll
+  for (int tl = 0; tl < NH; ++tl) { racc[tl][0] = f32x2{0.f, 0.f}; racc[tl][1] = f32x2{0.f, 0.f}; }
+
+  // this workgroup's sequences: the clips [c0, c1) of every window position, window-major
+  const int cper = (B + nch - 1) / nch;
+  const int c0 = ch * cper, c1 = (c0 + cper < B) ? c0 + cper : B;
+  const int ncl = c1 > c0 ? c1 - c0 : 0, total = ncl * nWin;
+  int w_nx = 0, c_nx = c0;
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == c1) { c_nx = c0; ++w_nx; } };
+  const uint32_t off_q = (uint32_t)q * p.ld_qkv + p.q_off + h * HD + g * 8;
+  const uint32_t off_do = (uint32_t)q * pb.ld_dout + h * HD + g * 8;
+  const uint32_t off_o = (uint32_t)q * p.ld_out + h * HD + g * 8;
+  const uint32_t off_dq = (uint32_t)q * pb.ld_dqkv + p.q_off + h * HD + g * 4;
+  const uint32_t off_ls = (uint32_t)h * L + q;
+  constexpr int NF = (ROWS * 4 + NWV * 64 - 1) / (NWV * 64);            // 16-byte DMA requests per thread per image
+  uint32_t goff[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
+    goff[i] = (u < ROWS * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ swz_chunk<32>(row)) << 3)) * 2) : 0xffffffffu;
+  }
+  const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
+  bf16x8 qf, dof, of;
+  float lse_n = 0.f, ss_n = 1.0f;
+  auto fetch = [&](size_t seq) {
+    const u16* qb = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv;
+    const u16* dob = reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout;
+    const u16* ob = reinterpret_cast<const u16*>(p.out) + seq * L * p.ld_out;
+    qf = load_frag_global(qb + off_q, qv);
+    dof = load_frag_global(dob + off_do, qv);
+    of = load_frag_global(ob + off_o, qv);
+    lse_n = qv ? (p.lse + seq * heads * L)[off_ls] : __builtin_huge_valf();
+    ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  };
+  if (total > 0) {
+    const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    fill_pre<NF, NWV * 64 * 16>(smem + (tid & ~63) * 16, KV, qkv + p.k_off, qkv + p.v_off, fill_bytes, goff);
+    fetch(seq_nx());
+    advance();
+  }
+
+  f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  auto flush_prev = [&](size_t seq, int par) {           // split 0: add the other split's partial (in LDS buffer `par`) and store dQ
+    if (kh == 0 && qv) {
+      float4 x0 = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]), x1 = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+      const float* x = xch + par * XCH + (ql * 64 + lane) * 8;
+      const float4 y0 = *reinterpret_cast<const float4*>(x), y1 = *reinterpret_cast<const float4*>(x + 4);
+      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+      x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+      u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv + off_dq;
+      const float sc = p.scale;
+      *reinterpret_cast<uint2*>(dqp) = make_uint2(pack_bf2(x0.x * sc, x0.y * sc), pack_bf2(x0.z * sc, x0.w * sc));
+      *reinterpret_cast<uint2*>(dqp + 16) = make_uint2(pack_bf2(x1.x * sc, x1.y * sc), pack_bf2(x1.z * sc, x1.w * sc));
+    }
+  };
+
+  int wprev = -1, w_cu = 0, c_cu = c0, m4 = 15;
+  size_t seq_pv = 0;
+  for (int b = 0; b < total; ++b) {
+    const int cur = b & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    fill_wait();
+    __syncthreads();                                      // sequence b landed; other buffer free; partials of b-1 visible
+    if (b > 0) flush_prev(seq_pv, cur ^ 1);
+    seq_pv = seq;
+    const int wcur = w_cu;
+    if (++c_cu == c1) { c_cu = c0; ++w_cu; }
+    if (MASK && wcur != wprev) {
+      wprev = wcur;
+      m4 = w3_live_rt(qc, __builtin_amdgcn_readfirstlane(w3_window_type(p.region, wcur)));
+    }
+    const bf16x8 cqf = qf, cdof = dof, cof = of;
+    const float clse2 = lse_n * LOG2E, seq_scale = ss_n;
+    const bool has_next = b + 1 < total;
+    const u16* kv_nx = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    unsigned char* dst_nx = smem + (cur ^ 1) * 2 * KV + (tid & ~63) * 16;
+    if (has_next) {
+      fetch(seq_nx());
+      advance();
+      if (!active) fill_pre<NF, NWV * 64 * 16>(dst_nx, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff);
+    }
+    if (!active) continue;
+    const unsigned char* Ksm = smem + cur * 2 * KV;
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)cdof[e] * (float)cof[e];
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (kh == 0 && g == 0 && qv) (pb.delta + seq * heads * L)[off_ls] = dl;
+    dq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 nl2 = {-clse2, -clse2}, ss2 = {seq_scale, seq_scale}, ndl2 = {-dl, -dl};
+    asm volatile("" : "+v"(nl2), "+v"(ss2), "+v"(ndl2));   // real register pairs (see attn_bwd_dq_win2_kernel)
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const unsigned char* kb = Ksm + k_off_swz<HD>(r, g);                 // tile 0; every tile is a compile-time immediate away
+    const unsigned char* tk0 = Ksm + k_off_swz<HD>(g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
+    const unsigned char* tk1 = Ksm + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    const uint32_t tk0a = lds_addr(tk0), tk1a = lds_addr(tk1);
+
+    auto walk = [&](auto khc, auto m4c) {
+      constexpr int KH = decltype(khc)::value, M4 = decltype(m4c)::value;
+      constexpr w3::TileList KL = w3::list_part(M4, KH, NS);
+      constexpr int NP = (KL.n + 1) / 2;
+      bf16x8 kf[2], vf[2];
+      f32x4 bias[2];
+      auto reads = [&](const int c) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (2 * c + u < KL.n) {
+            const int kt = KL.t[2 * c + u];
+            kf[u] = *reinterpret_cast<const bf16x8*>(kb + kt * 1024);
+            vf[u] = *reinterpret_cast<const bf16x8*>(kb + KV + kt * 1024);
+            const unsigned char* bp = kt == w3::NT - 1 ? tb24 : (w3::tileStep(kt) == 13 ? tb13 : tb1) + (84 - w3::tileA0(kt)) * w3::ROWB;
+            bias[u] = *reinterpret_cast<const f32x4*>(bp);
+          }
+        }
+      };
+      if (NP > 0) reads(0);
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        f32x4 s4[2], dp4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (2 * c + u < KL.n) {
+            s4[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], cqf, bias[u], 0, 0, 0);
+            dp4[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], cdof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+        }
+        const int ta = KL.t[2 * c], tb = (2 * c + 1 < KL.n) ? KL.t[2 * c + 1] : KL.t[2 * c];
+        s16x4 a0, a1, c0_, c1_;
+        tr_read4_2(a0, a1, c0_, c1_, tk0a, tk1a, ta * 1024, tb * 1024);
+        if (c < NF && has_next) fill_one(dst_nx + c * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[c], c == NF - 1);
+        if (c + 1 < NP) reads(c + 1);
+        uint32_t dsw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (2 * c + u < KL.n) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = w3::slot_in_part(KL.t[2 * c + u], KH, NS);
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+              const f32x2 sv = {s4[u][2 * hj], s4[u][2 * hj + 1]}, dpv = {dp4[u][2 * hj], dp4[u][2 * hj + 1]};
+              const f32x2 e = __builtin_elementwise_fma(sv, f32x2{LOG2E, LOG2E}, nl2);
+              const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+              const f32x2 d = pr * __builtin_elementwise_fma(dpv, ss2, ndl2);
+              asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(racc[slot][hj]) : "v"(d));
+              dsw[2 * u + hj] = pack_bf2v(d);
+            }
+          }
+        }
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(dsw[0], dsw[1], dsw[2], dsw[3]));
+        tr_wait4(a0, a1, c0_, c1_);
+        const s16x8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const s16x8 v1 = {c0_[0], c0_[1], c0_[2], c0_[3], c1_[0], c1_[1], c1_[2], c1_[3]};
+        dq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), dsf, dq[0], 0, 0, 0);
+        dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), dsf, dq[1], 0, 0, 0);
+      }
+      if (has_next) {                                     // (short walks: the DMA requests the pairs did not cover)
+#pragma unroll
+        for (int c = NP; c < NF; ++c) fill_one(dst_nx + c * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[c], c == NF - 1);
+      }
+    };
+    auto walk_m = [&](auto khc) {
+      if constexpr (!MASK) {
+        walk(khc, IC<15>{});
+      } else {
+        switch (m4) {
+          case 15: walk(khc, IC<15>{}); break;
+          case 3: walk(khc, IC<3>{}); break;
+          case 12: walk(khc, IC<12>{}); break;
+          case 5: walk(khc, IC<5>{}); break;
+          case 10: walk(khc, IC<10>{}); break;
+          case 1: walk(khc, IC<1>{}); break;
+          case 2: walk(khc, IC<2>{}); break;
+          case 4: walk(khc, IC<4>{}); break;
+          default: walk(khc, IC<8>{}); break;
+        }
+      }
+    };
+    if (kh == 0) walk_m(IC<0>{}); else walk_m(IC<1>{});
+    if (kh > 0) {                                         // split 1 publishes its partial; split 0 adds it after the next barrier
+      float* x = xch + cur * XCH + (ql * 64 + lane) * 8;
+      *reinterpret_cast<float4*>(x) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
+      *reinterpret_cast<float4*>(x + 4) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+    }
+  }
+  __syncthreads();
+  if (total > 0 && active) flush_prev(seq_pv, (total - 1) & 1);
+  if (want_dtab) {
+    float* dtab = reinterpret_cast<float*>(smem);         // (the K / V buffers are free now)
+    __syncthreads();
+    for (int i = tid; i < 15 * 169; i += NWV * 64) dtab[i] = 0.f;
+    __syncthreads();
+    if (qv) {
+      auto scatter = [&](auto khc) {
+        constexpr int KH = decltype(khc)::value;
+        constexpr w3::TileList KL = w3::list_part(15, KH, NS);
+#pragma unroll
+        for (int i = 0; i < KL.n; ++i) {
+          const int kt = KL.t[i];
+          if (!(kt == w3::NT - 1 && lk == 1)) {
+            const int rho = aq - (w3::tileA0(kt) + lk * w3::tileStep(kt)) + 84;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int dlt = (r & 7) - (4 * (g & 1) + j) + 7;
+              atomicAdd(&dtab[dlt * 169 + rho], racc[i][j >> 1][j & 1]);
+            }
+          }
+        }
+      };
+      if (kh == 0) scatter(IC<0>{}); else scatter(IC<1>{});
+    }
+    __syncthreads();
+    for (int i = tid; i < 15 * 169; i += NWV * 64) {
+      const float v = dtab[i];
+      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
     }
   }
 }
@@ -449,24 +710,50 @@ __attribute__((visibility("hidden"))) bool applicable(const vmvm_attn_fwd_desc* 
          d->dropout_p == 0.f && d->nseq % nwin == 0;
 }
 
-__attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st) {
-  constexpr int IMG = 400 * 64, BUF = 2 * IMG + 2 * 512 * 4;
-  const int smem = 2 * BUF + w3::TAB_BYTES;
-  const int base = d->f.heads * 2;
+__attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st) {
+  constexpr int KV = 400 * 64, XCH = 4 * 64 * 8;
+  const int smem = 4 * KV + 2 * XCH * 4 + w3::TAB_BYTES;
+  const int nqg = (w3::NT + 3) / 4;
+  const int base = d->f.heads * nqg;
   const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
-  const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 4.f);
-  const bool mask = d->f.region != nullptr;
-  if (mask) {
-    int rc_ = w3_set_smem(attn_bwd_dkv_win3_kernel<true>, smem);
+  const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 10.f);
+  if (d->f.region) {
+    int rc_ = w3_set_smem(attn_bwd_dq_win3_kernel<true>, smem);
     if (rc_) return rc_;
-    hipLaunchKernelGGL((attn_bwd_dkv_win3_kernel<true>), dim3(base * nch), dim3(512), smem, st, *d, nch);
+    hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<true>), dim3(base * nch), dim3(512), smem, st, *d, nqg, nch);
   } else {
-    int rc_ = w3_set_smem(attn_bwd_dkv_win3_kernel<false>, smem);
+    int rc_ = w3_set_smem(attn_bwd_dq_win3_kernel<false>, smem);
     if (rc_) return rc_;
-    hipLaunchKernelGGL((attn_bwd_dkv_win3_kernel<false>), dim3(base * nch), dim3(512), smem, st, *d, nch);
+    hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<false>), dim3(base * nch), dim3(512), smem, st, *d, nqg, nch);
   }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
 
+__attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st) {
+  constexpr int IMG = 400 * 64, BUF = 2 * IMG + 2 * 512 * 4;
+  const int smem = 2 * BUF + w3::TAB_BYTES;
+  static const int nwv = getenv("VMVM_W3_DKV_WAVES") ? atoi(getenv("VMVM_W3_DKV_WAVES")) : 8;
+  const int base = d->f.heads * (nwv == 12 ? 1 : 2);
+  const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
+  const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 4.f);
+  const bool mask = d->f.region != nullptr;
+#define W3_LAUNCH_DKV(MASK, NWV)                                                                                     \
+  do {                                                                                                               \
+    int rc_ = w3_set_smem(attn_bwd_dkv_win3_kernel<MASK, NWV>, smem);                                                 \
+    if (rc_) return rc_;                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dkv_win3_kernel<MASK, NWV>), dim3(base * nch), dim3(NWV * 64), smem, st, *d, nch);   \
+  } while (0)
+  if (nwv == 12) { if (mask) W3_LAUNCH_DKV(true, 12); else W3_LAUNCH_DKV(false, 12); }
+  else { if (mask) W3_LAUNCH_DKV(true, 8); else W3_LAUNCH_DKV(false, 8); }
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
 }  // namespace vmvm_w3
+
+#ifdef W3_TIMELINE
+extern "C" int vmvm_w3_debug_read(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w3_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

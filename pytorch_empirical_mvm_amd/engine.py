@@ -376,11 +376,16 @@ class VioletEngine:
         Lp = wm.size
         nW = Lp // N
         dev = self.device
-        src = self._cached(("wm", dims, ws, ss), lambda: _dev_i32(wm, dev))
         reg_np = SI.region_ids(Dp, Hp, Wp, ws, ss)
-        reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss), lambda: torch.from_numpy(reg_np).to(dev))
         rc_np, rc0 = SI.rc_codes(N, win)
-        rc = self._cached(("rc", N, win), lambda: _dev_i32(rc_np, dev))
+        # win_layout = 1 (include/vmvm.h, swin_index.win3_perm): the order of the tokens INSIDE a window is free -- one gather map serves
+        # the LayerNorm, the projection's un-gather epilogue and the backward -- so (8,7,7) windows are laid out d-fastest and region-major,
+        # which is what the win3 attention kernels assume (Toeplitz bias reads, masked score tiles skipped); rc / region follow the slots
+        w3 = 1 if (SI.win3_ok(ws, ss) and os.environ.get("VMVM_WIN_LAYOUT", "1") != "0") else 0
+        pm = SI.win3_perm() if w3 else None               # (applied inside the cached builders: host work once per shape, not per block call)
+        src = self._cached(("wm", dims, ws, ss, w3), lambda: _dev_i32(wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm, dev))
+        reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss, w3), lambda: torch.from_numpy(np.ascontiguousarray(reg_np[:, pm]) if w3 else reg_np).to(dev))
+        rc = self._cached(("rc", N, win, w3), lambda: _dev_i32(rc_np[pm] if w3 else rc_np, dev))
         scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
         # DropPath (video_swin.py:46-63): the block calls it TWICE -- on the attention branch (:256) and on the MLP branch (:248) -- with
         # independent per-sample draws; `dp` = (scale vector of the attention branch, scale vector of the MLP branch), or one vector for both
@@ -418,7 +423,7 @@ class VioletEngine:
                 dpk = dpv
             xw, mean1, rstd1 = K.layernorm_fwd(x, g1, b1, 1e-5, **lnkw)
             qkv = K.gemm(xw, S.b(pre + "attn.qkv.weight"), bias=S.p(pre + "attn.qkv.bias"), col_scale=scale, col_scale_n=C)
-            akw = dict(q_off=0, k_off=C, v_off=2 * C, bias_table=table, rc=rc, rc0=rc0, region=reg, n_win=nW, seq_scale=dpk, seqs_per_scale=nW)
+            akw = dict(q_off=0, k_off=C, v_off=2 * C, bias_table=table, rc=rc, rc0=rc0, region=reg, n_win=nW, seq_scale=dpk, seqs_per_scale=nW, win_layout=w3)
             ao, lse = K.attention_fwd(qkv, Bk * nW, N, nh, C // nh, 0, scale, **akw)
             x1 = K.gemm(ao, S.b(pre + "attn.proj.weight"), bias=S.p(pre + "attn.proj.bias"), row_scale=dpk, rows_per_scale=Lp,
                         scale_bias_only=True, resid=x, out_rows=B * L, **mapkw)

@@ -49,3 +49,30 @@ def test_merge_map(dims):
         x = torch.nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2))
     cat = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
     np.testing.assert_array_equal(m, cat.reshape(-1).long().numpy() - 1)
+
+
+def test_win3_layout_tables():
+    """win_layout = 1 (include/vmvm.h): the slot order inside an (8,7,7) window is a permutation, every 16-token tile lies in ONE mask
+    region of every window of the (0,3,3) shift (video_swin.py:292-307) with the class boundaries at tiles 8 / 14 / 20, the two (h, w)
+    positions of a tile are w- or h-neighbours, and the C++ geometry table (csrc/attn_win3.h) lists the same positions."""
+    import os
+    import re
+    from pytorch_empirical_mvm_amd import swin_index as SI
+    pm = SI.win3_perm()
+    assert sorted(pm.tolist()) == list(range(392))
+    assert SI.win3_ok((8, 7, 7), (0, 3, 3)) and SI.win3_ok((8, 7, 7), (0, 0, 0)) and not SI.win3_ok((8, 7, 7), (4, 3, 3)) and not SI.win3_ok((4, 7, 7), (0, 3, 3))
+    for (H, W) in ((14, 14), (28, 28), (56, 56)):
+        reg = SI.region_ids(8, H, W, (8, 7, 7), (0, 3, 3))[:, pm]
+        for w in range(reg.shape[0]):
+            tiles = [set(reg[w, 16 * t:16 * t + 16].tolist()) for t in range(25)]
+            assert all(len(x) == 1 for x in tiles), (H, W, w)
+            ids = [next(iter(x)) for x in tiles]
+            for lo, hi in ((0, 8), (8, 14), (14, 20), (20, 25)):
+                assert len(set(ids[lo:hi])) == 1, (H, W, w, ids)
+    pos = SI.WIN3_POS
+    for t in range(24):
+        (h0, w0), (h1, w1) = pos[2 * t], pos[2 * t + 1]
+        assert (h1 - h0, w1 - w0) in ((0, 1), (1, 0)), (t, pos[2 * t], pos[2 * t + 1])
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pytorch_empirical_mvm_amd", "csrc", "attn_win3.h")).read()
+    nums = lambda name: [int(x) for x in re.findall(r"\d+", re.sub(r"//[^\n]*", "", re.search(name + r"\[50\] = \{([^}]*)\}", hdr, re.S).group(1)))]
+    assert list(zip(nums("PH"), nums("PW")))[:49] == pos

@@ -25,8 +25,15 @@ if "attn" in which:
     qkv = rnd(nseq * N, 3 * C_)
     rc, rc0 = SI.rc_codes(N, (8, 7, 7)); rc_t = torch.from_numpy(rc).to(dev)
     table = torch.randn(2535, heads, device=dev) * 0.1
-    reg = torch.from_numpy(SI.region_ids(8, 14, 14, (8, 7, 7), (0, 3, 3))).to(dev)
-    kw = dict(q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW)
+    reg_np = SI.region_ids(8, 14, 14, (8, 7, 7), (0, 3, 3))
+    layout = int(os.environ.get("VMVM_PMC_LAYOUT", "1"))
+    if layout:                                                    # the win_layout = 1 token order (win3 kernels)
+        import numpy as np
+        pm = SI.win3_perm()
+        rc_t = torch.from_numpy(np.ascontiguousarray(rc[pm])).to(dev)
+        reg_np = np.ascontiguousarray(reg_np[:, pm])
+    reg = torch.from_numpy(reg_np).to(dev) if os.environ.get("VMVM_PMC_SHIFTED", "1") == "1" else None
+    kw = dict(q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, win_layout=layout)
     dtab = torch.zeros_like(table)
     for _ in range(3):
         out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, **kw)
