@@ -664,14 +664,19 @@ def vtm_negatives_default(B):
     return neg
 
 
-def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None):
-    """VIOLET_Pretrain.forward main_pretrain.py:226-267 (eval mode / explicit negatives)."""
+def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None, drop=None):
+    """VIOLET_Pretrain.forward main_pretrain.py:226-267 (eval mode / explicit negatives).
+    drop (train mode with EXPLICIT dropout multipliers, 0 or 1/keep): dict(emb (B,X,H) -- BertEmbeddings.dropout on the text features
+    (HF BertEmbeddings.forward, call site model.py:107), vtm (B*O,H) -- the VTM head's Dropout(0.1) on the text-[CLS] states
+    (main_pretrain.py:146,260))."""
     B, T, _, H, W = img.shape
     h, w = H // cfg["size_patch"], W // cfg["size_patch"]
     O = min(B, 4)
     Lv = (1 + h * w) * T
     feat_img, mask_img = enc_video(sd, cfg, img, dp_scales)
     feat_txt = enc_txt(sd, txt)
+    if drop is not None and drop.get("emb") is not None:
+        feat_txt = feat_txt * drop["emb"]
     out = go_cross(sd, cfg, feat_img, mask_img, feat_txt, mask)
     out_mtm = mlm_head(sd, out[:, Lv:])
     out_mvm = out[:, :Lv]
@@ -686,9 +691,12 @@ def pretrain_forward(sd, cfg, img, txt, mask, negatives=None, dp_scales=None):
         for k in range(O - 1):
             ii.append(i); jj.append(int(negatives[i][k]))
     out2 = go_cross(sd, cfg, feat_img[ii], mask_img[ii], feat_txt[jj], mask[jj])
-    out_vtm = vtm_head(sd, out2[:, Lv, :], cfg["temp"]).reshape(B, O)
+    cls2 = out2[:, Lv, :]
+    if drop is not None and drop.get("vtm") is not None:
+        cls2 = cls2 * drop["vtm"]
+    out_vtm = vtm_head(sd, cls2, cfg["temp"]).reshape(B, O)
     return dict(out_vtm=out_vtm, out_mvm=out_mvm, out_mtm=out_mtm, out_smtm=out_smtm, feat_img=feat_img, feat_txt=feat_txt,
-                ans_vtm=torch.zeros(B, dtype=torch.long))
+                vtm_cls=out2[:, Lv, :], ans_vtm=torch.zeros(B, dtype=torch.long))
 
 
 def pixel_loss(sd, cfg, out_mvm, unmask_img, mvm_mask):
@@ -970,9 +978,9 @@ def cross_entropy_ignore(logits, target):
     return F.cross_entropy(logits, target, ignore_index=-1)
 
 
-def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None):
+def pretrain_losses(sd, cfg, batch, negatives=None, dp_scales=None, drop=None):
     """Agent_Pretrain.step main_pretrain.py:555-567 : ls = mtm + vtm + mvm"""
-    out = pretrain_forward(sd, cfg, batch["img"], batch["txt"], batch["mask"], negatives, dp_scales)
+    out = pretrain_forward(sd, cfg, batch["img"], batch["txt"], batch["mask"], negatives, dp_scales, drop)
     ls_mtm = cross_entropy_ignore(out["out_mtm"].flatten(0, 1), batch["ans_mtm"].flatten())
     ls_vtm = cross_entropy_ignore(out["out_vtm"], out["ans_vtm"])
     ls_mvm = 0.0

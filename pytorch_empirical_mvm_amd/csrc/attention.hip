@@ -18,8 +18,8 @@
 // Backward is two kernels (no atomics on dQ/dK/dV): A) per query tile: dQ (+ the bias-table
 // gradient, accumulated in an LDS copy of the table, one global atomic per entry per workgroup),
 // B) per key tile: dK, dV.  Probabilities are recomputed from the saved log-sum-exp.
-// Attention-prob dropout: Philox4x32-7 per 4x4 (query,key) block, 8 random bits per element
-// (p_eff = round(256p)/256), the same block is addressed row-wise by fwd/A and column-wise by B.
+// Attention-prob dropout: Philox4x32-7 per 4x4 (query,key) block, 16 random bytes; an element compares a 16-bit field
+// (p quantised to 1/65536, attn_common.h drop_field), the same block is addressed row-wise by fwd/A and column-wise by B.
 #include "attn_common.h"
 #include <cstdlib>
 
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
   constexpr bool FAST1 = (MODE == 1) && !CAUSAL;          // fusion encoder: log2-domain packed softmax math
   const float sc2 = p.scale * 1.4426950408889634f;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
                   own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
                 const uint32_t w = u4_static(own, t & 3);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[u][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : e[u][j];
+                for (int j = 0; j < 4; ++j) e[u][j] = (drop_field(w, j) < thr16) ? 0.f : e[u][j];
               }
             }
             const bf16x8 pf = frag_from_f32(e[0], e[1]);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
         if (TILE_ON(t)) {
           const uint32_t w = u4_static(own, t & 3);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j];      // the 1/(1-p) keep scale rides on 1/sum below
+          for (int j = 0; j < 4; ++j) acc[t][j] = (drop_field(w, j) < thr16) ? 0.f : acc[t][j];      // the 1/(1-p) keep scale rides on 1/sum below
         }
       }
     }
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
   float* dtab = reinterpret_cast<float*>(smem + sm.off_dtab);
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
   const bool want_dtab = pb.dbias_table != nullptr;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
   if (MODE == 0) {
     for (int i = tid; i < sm.lp32; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
             float dp[4] = {d01[0], d01[1], d23[0], d23[1]};
             if (DROP) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) dp[j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dp[j];
+              for (int j = 0; j < 4; ++j) dp[j] = (drop_field(w, j) < thr16) ? 0.f : dp[j];
             }
             const f32x2 o01 = f32x2{pr[0], pr[1]} * (f32x2{dp[0], dp[1]} + ndl), o23 = f32x2{pr[2], pr[3]} * (f32x2{dp[2], dp[3]} + ndl);
             ds[u][0] = o01[0]; ds[u][1] = o01[1]; ds[u][2] = o23[0]; ds[u][3] = o23[1];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
               if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q >= p.causal_from && key0 + j <= q && key0 + j < L);
               const float pr = (ok && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
               float dpj = dp4[j] * seq_scale;
-              if (DROP) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
+              if (DROP) dpj = (drop_field(w, j) < thr16) ? 0.f : dpj * keep;
               ds[u][j] = pr * (dpj - dl);
             }
           }
@@ -1162,8 +1162,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
   const int nt = sm.nt, nt2 = sm.nt2;
   constexpr bool FAST1 = (MODE == 1) && !CAUSAL;
   const float sc2 = p.scale * 1.4426950408889634f, cdk = seq_scale * keep;
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 if (DROP) {
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
-                    const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                    const bool dropped = drop_field(u4_get(blk, j), key[t] & 3) < thr16;
                     pj[j] = dropped ? 0.f : pj[j];
                   }
                 }
@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                 const float pr = ok ? __expf(s4[t][j] * p.scale - ls[j]) : 0.f;
                 float dpj = dp4[t][j] * seq_scale, pj = pr;
                 if (DROP) {
-                  const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                  const bool dropped = drop_field(u4_get(blk, j), key[t] & 3) < thr16;
                   dpj = dropped ? 0.f : dpj * keep;
                   pj = dropped ? 0.f : pr * keep;
                 }
@@ -1679,8 +1679,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_stream_kernel(const vmvm_
   }
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
 
   const int qt = qb * NW + wave;
   const int q = qt * 16 + r;
@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_stream_kernel(const vmvm_
           own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((k0 / 16 + t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
         const uint32_t w = u4_static(own, t & 3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : acc[t][j] * keep;
+        for (int j = 0; j < 4; ++j) acc[t][j] = (drop_field(w, j) < thr16) ? 0.f : acc[t][j] * keep;
       }
     }
 #pragma unroll
@@ -1810,8 +1810,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dq_stream_kernel(const vm
   unsigned char* reg = smem + sm.off_reg;
   float* tab = reinterpret_cast<float*>(smem + sm.off_tab);
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
   if (MODE == 0) {
     for (int i = tid; i < sm.lpk; i += NW * 64) rc[i] = i < L ? p.rc[i] : 0;
     for (int i = tid; i < p.table_len; i += NW * 64) tab[i] = p.bias_table[(size_t)i * heads + h] * LOG2E;     // log2-domain scores
@@ -1901,7 +1901,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dq_stream_kernel(const vm
             for (int j = 0; j < 4; ++j) {
               const float pr = mks[j] ? __builtin_amdgcn_exp2f(__builtin_fmaf(s4[j], sc2, -lse2)) : 0.f;
               float dpj = dp4[j] * seq_scale;
-              if (has_drop) dpj = (((w >> (8 * j)) & 0xffu) < thr8) ? 0.f : dpj * keep;
+              if (has_drop) dpj = (drop_field(w, j) < thr16) ? 0.f : dpj * keep;
               ds[u][j] = pr * (dpj - dl);
             }
           }
@@ -2088,8 +2088,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dkv_stream_kernel(const v
 
   const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
   const bool has_drop = (MODE == 1) && p.dropout_p > 0.f;
-  const uint32_t thr8 = drop_thr8(p.dropout_p);
-  const float keep = has_drop ? 256.f / (256.f - (float)thr8) : 1.f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = has_drop ? 65536.f / (65536.f - (float)thr16) : 1.f;
   const int nt = (L + 15) / 16;
   const float sc2 = p.scale * LOG2E;
 
@@ -2184,7 +2184,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_dkv_stream_kernel(const v
                 const float pr = (kv[t] && regk[t]) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s4[t][j], sc2, -ls[j])) : 0.f;
                 float dpj = dp4[t][j] * seq_scale, pj = pr;
                 if (has_drop) {
-                  const bool dropped = ((u4_get(blk, j) >> (8 * (key[t] & 3))) & 0xffu) < thr8;
+                  const bool dropped = drop_field(u4_get(blk, j), key[t] & 3) < thr16;
                   dpj = dropped ? 0.f : dpj * keep;
                   pj = dropped ? 0.f : pr * keep;
                 }

@@ -260,6 +260,8 @@ class VioletEngine:
         self.store = ParamStore(CFG.param_shapes(cfg), self.device)
         self.seed = int(seed)
         self.rng_offset = 0
+        self._drop_sites = None                # None = every dropout site follows `train` (forward_backward(dropout=...))
+        self.last_offsets = {}                 # Philox offsets of the last pass' named dropout sites (tests recover the masks)
         self._idx_cache = {}
         self.tape = []
         self.teacher = None                 # frozen dVAE tokenizer (MVM 'vq' target), set by the model
@@ -553,6 +555,9 @@ class VioletEngine:
         return out, dims, C
 
     # -------------------------------------------------------------- EncVideo / EncTxt  -> one token pool
+    def _drop_on(self, site, train):
+        return bool(train) and (self._drop_sites is None or site in self._drop_sites)
+
     def encode(self, img, cov, txt, dp_all, train, odr=None):
         """returns pool V([B*Lv + NT*X, 768]) : rows [0, B*Lv) = feat_img (model.py:71), rest = feat_txt (model.py:107) of the NT =
         txt.shape[0] text sequences (NT = B in pre-training; B*O option sequences in multiple-choice QA)."""
@@ -595,8 +600,9 @@ class VioletEngine:
                          S.p(pt + "token_type_embeddings.weight")[0])
         gt, bt = S.p(pt + "LayerNorm.weight"), S.p(pt + "LayerNorm.bias")
         ft, mean_t, rstd_t = K.layernorm_fwd(e, gt, bt, CFG.BERT["eps"])
-        p_drop = CFG.BERT["hidden_dropout"] if train else 0.0
+        p_drop = CFG.BERT["hidden_dropout"] if self._drop_on("emb", train) else 0.0
         off_t = self._next_offset(ft.numel())
+        self.last_offsets["emb"] = off_t
         if p_drop > 0:
             ft = K.dropout(ft, p_drop, self.seed, off_t)
         pool[B * Lv:].copy_(ft)
@@ -845,7 +851,11 @@ class VioletEngine:
         self.tape = []
         if train and dp_all is None:
             dp_all = self.sample_drop_path(B)
-        train = train if dropout is None else bool(dropout)      # dropout sites follow `train` unless overridden
+        # dropout sites follow `train` unless overridden: dropout = False / True for all of them, or a collection of site names out of
+        # {"emb" (BertEmbeddings), "fusion" (the 12 BertLayers), "vtm" (the VTM head's Dropout, main_pretrain.py:146)} -- parity tests
+        # switch sites on one group at a time and feed the kernels' own masks to the oracle
+        self._drop_sites = None if (dropout is None or isinstance(dropout, bool)) else frozenset(dropout)
+        train = train if (dropout is None or self._drop_sites is not None) else bool(dropout)
         feat_target = batch.get("feature_target")
         if feat_target is None and self.feature_teacher is not None:
             feat_target = self.feature_teacher.features(img)     # frozen Swin teacher first: its activations are gone before the student's pile up
@@ -885,11 +895,11 @@ class VioletEngine:
         ntape = len(self.tape)
         qrow = os.environ.get("VMVM_QROW", "1") != "0"                             # (0: the whole last layer for every sequence, for A/B runs)
         if qrow:
-            (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train, qrow_split=(n1, Lv))
+            (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), qrow_split=(n1, Lv))
             if backward:
                 out1.g = torch.empty_like(out1.t)                                  # the heads write it in place
         else:
-            out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, train)
+            out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train))
             cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
             out1, out2c = V(out12.t[:n1 * Lq]), V(K.gather_rows(out12.t[n1 * Lq:], cls_rows, n2))
             if backward:
@@ -898,7 +908,7 @@ class VioletEngine:
         n_fusion_closures = len(self.tape) - ntape
         use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
         if use_smtm:                            # third pass under the seq2seq mask (main_pretrain.py:238-240)
-            out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, train, causal_from=Lv)
+            out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, self._drop_on("fusion", train), causal_from=Lv)
         losses = {k: torch.zeros(1, device=dev, dtype=F32) for k in ("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature", "mvm_hog", "smtm")}
         outs = {}
 
@@ -922,8 +932,9 @@ class VioletEngine:
 
         # ---- VTM head (main_pretrain.py:146-147,260-262,561)
         r_v = out2c.t                                    # [B*O, H]: the text [CLS] states of the VTM sequences
-        p_fc = 0.1 if train else 0.0
+        p_fc = 0.1 if self._drop_on("vtm", train) else 0.0
         off_fc = self._next_offset(r_v.numel())
+        self.last_offsets["vtm"] = off_fc
         r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
         h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
         inv_temp = 1.0 / cfg["temp"]
@@ -981,7 +992,7 @@ class VioletEngine:
             r_q = K.gather_rows(out1.t, prow, n_mp)
             y_q = K.gemm(r_q, Wq, bias=bq)                                            # [n_mp, 16*cq]
             x_q = y_q.view(n_mp * up * up, cq)
-            p_q = 0.1 if train else 0.0
+            p_q = 0.1 if self._drop_on("heads", train) else 0.0
             off_q = self._next_offset(x_q.numel())
             x_qd = K.dropout(x_q, p_q, self.seed, off_q) if p_q > 0 else x_q
             h_q = K.gemm(x_qd, S.b("fc_mvm.1.weight"), bias=S.p("fc_mvm.1.bias"), act=2)
@@ -996,7 +1007,7 @@ class VioletEngine:
         if use_feat:
             tgt_f = feat_target                                                          # bf16 [B*T*hw, F], no grad
             r_f = r_p if (use_pix or use_hog) else K.gather_rows(out1.t, vis_rows, B * T * hw)
-            p_f = 0.1 if train else 0.0
+            p_f = 0.1 if self._drop_on("heads", train) else 0.0
             off_f = self._next_offset(r_f.numel())
             r_fd = K.dropout(r_f, p_f, self.seed, off_f) if p_f > 0 else r_f
             h_f = K.gemm(r_fd, S.b("fc_mvm.1.weight"), bias=S.p("fc_mvm.1.bias"), act=2)

@@ -13,8 +13,8 @@ Tolerances AS ASSERTED below (bf16 activations / MFMA inputs, f32 accumulation a
 * out_vtm: absolute 0.15 at logit scale 1 / temp = 20 (a difference of two bf16-rounded [CLS] states times 20; measured 0.05);
 * the VTM head's fc.3.weight gradient (a difference of bf16-rounded activations): cosine >= 0.97 (measured 0.984), fc.1.*: >= 0.999; AdamW
   update direction after three steps (sign-like at step 1): cosine >= 0.98 (measured 0.995), update norm within 3 %.
-Attention-probability dropout is quantised to p = 26/256 = 0.1016 with the matching keep scale 256/230 (unbiased; the reference's
-p = 0.1): tests/test_round3_gpu.py feeds the kernels' own masks to the oracle."""
+Attention-probability dropout is quantised to p = 6554/65536 = 0.10001 (a 16-bit field compare on the block's random bytes; 26/256 until
+round 3) with the matching keep scale: tests/test_round3_gpu.py feeds the kernels' own masks to the oracle."""
 import os
 
 import numpy as np

@@ -511,8 +511,8 @@ def check_attn_bert():
     out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=11, offset=5)
     pm = out.float() * 64.0                                          # = mask/(1-p_eff)
     frac = (pm == 0).float().mean().item()
-    print(f"     attn dropout drop fraction {frac:.4f} (p_eff = 26/256 = 0.1016)")
-    mask = (pm != 0).float() * (256.0 / 230.0)
+    print(f"     attn dropout drop fraction {frac:.4f} (p = 6554/65536 = 0.10001)")
+    mask = (pm != 0).float() * (65536.0 / (65536.0 - 6554.0))
     qkv = rnd(nseq * Lq, 3 * Hd)
     out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=11, offset=5)
     qf = qkv.float().requires_grad_(True)
