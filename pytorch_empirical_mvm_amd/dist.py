@@ -150,8 +150,8 @@ class GradReducer:
         self.wire_bytes += 2 * (e - a)
 
     def _side(self, ranges):
-        """run the ranges on the side stream (GPU) / inline (CPU); from here until reduce_swin_and_wait() the persistent kernels of
-        the main stream are launched `reserve_cus` CUs short"""
+        """run the ranges on the side stream (GPU) / inline (CPU); from here until the side stream has finished them (polled by
+        kernels.reserve_cus(); at the latest reduce_swin_and_wait()) the persistent kernels are launched `reserve_cus` CUs short"""
         ranges = [(a, e) for a, e in ranges if e > a]
         if not ranges:
             return
@@ -165,7 +165,9 @@ class GradReducer:
             self.pending = True
             if self.reserve_cus > 0:
                 from . import kernels as K
-                K.RESERVE_CUS = self.reserve_cus
+                ev = torch.cuda.Event()
+                ev.record(self.stream)            # behind the last collective queued so far: kernels.reserve_cus() polls it and gives the
+                K.RESERVE_CUS, K.RESERVE_EVENT = self.reserve_cus, ev      # CUs back as soon as it has completed (not at the end of the backward)
         else:
             for a, e in ranges:
                 self._reduce_range(a, e)
@@ -199,4 +201,4 @@ class GradReducer:
             self.pending = False
         if self.cuda and self.reserve_cus > 0:
             from . import kernels as K
-            K.RESERVE_CUS = 0
+            K.RESERVE_CUS, K.RESERVE_EVENT = 0, None

@@ -30,10 +30,12 @@ def _run(script_args, timeout, **extra):
 @pytest.mark.parametrize("wire,cus", [("f32", "0"), ("bf16", "16")], ids=["f32-wire", "bf16-wire+16-CUs-reserved"])
 def test_two_ranks_gradient_mean_and_identical_replicas(wire, cus):
     """the default multi-GPU configuration -- bf16 gradient payload, persistent grids 16 CUs short while a collective is pending --
-    and the full-precision one: reduced gradient = mean of the per-rank gradients, replicas bit-identical after 3 optimizer steps"""
+    and the full-precision one: reduced gradient = mean of the per-rank gradients, = the gradient of ONE process on the concatenated
+    batch with the same (block-diagonal) negatives and equalised loss denominators, replicas bit-identical after 3 optimizer steps"""
     p = _run(["tools/dp_check.py"], 500, VMVM_GRAD_WIRE=wire, VMVM_COMM_CUS=cus, VMVM_COMM_CUS_ANY_BACKEND="1")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "replicas identical=True" in p.stdout and f"wire={wire} reserve_cus={cus}" in p.stdout, p.stdout[-2000:]
+    assert "concat-batch rel err" in p.stdout                    # SURVEY 8 a17's pin: DP-2 == one process on the concatenated batch (same negatives)
 
 
 @pytest.mark.timeout(900)

@@ -17,6 +17,54 @@ from pytorch_empirical_mvm_amd.agent import Agent_Pretrain  # noqa: E402
 from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain  # noqa: E402
 
 
+def concat_check(agent, model, mb, world, rank, dev):
+    """SURVEY 8 a17's pin: the data-parallel result equals ONE process on the concatenated batch with the same negatives.  The
+    reference's DDP averages per-rank MEAN losses, which is the mean over the concatenated batch exactly when the per-rank denominators
+    agree -- so the ranks' MLM target counts and covered-patch counts are first equalised (extra targets / covered patches are dropped
+    down to the minimum over the ranks; both sides see the same edited batch) and B_local = 4 keeps O = min(B, 4) the same on both
+    sides, with the single process' negatives block-diagonal (drawn inside each rank's own clips, main_pretrain.py:250).  Eval mode
+    (no dropout / DropPath draws).  Returns max |reduced / world - single| / max |single| over the gradient arena."""
+    eng, S = model.engine, model.engine.store
+    B = mb["txt"].shape[0]
+    ans, cov = mb["ans_mtm"].clone(), mb["cov"].clone()
+    n_t = torch.tensor([int((ans != -1).sum()), int(cov.sum())], device=dev)
+    dist.all_reduce(n_t, op=dist.ReduceOp.MIN)
+    idx = (ans != -1).flatten().nonzero().flatten()
+    ans.view(-1)[idx[int(n_t[0]):]] = -1
+    idc = cov.flatten().nonzero().flatten()
+    cov.view(-1)[idc[int(n_t[1]):]] = 0
+    assert int((ans != -1).sum()) == int(n_t[0]) > 0 and int(cov.sum()) == int(n_t[1]) > 0
+    b = dict(img=mb["img"].float().contiguous(), cov=cov.contiguous(), txt=mb["txt"].contiguous(), mask=mb["mask"].contiguous(), ans_mtm=ans.contiguous())
+    neg = eng.sample_negatives(B, np.random.RandomState(11 + rank))
+    # data-parallel side: every rank its own clips, gradients through the reducer
+    S.grad.zero_()
+    eng.on_swin_tail_ready = agent.comm.reduce_swin_tail
+    eng.forward_backward(b, negatives=neg, train=False, backward=True, on_other_grads_ready=agent.comm.reduce_other)
+    agent.comm.reduce_swin_and_wait()
+    torch.cuda.synchronize()
+    red = (S.grad[:S.n_trainable] / world).clone()
+    # single-process side (computed redundantly on every rank): the concatenated batch, block-diagonal negatives
+    cat = {}
+    for k, v in b.items():
+        parts = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        cat[k] = torch.cat(parts, 0).contiguous()
+    negs = [torch.empty_like(torch.from_numpy(np.ascontiguousarray(neg)).to(dev)) for _ in range(world)]
+    dist.all_gather(negs, torch.from_numpy(np.ascontiguousarray(neg)).to(dev))
+    neg_cat = np.concatenate([n_.cpu().numpy() + r_ * B for r_, n_ in enumerate(negs)], 0)
+    S.grad.zero_()
+    eng.on_swin_tail_ready = None
+    eng.forward_backward(cat, negatives=neg_cat, train=False, backward=True)
+    torch.cuda.synchronize()
+    one = S.grad[:S.n_trainable].clone()
+    S.grad.zero_()
+    err = float((red - one).abs().max() / (one.abs().max() + 1e-12))
+    cos = float((red.double() @ one.double()) / (red.double().norm() * one.double().norm() + 1e-30))
+    # (bf16 wire: each rank's term is rounded once before the sum; f32 wire: only summation order differs)
+    assert cos > (0.99999 if agent.comm.wire == "f32" else 0.9999) and err < (2e-3 if agent.comm.wire == "f32" else 1e-2), (cos, err)
+    return err
+
+
 def main():
     rank, world, local = D.init_from_env("nccl")
     assert world >= 2, "launch with torch.distributed.run --nproc-per-node >= 2"
@@ -64,7 +112,8 @@ def main():
         rel = float(((red - mean_ref).abs() / (mag + 1e-6 * mag.max())).max())
         assert rel < 2.0 ** -7 and agent.comm.wire_bytes == 2 * S.n_trainable, (rel, agent.comm.wire_bytes)
     from pytorch_empirical_mvm_amd import kernels as K
-    assert K.RESERVE_CUS == 0                                 # back to the whole chip once the reductions have been waited for
+    assert K.RESERVE_CUS == 0 and K.RESERVE_EVENT is None     # back to the whole chip once the reductions have been waited for
+    concat_err = concat_check(agent, model, mb, world, rank, dev)
     S.grad.zero_()
     for _ in range(3):
         r = agent.step(mb, is_train=True)
@@ -80,7 +129,7 @@ def main():
     dist.all_reduce(t)
     if rank == 0:
         print(f"dp_check world={world} backend={dist.get_backend()} wire={wire} reserve_cus={agent.comm.reserve_cus} grad-mean rel err {err:.2e} "
-              f"replicas identical={int(t.item()) == world} losses {r}", flush=True)
+              f"concat-batch rel err {concat_err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
     assert int(t.item()) == world
     dist.barrier()
     dist.destroy_process_group()
