@@ -279,19 +279,25 @@ class Agent_Pretrain:
         self.opt_step += 1
         gscale = 1.0 / self.world_size
         self._sumsq.zero_()
+        z1 = self.comm is not None and getattr(self.comm, "zero1", False)
+        oa, oe = self.comm.own if z1 else (0, S.n_trainable)
         if self.args.max_grad_norm > 0:
-            K.sumsq(S.grad[:S.n_trainable], self._sumsq)
+            if oe > oa:
+                K.sumsq(S.grad[oa:oe], self._sumsq)
+            if z1:
+                D.all_reduce_(self._sumsq)               # the global norm: every rank holds the reduced gradient of its shard only
         lrs = self.current_lrs()
 
         def update(groups):
             for gi in groups:
                 a, e = S.segments[gi]
+                a, e = max(a, oa), min(e, oe)            # (ZeRO-1: this rank's shard of the group; otherwise the whole group)
                 if e > a:
                     K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
                             beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
                             grad_scale=gscale)
         eng = self.engine
-        split = getattr(eng, "wstream", None) is not None and getattr(S, "shadow8", None) is None and os.environ.get("VMVM_OPT_OVERLAP", "1") != "0"
+        split = getattr(eng, "wstream", None) is not None and getattr(S, "shadow8", None) is None and os.environ.get("VMVM_OPT_OVERLAP", "1") != "0" and not z1
         if split:
             # The next forward starts with the Video-Swin backbone, which reads Swin parameters only: the update of the other 137 M parameters
             # (fusion encoder, heads, embeddings), their W^T copies and the zeroing of their gradients run on the engine's second stream
@@ -313,6 +319,9 @@ class Agent_Pretrain:
                 S.grad[a:e].zero_()
         else:
             update(range(4))
+            if z1:                                       # the other ranks' updated master shards, then their bf16 compute copies
+                for sa, se in self.comm.gather_params(S.flat):
+                    K.cast_bf16(S.flat[sa:se], S.shadow[sa:se])
             S.refresh_transposed()
             if getattr(S, "shadow8", None) is not None:      # fp8 forward (config 5): the e4m3 weight copy follows the updated bf16 copy
                 K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE, out=S.shadow8[:S.total8])

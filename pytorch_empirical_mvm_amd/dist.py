@@ -16,7 +16,15 @@ CU reservation (`VMVM_COMM_CUS`, default 16, 0 = off; nccl backend only): the pe
 CU and split their tiles statically, so a collective's channel workgroups either wait for a kernel boundary or -- once resident --
 push persistent workgroups into a second round.  While a collective is pending the kernels are launched `VMVM_COMM_CUS` CUs short
 (vmvm_gemm_desc.reserve_cus) and RCCL is held to as many channels (NCCL_MAX_NCHANNELS, set before the process group is created,
-unless the user already set it)."""
+unless the user already set it).
+
+ZeRO-1 shape (`VMVM_ZERO1=1`, off by default; the reference's default engine is DeepSpeed ZeRO stage 1, utils/deepspeed.py:42-44 /
+agent.py:196-199): the trainable arena is cut into `world` contiguous shards; every phase REDUCES each shard's piece to its owner
+(same wire bytes as a reduce-scatter), the owner alone runs the clip + AdamW on its 1/world of the arena (Adam state touched: 1/world
+-- the 6.75 GB per step optimizer stream of a GPU becomes 0.84 GB at 8 ranks), and the updated f32 master shards are broadcast
+(= all-gather).  f32, not the bf16 compute copy: biases, LayerNorm weights, the embedding tables and the relative-position tables are
+consumed in f32 by the kernels, so replicas stay bit-identical only if the masters are.  Wire per step: 2 B (gradients) + 4 B
+(parameters) per element against 2 x 2 B of the bf16 all-reduce; the global gradient norm is one extra scalar all-reduce."""
 import os
 
 import torch
@@ -101,6 +109,25 @@ def broadcast_(t, src=0):
     return t
 
 
+def zero1():
+    return os.environ.get("VMVM_ZERO1", "0") == "1"
+
+
+def shard_bounds(n, world, align=256):
+    """`world` contiguous shards of [0, n), boundaries on multiples of `align` elements"""
+    per = -(-(-(-n // world)) // align) * align
+    return [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+
+
+def reduce_chunks_(flat, a, e, dst):
+    """sum-reduce flat[a:e] onto rank `dst` in CHUNK_ELEMS pieces; returns the number of collectives issued."""
+    n = 0
+    for s in range(a, e, CHUNK_ELEMS):
+        dist.reduce(flat[s:min(e, s + CHUNK_ELEMS)], dst)
+        n += 1
+    return n
+
+
 def all_reduce_chunks_(flat, a, e):
     """sum-all-reduce flat[a:e] in CHUNK_ELEMS pieces; returns the number of collectives issued."""
     n = 0
@@ -126,12 +153,22 @@ class GradReducer:
         # (VMVM_COMM_CUS_ANY_BACKEND: test hook -- the shared-GPU gloo test runs the short grids too)
         on = nccl or bool(os.environ.get("VMVM_COMM_CUS_ANY_BACKEND"))
         self.reserve_cus = (comm_cus() if (on and self.cuda) else 0) if reserve_cus is None else int(reserve_cus)
+        self.zero1 = zero1() and dist.is_available() and dist.is_initialized()
+        self.shards = shard_bounds(store.n_trainable, dist.get_world_size(), 256) if self.zero1 else None
+        self.own = self.shards[dist.get_rank()] if self.zero1 else (0, store.n_trainable)
         self.wait_streams = []                    # further producer streams (the engine's weight-gradient stream) a reduction must wait for
         self.collectives = 0                      # issued so far (tests / profiling)
         self.wire_bytes = 0
 
     # ---- one contiguous range of the arena
     def _reduce_range(self, a, e):
+        if self.zero1:                            # every shard's piece of the range goes to its owner only
+            me = dist.get_rank()
+            for r, (sa, se) in enumerate(self.shards):
+                lo, hi = max(a, sa), min(e, se)
+                if hi > lo:
+                    self._reduce_piece(lo, hi, r, r == me)
+            return
         g = self.store.grad
         if self.wire_buf is None:
             self.collectives += all_reduce_chunks_(g, a, e)
@@ -148,6 +185,40 @@ class GradReducer:
             self.collectives += all_reduce_chunks_(w, a, e)
             g[a:e].copy_(w[a:e])
         self.wire_bytes += 2 * (e - a)
+
+    def _reduce_piece(self, a, e, dst, mine):
+        g, w = self.store.grad, self.wire_buf
+        if w is None:
+            self.collectives += reduce_chunks_(g, a, e, dst)
+            self.wire_bytes += 4 * (e - a)
+            return
+        if self.cuda:
+            from . import kernels as K
+            K.cast_bf16(g[a:e], w[a:e])
+            self.collectives += reduce_chunks_(w, a, e, dst)
+            if mine:
+                K.cast_f32(w[a:e], g[a:e])
+        else:
+            w[a:e].copy_(g[a:e])
+            self.collectives += reduce_chunks_(w, a, e, dst)
+            if mine:
+                g[a:e].copy_(w[a:e])
+        self.wire_bytes += 2 * (e - a)
+
+    def gather_params(self, flat):
+        """ZeRO-1: every owner broadcasts its updated f32 master shard (an all-gather as `world` broadcasts); returns the shards the
+        caller did NOT own (their bf16 compute copies have to be re-cast)."""
+        others = []
+        me = dist.get_rank()
+        for r, (sa, se) in enumerate(self.shards):
+            if se > sa:
+                for s0 in range(sa, se, CHUNK_ELEMS):
+                    dist.broadcast(flat[s0:min(se, s0 + CHUNK_ELEMS)], r)
+                    self.collectives += 1
+                self.wire_bytes += 4 * (se - sa)
+                if r != me:
+                    others.append((sa, se))
+        return others
 
     def _side(self, ranges):
         """run the ranges on the side stream (GPU) / inline (CPU); from here until the side stream has finished them (polled by

@@ -113,3 +113,55 @@ def test_two_phase_gradient_reduction_world2_gloo(wire):
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _worker_zero1(rank, world, port, q):
+    """ZeRO-1 shape (VMVM_ZERO1=1; the reference's default engine, utils/deepspeed.py:42-44): after the three phases a rank holds the
+    rank-sum of ITS shard only, 2 bytes per trainable element crossed the wire for the gradients, and gather_params makes the f32
+    masters identical again from the owners' shards."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VMVM_GRAD_WIRE="bf16",
+                      VMVM_ZERO1="1")
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd import dist as D
+    from pytorch_empirical_mvm_amd.engine import ParamStore
+    D.init_from_env("gloo")
+    args = CFG.get_args(vis_backbone_size="tiny", arch_override=dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7)),
+                        bert_layers=1)
+    S = ParamStore(CFG.param_shapes(CFG.model_cfg(args)), torch.device("cpu"))
+    S.grad[:S.total].copy_(torch.randn(S.total, generator=torch.Generator().manual_seed(100 + rank)))
+    mine = S.grad[:S.total].clone()
+    red = D.GradReducer(S, "cpu")
+    ok = red.zero1 and len(red.shards) == world and red.shards[0][0] == 0 and red.shards[-1][1] == S.n_trainable
+    ok &= all(red.shards[i][1] == red.shards[i + 1][0] and red.shards[i][1] % 256 == 0 for i in range(world - 1))
+    red.reduce_other(); red.reduce_swin_tail(); red.reduce_swin_and_wait()
+    locals_ = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)).to(torch.bfloat16) for k in range(world)]
+    want = (locals_[0].float() + locals_[1].float()).to(torch.bfloat16).float()
+    oa, oe = red.own
+    ok &= oe > oa and torch.equal(S.grad[oa:oe], want[oa:oe])                        # my shard: the sum
+    ok &= red.wire_bytes == 2 * S.n_trainable
+    a, e = S.segments[4]
+    ok &= torch.equal(S.grad[a:e], mine[a:e])                                         # frozen segment untouched
+    # the "optimizer": every rank rewrites its own master shard, then the shards travel
+    S.flat[:S.total].fill_(-1.0)
+    S.flat[oa:oe] = torch.arange(oa, oe, dtype=torch.float32) * (rank + 1)
+    others = red.gather_params(S.flat)
+    ok &= sorted(others + [red.own]) == sorted(red.shards)
+    for r_, (sa, se) in enumerate(red.shards):
+        ok &= torch.equal(S.flat[sa:se], torch.arange(sa, se, dtype=torch.float32) * (r_ + 1))
+    q.put((rank, bool(ok)))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_zero1_sharded_reduction_and_parameter_gather_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_zero1, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

@@ -34,7 +34,7 @@ def test_two_ranks_gradient_mean_and_identical_replicas(wire, cus):
     batch with the same (block-diagonal) negatives and equalised loss denominators, replicas bit-identical after 3 optimizer steps"""
     p = _run(["tools/dp_check.py"], 500, VMVM_GRAD_WIRE=wire, VMVM_COMM_CUS=cus, VMVM_COMM_CUS_ANY_BACKEND="1")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "replicas identical=True" in p.stdout and f"wire={wire} reserve_cus={cus}" in p.stdout, p.stdout[-2000:]
+    assert "replicas identical=True" in p.stdout and f"wire={wire} " in p.stdout and f"reserve_cus={cus} " in p.stdout, p.stdout[-2000:]
     assert "concat-batch rel err" in p.stdout                    # SURVEY 8 a17's pin: DP-2 == one process on the concatenated batch (same negatives)
 
 
@@ -48,3 +48,20 @@ def test_bench_contract_two_ranks():
     assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak" and o["config"]["global_batch"] == 8
     assert o["value"] > 0 and abs(o["value"] - 8 * 2 / (o["ms_per_step"] * 2 / 1e3)) < 1e-2 * o["value"]
     assert "cpu_baseline" not in o and o["roofline"]["frac"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_zero1_shape_equals_plain_data_parallel():
+    """VMVM_ZERO1=1 (the reference's default engine is DeepSpeed ZeRO-1, utils/deepspeed.py:42-44): per-shard reduce -> the owner's clip +
+    AdamW on 1/world of the arena -> f32 master shards broadcast.  Same checks as the plain path (own-shard gradient = mean of the ranks',
+    = one process on the concatenated batch, replicas bit-identical after 3 steps, 2 + 4 bytes per element per step on the wire) and the
+    parameters after the 3 steps equal those of the plain data-parallel run (same sums, same update arithmetic)."""
+    out = {}
+    for z in ("0", "1"):
+        p = _run(["tools/dp_check.py"], 400, VMVM_GRAD_WIRE="bf16", VMVM_COMM_CUS="0", VMVM_ZERO1=z)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        assert "replicas identical=True" in p.stdout and f"zero1={z}" in p.stdout, p.stdout[-2000:]
+        out[z] = float([l for l in p.stdout.splitlines() if l.startswith("param-checksum")][0].split()[1])
+        per = float(p.stdout.split("wire-bytes/element/step")[1].split()[0])
+        assert abs(per - (6.0 if z == "1" else 2.0)) < 0.05, per
+    assert abs(out["0"] - out["1"]) <= 1e-6 * abs(out["0"]), out

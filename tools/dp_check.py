@@ -42,7 +42,8 @@ def concat_check(agent, model, mb, world, rank, dev):
     eng.forward_backward(b, negatives=neg, train=False, backward=True, on_other_grads_ready=agent.comm.reduce_other)
     agent.comm.reduce_swin_and_wait()
     torch.cuda.synchronize()
-    red = (S.grad[:S.n_trainable] / world).clone()
+    oa, oe = agent.comm.own
+    red = (S.grad[oa:oe] / world).clone()
     # single-process side (computed redundantly on every rank): the concatenated batch, block-diagonal negatives
     cat = {}
     for k, v in b.items():
@@ -56,7 +57,7 @@ def concat_check(agent, model, mb, world, rank, dev):
     eng.on_swin_tail_ready = None
     eng.forward_backward(cat, negatives=neg_cat, train=False, backward=True)
     torch.cuda.synchronize()
-    one = S.grad[:S.n_trainable].clone()
+    one = S.grad[oa:oe].clone()
     S.grad.zero_()
     err = float((red - one).abs().max() / (one.abs().max() + 1e-12))
     cos = float((red.double() @ one.double()) / (red.double().norm() * one.double().norm() + 1e-30))
@@ -101,7 +102,10 @@ def main():
     eng.forward_backward(b, negatives=neg, train=True, dp_all=dp, on_other_grads_ready=agent.comm.reduce_other)
     agent.comm.reduce_swin_and_wait()
     torch.cuda.synchronize()
-    red = S.grad[:S.n_trainable] / world
+    oa, oe = agent.comm.own                                   # ZeRO-1 (VMVM_ZERO1=1): a rank holds the reduced gradient of its shard only
+    red = S.grad[oa:oe] / world
+    mean_ref = mean_ref[oa:oe]
+    gather = [g_[oa:oe] for g_ in gather]
     err = float((red - mean_ref).abs().max() / (mean_ref.abs().max() + 1e-12))
     wire = agent.comm.wire
     # f32 payload: the mean to rounding; bf16 payload: two roundings of 2^-9 relative each (cast + reduction), element by element
@@ -114,6 +118,7 @@ def main():
     from pytorch_empirical_mvm_amd import kernels as K
     assert K.RESERVE_CUS == 0 and K.RESERVE_EVENT is None     # back to the whole chip once the reductions have been waited for
     concat_err = concat_check(agent, model, mb, world, rank, dev)
+    wb0, nc0 = agent.comm.wire_bytes, agent.comm.collectives
     S.grad.zero_()
     for _ in range(3):
         r = agent.step(mb, is_train=True)
@@ -125,10 +130,14 @@ def main():
     if not same:
         d = (flat - ref).abs()
         print(f"rank {rank}: {int((d > 0).sum())} of {flat.numel()} parameters differ from rank 0, max abs diff {float(d.max()):.3e}", flush=True)
+    if rank == 0:
+        print(f"param-checksum {float(flat.double().abs().sum()):.9e}", flush=True)
     t = torch.tensor([1.0 if same else 0.0], device=dev)
     dist.all_reduce(t)
     if rank == 0:
-        print(f"dp_check world={world} backend={dist.get_backend()} wire={wire} reserve_cus={agent.comm.reserve_cus} grad-mean rel err {err:.2e} "
+        per_step = (agent.comm.wire_bytes - wb0) / 3 / S.n_trainable
+        print(f"dp_check world={world} backend={dist.get_backend()} wire={wire} zero1={int(agent.comm.zero1)} wire-bytes/element/step {per_step:.2f} "
+              f"reserve_cus={agent.comm.reserve_cus} grad-mean rel err {err:.2e} "
               f"concat-batch rel err {concat_err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
     assert int(t.item()) == world
     dist.barrier()
