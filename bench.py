@@ -310,6 +310,7 @@ def main():
                              "achieved": round(30.0 * adamw_n / adamw_s / 1e9, 1) if adamw_s else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                              "frac": round(30.0 * adamw_n / adamw_s / PEAK_HBM, 4) if adamw_s else None, "algorithmic_bytes": int(30 * adamw_n)}},
         "losses_last_step": last,
+        "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),      # caching-allocator peak of this rank over the whole run
     }
     if world == 1 and not a.no_cpu_baseline and a.img == 224:
         out["cpu_baseline"] = cpu_baseline(a.size, a.frames)

@@ -94,7 +94,7 @@ def install_stubs():
     _stub("timm"); _stub("timm.models"); _stub("timm.models.layers", DropPath=object, to_2tuple=None, trunc_normal_=None)
     _stub("wandb")
     _stub("dataset", Dataset_Base=object, get_dl=None, move_to_cuda=lambda b: b, get_tsv_dls=None,
-          MetaLoader=object, PrefetchLoader=object)
+          MetaLoader=object, PrefetchLoader=object, TsvCompositeDataset=object, make_data_loader=None)
     os.environ["WANDB_ENABLE"] = "0"
 
 
@@ -938,6 +938,66 @@ def gold_mlm_qa(size="tiny", T=4, B=3):
     print("mlm_qa ok", {k: (v.tolist() if v.size < 8 else v.shape) for k, v in d.items() if k.split(".")[-1] in ("loss", "ac", "ac_1", "ac_5", "toy_ac1", "toy_ac5")})
 
 
+def gold_loop():
+    """tests/golden/loop.json: the control flow of the reference's training driver -- `MetaLoader` (dataset.py:511-547; the class body is
+    exec'd from the reference's file here, the module itself needs the data stack), `RunningMeter` (utils/logger.py) and
+    `Agent_Pretrain_YAML.run_meta_loader` / `go_ep` (main_pretrain_yaml.py:123-194) with the step / evaluate / save hooks replaced by
+    recorders: which (task, batch) comes when, when evaluation and checkpoints happen, what the smoothed losses and the log dict hold."""
+    import re
+    from utils.logger import RunningMeter
+    import main_pretrain_yaml as MY
+    src = open(os.path.join(REF, "dataset.py")).read()
+    m = re.search(r"^class MetaLoader\(object\):.*?(?=^class |\Z)", src, re.S | re.M)
+    ns = dict(random=random, T=torch, DIST=None)
+    exec(m.group(0), ns)
+    RefMeta = ns["MetaLoader"]
+    mk = lambda n, tag: torch.utils.data.DataLoader([f"{tag}{i}" for i in range(n)], batch_size=1, collate_fn=lambda x: x[0])
+    out = {}
+    for acc in (1, 2):
+        random.seed(5)
+        ml = RefMeta({"a": (mk(3, "a"), 2), "b": mk(2, "b")}, accum_steps=acc)
+        it = iter(ml)
+        out[f"meta_accum{acc}"] = [list(next(it)) for _ in range(14)]
+    rm = RunningMeter("x")
+    vals = []
+    for v in (2.0, 1.0, 4.0, -1.0):
+        rm(v); vals.append(rm.val)
+    out["running_meter"] = vals
+
+    class Rec(MY.Agent_Pretrain_YAML):
+        def __init__(self, args):
+            self.args, self.trace = args, []
+            self.task2loss, self.log, self.ds_tr_steps, self.global_step = {}, MY.defaultdict(list), MY.defaultdict(int), 0
+            self.n = 0
+        def masking(self, img, txt, mask, vq): return {"masked": True}
+        def prepare_batch(self, b): return b
+        def step(self, batch, is_train):
+            self.n += 1
+            self.trace.append(["step", batch["id"]])
+            return {"mtm": 1.0 + 0.5 * self.n, "vtm": 0.25 * self.n, "mvm": -1}
+        def evaluate(self, dl):
+            self.trace.append(["eval", dl])
+            return {"mtm": 0.5, "vtm": 0.75}
+        def save_model(self, ep, ds, step): self.trace.append(["save", ep, ds, step])
+        def log_memory(self, ep=-1, step=-1): return "mem"
+        def log_dict_to_wandb(self, d, step=-1): pass
+    dump = lambda a: dict(trace=a.trace, meters={k: v.val for k, v in a.task2loss.items()}, log={k: v for k, v in a.log.items()},
+                          ds_tr_steps=dict(a.ds_tr_steps), global_step=a.global_step)
+    for max_iter, eval_step in ((7, 3), (6, 3), (4, 10)):
+        a = Rec(_AttrDict(iter_per_ep=4, logging_steps=2, eval_step=eval_step, max_iter=max_iter))
+        stream = [("ds%d" % (i % 2), {"id": i, "img": None, "txt": None, "mask": None, "vq": None}) for i in range(50)]
+        a.run_meta_loader(stream, {"val": "VL"})
+        out[f"run_meta_loader_{max_iter}_{eval_step}"] = dump(a)
+    for iter_per_ep, eval_step in ((5, 2), (4, 2)):
+        a = Rec(_AttrDict(iter_per_ep={"d": iter_per_ep}, logging_steps=2, eval_step={"d": eval_step}))
+        class DL(list):
+            pass
+        a.go_ep({"d": DL({"id": i, "img": None, "txt": None, "mask": None, "vq": None, "vid": ["v"]} for i in range(20))}, {"val": "VL"}, 2)
+        out[f"go_ep_{iter_per_ep}_{eval_step}"] = dump(a)
+    json.dump(out, open(os.path.join(OUT, "loop.json"), "w"), indent=1)
+    print("wrote loop.json")
+
+
 def gold_inflate(vs):
     """SwinTransformer3D.inflate_weights (video_swin.py:484-535) on a synthetic image-Swin checkpoint: one with 7x7-window tables (tiled
     only) and one with 6x6-window tables (bicubic resize to 13x13, then tiled); the reference module's state_dict afterwards"""
@@ -1003,6 +1063,9 @@ if __name__ == "__main__":
     if "--tsv-only" in sys.argv:
         gold_tsv()
         sys.exit(0)
+    if "--loop-only" in sys.argv:
+        gold_loop()
+        sys.exit(0)
     if "--inflate-only" in sys.argv:
         gold_inflate(vs)
         sys.exit(0)
@@ -1055,3 +1118,4 @@ if __name__ == "__main__":
     gold_encvideo_odr()
     gold_inflate(vs)
     gold_tsv()
+    gold_loop()
