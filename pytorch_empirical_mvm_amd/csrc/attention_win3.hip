@@ -438,9 +438,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
   unsigned char* TL = smem + 4 * KV + 2 * XCH * 4;
   const bool want_dtab = pb.dbias_table != nullptr;
   const int ql = wave % NQ, kh = wave / NQ;                             // query tile slot, key half
-  const int qt = qg * NQ + ql;
+  // query tiles of this group: the 25 tiles are dealt evenly over the nqg groups (nqg = 7: 4,4,4,4,4,4,1 as in win2; nqg = 8: runs of
+  // 3 / 4 tiles -- heads x 8 base workgroups divide the 256 CUs for every stage's head count, and a CU carries 6 waves instead of 8)
+  const int qt0 = nqg == 7 ? qg * NQ : (w3::NT * qg) / nqg;
+  const int qcnt = nqg == 7 ? (w3::NT - qt0 < NQ ? w3::NT - qt0 : NQ) : (w3::NT * (qg + 1)) / nqg - qt0;
+  const int qt = qt0 + ql;
   const int q = qt * 16 + r;
-  const bool active = qt < w3::NT;
+  const bool active = ql < qcnt;
   const bool qv = active && (q < L);
   const int qc = qt < w3::CB[1] ? 0 : qt < w3::CB[2] ? 1 : qt < w3::CB[3] ? 2 : 3;
 
@@ -713,7 +717,8 @@ __attribute__((visibility("hidden"))) bool applicable(const vmvm_attn_fwd_desc* 
 __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st) {
   constexpr int KV = 400 * 64, XCH = 4 * 64 * 8;
   const int smem = 4 * KV + 2 * XCH * 4 + w3::TAB_BYTES;
-  const int nqg = (w3::NT + 3) / 4;
+  static const int nqg_env = getenv("VMVM_W3_DQ_GROUPS") ? atoi(getenv("VMVM_W3_DQ_GROUPS")) : 7;
+  const int nqg = nqg_env == 8 ? 8 : 7;
   const int base = d->f.heads * nqg;
   const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
   const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 10.f);

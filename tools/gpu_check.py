@@ -1041,7 +1041,10 @@ def bench_attn():
     fl = 4.0 * nseq * heads * Lq * Lq * 64
     f0 = lambda: K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.0, seed=1)
     b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.0, seed=1)
-    for name, fn, mult in (("bert fwd", f, 1), ("bert bwd", b, 2.5), ("bert fwd (no dropout)", f0, 1), ("bert bwd (no dropout)", b0, 2.5)):
+    fs = lambda: K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, stream_min_len=1)
+    bs = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, stream_min_len=1)
+    for name, fn, mult in (("bert fwd", f, 1), ("bert bwd", b, 2.5), ("bert fwd (no dropout)", f0, 1), ("bert bwd (no dropout)", b0, 2.5),
+                           ("bert fwd (streaming kernels)", fs, 1), ("bert bwd (streaming kernels)", bs, 2.5)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
