@@ -274,6 +274,7 @@ class Agent_Pretrain:
     def backward_step(self):
         """all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:186-193)"""
         S = self.engine.store
+        S.sync_pending()                                 # (a second backward_step without a forward in between: the previous tail first)
         if self.comm is not None:
             self.comm.reduce_swin_and_wait()
         self.opt_step += 1
@@ -312,11 +313,13 @@ class Agent_Pretrain:
                     S.grad[a:e].zero_()
                 eng.other_ready = torch.cuda.Event()
                 eng.other_ready.record()
+                S.pending = eng.other_ready              # (ParamStore.sync_pending: every reader of the non-Swin arena waits for this)
             update((0, 2))
             S.refresh_transposed("swin")
             for gi in (0, 2):
                 a, e = S.segments[gi]
                 S.grad[a:e].zero_()
+            S.grad[S.n_trainable:].zero_()               # the frozen segment + padding tail (S.grad.zero_() of the unsplit path covers them)
         else:
             update(range(4))
             if z1:                                       # the other ranks' updated master shards, then their bf16 compute copies

@@ -1491,7 +1491,10 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // remainder is more than ~a quarter of a round (50176 x 512: 1.53 rounds).  Row-indexed epilogue operands move with the rows;
     // the dropout stream is indexed by the absolute element (8-element blocks), so its offset moves by m_split * N / 8.
     const int cus_ = vmvm_usable_cus(dd.reserve_cus);      // the ping-pong grid: one workgroup per usable CU (fewer while a collective is pending)
-    if (pays && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
+    // (explicit: the split below offsets A / C / resid by ROWS of 2-byte elements -- k-major operands, 16-bit output, no row map /
+    //  column sums / accumulation.  pp_shape implies all of this today; the split must not depend on that staying true.)
+    const bool split_ok = dd.a_kmajor && dd.b_kmajor && !dd.out_fp32 && !dd.row_map && !dd.colsum && !dd.accumulate && !dd.in_fp8 && !dd.conv_taps;
+    if (pays && split_ok && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
       const int nbn_ = (dd.N + 255) / 256, nbm_ = (dd.M + 255) / 256;
       const int tm_split = (int)(((tiles / cus_) * cus_) / nbn_);
       const long rem_tiles = (long)(nbm_ - tm_split) * nbn_;

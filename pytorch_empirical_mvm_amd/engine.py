@@ -92,6 +92,18 @@ class ParamStore:
         o, c, s = self.index[n]
         return buf[o:o + c].view(shape or s)
 
+    pending = None          # event of an optimizer tail still running on the engine's second stream (agent.backward_step): it updates the
+                            # non-Swin parameters, their bf16 / W^T copies and zeroes their gradients beside the next Video-Swin forward
+
+    def sync_pending(self):
+        """make the current stream wait for that tail.  engine.encode() calls it before the first non-Swin parameter of a step is read;
+        every other reader / writer of non-Swin flat / shadow / grad outside the step (refresh_*, load / save, broadcasts, tests that poke
+        S.p() / S.g() directly, a second backward_step without a forward) goes through here as well."""
+        ev = self.pending
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.pending = None
+
     def p(self, n, shape=None):
         return self._view(self.flat, n, shape)
 
@@ -113,6 +125,7 @@ class ParamStore:
     W8_SCALE = 512.0        # static per-tensor scale of the fp8 weight copies (|w| up to 0.875 before e4m3 saturates at 448)
 
     def refresh_shadow(self):
+        self.sync_pending()
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
         self.refresh_transposed()
         if getattr(self, "shadow8", None) is not None:
@@ -120,6 +133,7 @@ class ParamStore:
 
     def enable_fp8(self):
         """allocate the e4m3 copy of the arena (BASELINE config 5's fp8 forward GEMMs); refreshed with the bf16 copy"""
+        self.sync_pending()
         if getattr(self, "shadow8", None) is None and self.device.type == "cuda":
             self.total8 = -(-self.total // 8) * 8
             self.shadow8 = torch.zeros(self.total8 + self.TAIL, device=self.device, dtype=torch.uint8)
@@ -182,6 +196,7 @@ class ParamStore:
     def load_state(self, sd):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)          # (an optimizer tail may still be updating part of the arena on the second stream)
+            self.pending = None
         for n, (o, c, s) in self.index.items():
             if n in sd:
                 self.flat[o:o + c].copy_(sd[n].reshape(-1).to(self.device, F32))
@@ -190,6 +205,7 @@ class ParamStore:
     def state_dict(self):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)          # (part of the optimizer tail may still be running on the engine's second stream)
+            self.pending = None
         return OrderedDict((n, self.p(n).detach().clone()) for n in self.index)
 
 
@@ -572,9 +588,8 @@ class VioletEngine:
         X = txt.shape[1]
         Hd = cfg["hidden"]
         sw, dims, C8 = self.swin_forward(img, cov, dp_all)
-        if self.other_ready is not None:    # everything below reads non-Swin parameters: their AdamW update ran beside the Swin forward
-            torch.cuda.current_stream().wait_event(self.other_ready)
-            self.other_ready = None
+        self.store.sync_pending()           # everything below reads non-Swin parameters: their AdamW update ran beside the Swin forward
+        self.other_ready = None
         hw = dims[1] * dims[2]
         assert dims[1] == H // 32 and dims[2] == W // 32                       # model.py:34 hard-codes //32
         Lv = T * (1 + hw)
@@ -761,6 +776,8 @@ class VioletEngine:
             return cur, xv, idx
         # last layer: the first n1 sequences in full, of the others only the row at `qpos` (see _bert_layer_qrow)
         n1, qpos = qrow_split
+        if causal_from != 0 or att_out is not None:     # _bert_layer_qrow has neither the seq2seq mask nor the attention capture
+            raise RuntimeError("go_cross(qrow_split=...) serves the plain key-mask pass only (no causal_from / att_out)")
         if n1 == 0:                               # every sequence: only the row at `qpos` (retrieval / open-ended QA read the text [CLS] state only)
             return (None, self._bert_layer_qrow(cur, nseq, Lq, qpos, keymask, nl - 1, train)), xv, idx
         xa, xb = V(cur.t[:n1 * Lq]), V(cur.t[n1 * Lq:])

@@ -165,3 +165,51 @@ def test_zero1_sharded_reduction_and_parameter_gather_world2_gloo():
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _worker_wire8(rank, world, port, q):
+    """the bf16 gradient payload at EIGHT ranks.  gloo's ring adds partial sums in bf16 as well, so the reduced value carries
+    up to world - 1 roundings of 2^-9 relative each (of the running sum), on top of the one cast per rank.  Asserted here, against the
+    f32 sum of the ranks' f32 gradients: every rank receives identical bits; the error of an element stays below
+    world * 2^-8 * sum_k |g_k| (measured: ~1/4 of that bound), i.e. the relative error of the gradient NORM is far below the clip
+    threshold's resolution.  (RCCL's ring reduces the same way; its tree variants round fewer times.)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VMVM_GRAD_WIRE="bf16")
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd import dist as D
+    from pytorch_empirical_mvm_amd.engine import ParamStore
+    D.init_from_env("gloo")
+    args = CFG.get_args(vis_backbone_size="tiny", arch_override=dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7)),
+                        bert_layers=1)
+    S = ParamStore(CFG.param_shapes(CFG.model_cfg(args)), torch.device("cpu"))
+    gens = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    S.grad[:S.total].copy_(gens[rank])
+    red = D.GradReducer(S, "cpu")
+    red.reduce_other(); red.reduce_swin_tail(); red.reduce_swin_and_wait()
+    n = S.n_trainable
+    exact = sum(g.double() for g in gens)[:n]
+    mag = sum(g.abs().double() for g in gens)[:n]
+    got = S.grad[:n].double()
+    rel = float(((got - exact).abs() / (mag + 1e-30)).max())
+    norm_err = abs(float(got.norm() / exact.norm()) - 1.0)
+    chk = S.grad[:n].double().sum().view(1).clone()
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    torch.distributed.all_gather(allc, chk)
+    same = all(bool(torch.equal(allc[0], c)) for c in allc)
+    q.put((rank, bool(same and rel < world * 2.0 ** -8 and norm_err < 2e-3), rel, norm_err))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bf16_wire_error_at_eight_ranks_gloo():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_wire8, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+    print("\n[bf16 wire, 8 ranks] max element error / sum|g_k|:", max(r[2] for r in res), " gradient-norm error:", max(r[3] for r in res))
+    assert all(r[1] for r in res), res
