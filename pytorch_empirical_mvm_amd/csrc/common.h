@@ -114,37 +114,34 @@ __device__ __forceinline__ float gelu_grad_f(float x);
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) { return f32x2{gelu_f(x[0]), gelu_f(x[1])}; }
 __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) { return f32x2{gelu_grad_f(x[0]), gelu_grad_f(x[1])}; }
 #else
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-  const f32x2 h = x * f32x2{0.5f, 0.5f};
-  return __builtin_elementwise_fma(h, erf_poly2(x * f32x2{0.70710678118654752f, 0.70710678118654752f}), h);
-}
+__device__ __forceinline__ f32x2 gelu_sigmoid2(f32x2 x, f32x2 t);
+__device__ __forceinline__ f32x2 gelu2(f32x2 x);
 // 8-bit code of GELU' (vmvm_gemm_desc.aux_code8): g in [-0.129, 1.129] -> round((g + 0.13) * 255 / 1.26), and back
 constexpr float GC8_LO = -0.13f, GC8_STEP = 1.26f / 255.0f, GC8_INV = 255.0f / 1.26f;
-// GELU and the (unrounded) code of GELU' together.  g = cdf + x * pdf with cdf = 0.5 + 0.5 * erf(z), z = x / sqrt(2), shares the erf
-// polynomial, its clamped argument zc and t = zc^2 with GELU; the affine map onto the code and the constants of the pdf are folded:
-//   code = erf * (INV / 2) + (INV / 2 - LO * INV) + zc * 2^(-t * log2(e) + log2(sqrt(2) * INV / sqrt(2 pi)))
-// (x * pdf(x) < 1e-3 beyond the clamp |z| = 3, so the clamped argument serves).  Cost over GELU alone: 3 packed FMAs + 2 v_exp_f32.
+// GELU and the (unrounded) code of GELU' together -- round 4: ONE shared exponential.  The normal cdf as a logistic of an odd cubic,
+//   Phi(x) ~ s = 1 / (1 + 2^(x (A2 + B2 x^2))),     A2 = -a log2 e, B2 = -b log2 e,  (a, b) = (1.59982729, 0.0699463)
+// (a minimax fit of GELU and GELU' against erf over |x| <= 8, tools/scratch/fit_gelu_logistic.py: max |GELU error| 3.3e-4 -- the erf
+// polynomial it replaces: 4.0e-4 --, max |GELU' error| 6.7e-4, an eighth of a code step; torch's tanh form is this family with other
+// constants).  Then GELU = x s and GELU' = s + x s (1 - s) u'(x) with u' = a + 3 b x^2, so the second transcendental pair of the
+// erf form (its pdf term) is gone: per pair of elements 9 packed instructions + 2 v_exp_f32 + 2 v_rcp_f32 against 19 + 2 before --
+// the GELU classes of the GEMM are bound by the ISSUE of their epilogue instructions, not by how they are arranged.
+// Saturation is benign: 2^(...) -> inf gives s = 0, y = 0, g = 0; -> 0 gives s = 1, y = x, g = 1 (no inf * 0 anywhere).
+constexpr float GL_A = 1.59982729f, GL_B = 0.0699463f;
+__device__ __forceinline__ f32x2 gelu_sigmoid2(f32x2 x, f32x2 t) {     // s = Phi(x), t = x * x
+  constexpr float A2 = -GL_A * 1.4426950408889634f, B2 = -GL_B * 1.4426950408889634f;
+  const f32x2 u = x * __builtin_elementwise_fma(t, f32x2{B2, B2}, f32x2{A2, A2});
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + f32x2{1.0f, 1.0f};
+  return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) { return x * gelu_sigmoid2(x, x * x); }
 __device__ __forceinline__ void gelu_and_code2(f32x2 x, f32x2& y, f32x2& cf) {
-  const f32x2 z = x * f32x2{0.70710678118654752f, 0.70710678118654752f};
-  const f32x2 zc = f32x2{__builtin_amdgcn_fmed3f(z[0], -3.0f, 3.0f), __builtin_amdgcn_fmed3f(z[1], -3.0f, 3.0f)};
-  const f32x2 t = zc * zc;
-  f32x2 p = f32x2{-4.0375596e-07f, -4.0375596e-07f};
-  p = __builtin_elementwise_fma(p, t, f32x2{1.7119051e-05f, 1.7119051e-05f});
-  p = __builtin_elementwise_fma(p, t, f32x2{-3.1437373e-04f, -3.1437373e-04f});
-  p = __builtin_elementwise_fma(p, t, f32x2{3.3201380e-03f, 3.3201380e-03f});
-  p = __builtin_elementwise_fma(p, t, f32x2{-2.2705898e-02f, -2.2705898e-02f});
-  p = __builtin_elementwise_fma(p, t, f32x2{1.0779675e-01f, 1.0779675e-01f});
-  p = __builtin_elementwise_fma(p, t, f32x2{-3.7335253e-01f, -3.7335253e-01f});
-  p = __builtin_elementwise_fma(p, t, f32x2{1.1279515e+00f, 1.1279515e+00f});
-  const f32x2 pz = p * zc;
-  const f32x2 e = f32x2{__builtin_amdgcn_fmed3f(pz[0], -1.0f, 1.0f), __builtin_amdgcn_fmed3f(pz[1], -1.0f, 1.0f)};
-  const f32x2 h = x * f32x2{0.5f, 0.5f};
-  y = __builtin_elementwise_fma(h, e, h);
-  constexpr float L2C = 6.83518164f;                    // log2(sqrt(2) * 0.39894228 * 255 / 1.26)
-  const f32x2 a = __builtin_elementwise_fma(t, f32x2{-1.44269504f, -1.44269504f}, f32x2{L2C, L2C});
-  const f32x2 ex = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-  constexpr float HI = 0.5f * GC8_INV, K0 = 0.5f * GC8_INV - GC8_LO * GC8_INV;
-  cf = __builtin_elementwise_fma(zc, ex, __builtin_elementwise_fma(e, f32x2{HI, HI}, f32x2{K0, K0}));
+  const f32x2 t = x * x;
+  const f32x2 s = gelu_sigmoid2(x, t);
+  y = x * s;
+  const f32x2 du = __builtin_elementwise_fma(t, f32x2{3.0f * GL_B, 3.0f * GL_B}, f32x2{GL_A, GL_A});
+  const f32x2 xw = __builtin_elementwise_fma(-y, s, y);               // x s (1 - s)
+  const f32x2 g = __builtin_elementwise_fma(xw, du, s);
+  cf = __builtin_elementwise_fma(g, f32x2{GC8_INV, GC8_INV}, f32x2{-GC8_LO * GC8_INV, -GC8_LO * GC8_INV});
 }
 __device__ __forceinline__ uint32_t gelu_code4(float c0, float c1, float c2, float c3) {      // round + saturate to bytes 0..3
   uint32_t w = 0;
@@ -167,8 +164,9 @@ __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
   return __builtin_elementwise_fma(x, pdf, cdf);
 }
 #endif
-__device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erf_poly(x * 0.70710678118654752f));
+__device__ __forceinline__ float gelu_f(float x) {          // the same logistic form as gelu2 (every GELU forward of the library agrees)
+  constexpr float A2 = -1.59982729f * 1.4426950408889634f, B2 = -0.0699463f * 1.4426950408889634f;
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * fmaf(x * x, B2, A2)));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);

@@ -245,9 +245,11 @@ def check_code8(variant, M, N, K_, tag):
     dcode = (code.float() - want).abs()
     print(f"     code8: max |code - round(g)| = {dcode.max().item():.0f}, off-by-one fraction {(dcode > 0).float().mean().item():.4f}, "
           f"code range {int(code.min())}..{int(code.max())}")
-    RESULTS.append((f"{tag} code8 codes within 1 of the f32 rounding", dcode.max().item(), 1, dcode.max().item() > 1 or (dcode > 0).float().mean().item() > 0.02))
+    # (round 4: GELU / GELU' share one exponential -- a logistic form within 6.7e-4 of the erf derivative, an eighth of a code step, so a
+    #  code sits one step off the rounding of the exact derivative for ~6 % of the elements; never more than one step)
+    RESULTS.append((f"{tag} code8 codes within 1 of the f32 rounding", dcode.max().item(), 1, dcode.max().item() > 1 or (dcode > 0).float().mean().item() > 0.10))
     dec = code.float() * (1.26 / 255.0) - 0.13
-    rep(f"{tag} code8 decode vs GELU'", dec, pf.grad, tol=0.0026 / 1.13)
+    rep(f"{tag} code8 decode vs GELU'", dec, pf.grad, tol=0.0033 / 1.13)
     rep(f"{tag} act3 code8", K.gemm(A, B, act=3, aux=code, code8=True, row_scale=rs8, rows_per_scale=196, variant=variant), base * dec * rs8[rows8, None])
     rep(f"{tag} act3 code8 vs exact GELU'", K.gemm(A, B, act=3, aux=code, code8=True, variant=variant), base * pf.grad, tol=1e-2)
 
@@ -263,6 +265,24 @@ def check_gemm_epilogues():
     rep("gemm gelu", out, torch.nn.functional.gelu(base + bias))
     rep("gemm gelu preact", pre, base + bias)
     rep("gemm relu", K.gemm(A, B, bias=bias, act=2), torch.relu(base + bias))
+    # the GELU form itself against torch.nn.functional.gelu (erf) in fp32: pre-activations on a grid over [-9, 9] through an identity
+    # weight (exact in bf16 up to the grid's rounding), so the only differences are the logistic approximation (<= 3.4e-4 absolute,
+    # csrc/common.h gelu_and_code2) and the bf16 rounding of the output (2^-9 relative); the 8-bit code against the erf derivative
+    xs = torch.linspace(-9, 9, 256 * 128, device=dev).to(BF).view(256, 128)
+    eye = torch.eye(128, device=dev, dtype=BF)
+    want = torch.nn.functional.gelu(xs.float())
+    for tagv, kw in (("", {}), (" (code8 build)", dict(out_preact=torch.empty(256, 128, device=dev, dtype=torch.uint8), code8=True))):
+        got = K.gemm(xs, eye, act=1, **kw).float()
+        err = ((got - want).abs() - want.abs() * 2.0 ** -8).clamp_min(0).max().item()
+        print(f"     gelu form{tagv}: max |error| beyond the bf16 rounding of the output = {err:.2e} (bound 3.5e-4)")
+        RESULTS.append((f"gemm gelu vs torch erf-GELU fp32{tagv}", err, 3.5e-4, err > 3.5e-4))
+        if kw:
+            xf = xs.float().requires_grad_(True)
+            torch.nn.functional.gelu(xf).sum().backward()
+            dec = kw["out_preact"].float() * (1.26 / 255.0) - 0.13
+            derr = (dec - xf.grad).abs().max().item()
+            print(f"     gelu' code: max |decode - erf derivative| = {derr:.2e} (half a code step 2.5e-3 + form 6.7e-4)")
+            RESULTS.append(("gemm gelu' code vs torch erf-GELU' fp32", derr, 3.3e-3, derr > 3.3e-3))
     u = rnd(M, N)
     uf = u.float().requires_grad_(True)
     torch.nn.functional.gelu(uf).sum().backward()
