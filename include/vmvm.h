@@ -222,8 +222,17 @@ typedef struct {
    * (query tile, key tile) pairs the shift mask (video_swin.py:292-307) zeroes are skipped.  `region` must be tile-uniform (checked on
    * the host side by the caller); kernels without a win_layout build ignore the flag (they are order-agnostic). */
   int32_t win_layout;
+  /* mode 1, dropout_p > 0, L = 432 (the fusion encoder's exact-tile kernels; no causal_from, att_colsum, streaming), NULL = off: the
+   * forward WRITES its keep / drop decisions here and the backward READS them instead of evaluating the Philox stream twice more.
+   * u32 [nseq * heads][27][27][8]: record (query tile qt, key tile t) = four 64-bit lane masks of the forward's compares -- bit
+   * 16 g + r of word j set = attention probability (query 16 qt + r, key 16 t + 4 g + j) is DROPPED.  The decisions are those of
+   * (seed, offset) either way, so a backward WITHOUT drop_mask after a forward with it (or the reverse) gives the same gradients.
+   * Any other problem with drop_mask set is refused (VMVM_ENOSUPPORT).  vmvm_attention_drop_mask_size() gives the bytes. */
+  uint32_t* drop_mask;
 } vmvm_attn_fwd_desc;
 int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream);
+/* bytes of drop_mask for this problem, 0 when the problem has no stored-decision build */
+int64_t vmvm_attention_drop_mask_size(const vmvm_attn_fwd_desc* d);
 
 typedef struct {
   vmvm_attn_fwd_desc f;        /* same problem description (out = forward output O, lse = saved) */

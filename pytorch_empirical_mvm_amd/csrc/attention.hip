@@ -162,8 +162,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto pairs = [&](auto drop_c) {
-        constexpr bool DROP = decltype(drop_c)::value;
+        constexpr int DROPM = decltype(drop_c)::value;       // 0 no dropout, 1 Philox decisions, 2 Philox decisions + stored for the backward (drop_mask)
+        constexpr bool DROP = DROPM != 0;
         uint4 own = make_uint4(0, 0, 0, 0);
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(DROPM == 2 ? const_cast<uint32_t*>(uniform_ptr(p.drop_mask + ((size_t)(seq * heads + h) * nt + qt) * nt * 8)) : (uint32_t*)nullptr, 0, NT_MAX * 32, 0x00020000);
 #pragma unroll
         for (int c = 0; c < NT_MAX / 2; ++c) {
           if (PAIR_ON(c)) {
@@ -180,8 +182,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
                 if ((t & 3) == 0)
                   own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
                 const uint32_t w = u4_static(own, t & 3);
+                bool dr[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[u][j] = (drop_field(w, j) < thr16) ? 0.f : e[u][j];
+                for (int j = 0; j < 4; ++j) { dr[j] = drop_field(w, j) < thr16; e[u][j] = dr[j] ? 0.f : e[u][j]; }
+                if (DROPM == 2) {                              // the four compares' lane masks ARE the tile's record: 8 dwords, lanes 0-7 store them
+                  const uint32_t rec = lane_masks_record(__builtin_amdgcn_ballot_w64(dr[0]), __builtin_amdgcn_ballot_w64(dr[1]), __builtin_amdgcn_ballot_w64(dr[2]),
+                                                         __builtin_amdgcn_ballot_w64(dr[3]));
+                  __builtin_amdgcn_raw_buffer_store_b32(rec, mrs, lane < 8 ? lane * 4 : 0x7fffffff, t * 32, 0);      // lanes 8-63 fall outside the record (bounds-checked away)
+                }
               }
             }
             const bf16x8 pf = frag_from_f32(e[0], e[1]);
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           }
         }
       };
-      if (has_drop) pairs(std::true_type{}); else pairs(std::false_type{});
+      if (has_drop) { if (p.drop_mask) pairs(std::integral_constant<int, 2>{}); else pairs(std::integral_constant<int, 1>{}); } else pairs(std::integral_constant<int, 0>{});
       float sum = sum2[0] + sum2[1];
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
@@ -290,7 +298,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 // ================================================================================================
 // backward A: dQ (+ delta, + relative-position-bias table gradient)
 // ================================================================================================
-template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false>
+// QT = query tiles a wave owns at a time (fusion build: 2 -- the K / V fragments, the transposed K fragments and the key mask a
+// wave reads from LDS per key tile then serve two score tiles: 7 -> 3.5 KB of LDS reads per score tile)
+template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false, int QT = 1>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bwd_desc pb, const int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -347,75 +357,99 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
   // the dropout tests are compile-time inside the tile loops (two copies of the loop, chosen once per sequence): as run-time tests they
   // were ~60 scalar branches per query tile, each one a scheduling boundary between the tiles' MFMA and VALU work
   auto qloop = [&](auto drop_c) {
-  constexpr bool DROP = decltype(drop_c)::value;
-  for (int qt = wave; qt < nt; qt += NW) {
-    const int q = qt * 16 + r;
-    const bool qv = q < L;
-    bf16x8 qf[HD / 32], dof[HD / 32];
-    float dl = 0.f;
+  constexpr int DROPM = decltype(drop_c)::value;          // 0 no dropout, 1 Philox decisions, 2 the forward's stored decisions (drop_mask; exact-tile fusion build)
+  constexpr bool DROP = DROPM == 1;
+  static_assert(DROPM != 2 || (QT == 1 && NXB > 0 && NXB * 8 <= 256 && FAST1), "stored-mask path: one query tile per wave, exact tile count");
+  for (int qt0 = wave * QT; qt0 < nt; qt0 += NW * QT) {
+    int q[QT]; bool qv[QT];
+    bf16x8 qf[QT][HD / 32], dof[QT][HD / 32];
+    float dl[QT], lse[QT], lse2[QT];
+    int rcq[QT], regq[QT];
+    f32x4 dq[QT][HD / 16];
+    uint4 own[QT];                                    // quad-shared dropout block (see quad_bcast)
 #pragma unroll
-    for (int s = 0; s < HD / 32; ++s) {
-      qf[s] = load_frag_global(qkv + (size_t)q * p.ld_qkv + p.q_off + h * HD + g * 8 + s * 32, qv);
-      dof[s] = load_frag_global(dO + (size_t)q * pb.ld_dout + g * 8 + s * 32, qv);
-      const bf16x8 of = load_frag_global(O + (size_t)q * p.ld_out + g * 8 + s * 32, qv);
+    for (int i = 0; i < QT; ++i) {
+      q[i] = (qt0 + i) * 16 + r;
+      qv[i] = q[i] < L;
+      dl[i] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dl += (float)dof[s][e] * (float)of[e];
+      for (int s = 0; s < HD / 32; ++s) {
+        qf[i][s] = load_frag_global(qkv + (size_t)q[i] * p.ld_qkv + p.q_off + h * HD + g * 8 + s * 32, qv[i]);
+        dof[i][s] = load_frag_global(dO + (size_t)q[i] * pb.ld_dout + g * 8 + s * 32, qv[i]);
+        const bf16x8 of = load_frag_global(O + (size_t)q[i] * p.ld_out + g * 8 + s * 32, qv[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl[i] += (float)dof[i][s][e] * (float)of[e];
+      }
+      dl[i] += __shfl_xor(dl[i], 16, 64);
+      dl[i] += __shfl_xor(dl[i], 32, 64);             // delta_q = sum_d dO'[q,d] * out'[q,d]
+      if (g == 0 && qv[i]) delta_g[q[i]] = dl[i];
+      lse[i] = qv[i] ? lse_g[q[i]] : 0.f;
+      lse2[i] = qv[i] ? lse[i] * 1.4426950408889634f : __builtin_huge_valf();
+      rcq[i] = (MODE == 0) ? rc[qv[i] ? q[i] : 0] : 0;
+      regq[i] = (MODE == 0) ? reg[qv[i] ? q[i] : 0] : 0;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) dq[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      own[i] = make_uint4(0, 0, 0, 0);
     }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);             // delta_q = sum_d dO'[q,d] * out'[q,d]
-    if (g == 0 && qv) delta_g[q] = dl;
-    const float lse = qv ? lse_g[q] : 0.f;
-    const float lse2 = qv ? lse * 1.4426950408889634f : __builtin_huge_valf();
-    const int rcq = (MODE == 0) ? rc[qv ? q : 0] : 0;
-    const int regq = (MODE == 0) ? reg[qv ? q : 0] : 0;
 
-    f32x4 dq[HD / 16];
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};                  // stored decisions of this query tile's row of tiles: nt x 8 dwords, dword i in lane i & 63 of mw[i >> 6]
+    if (DROPM == 2) {
+      const uint32_t* mrow = p.drop_mask + ((size_t)(seq * heads + h) * nt + qt0) * nt * 8;
 #pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint4 own = make_uint4(0, 0, 0, 0);               // quad-shared dropout block (see quad_bcast)
+      for (int i = 0; i < 4; ++i) mw[i] = (i * 64 + lane < NXB * 8) ? mrow[i * 64 + lane] : 0u;
+    }
     // score / dP MFMAs of one pair of key tiles
-    auto score_pair = [&](int c, f32x4 (&so)[2], f32x4 (&dpo)[2]) {
+    auto score_pair = [&](int c, f32x4 (&so)[2][QT], f32x4 (&dpo)[2][QT]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * c + u;
-        so[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dpo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < QT; ++i) { so[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dpo[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (NXB ? (t < NXB) : (t < nt)) {
           const int row = t * 16 + r;
 #pragma unroll
           for (int s = 0; s < HD / 32; ++s) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksm + k_off_swz<HD>(row, s * 4 + g));
-            so[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], so[u], 0, 0, 0);
             const bf16x8 vf = frag_hd<HD>(Vsm, row, s * 4 + g);
-            dpo[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dpo[u], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+              so[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][s], so[u][i], 0, 0, 0);
+              dpo[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[i][s], dpo[u][i], 0, 0, 0);
+            }
           }
         }
       }
     };
     // exact-tile fusion build: software-pipelined by one pair -- the score MFMAs of pair c + 1 are issued in front of the softmax-side
     // VALU work of pair c (they only depend on LDS reads), so their latency sits under it instead of in front of the next pair
-    constexpr bool PIPE = FAST1 && NXB > 0;
-    f32x4 s4c[2], dpc[2];
+    constexpr bool PIPE = FAST1 && NXB > 0 && QT == 1;
+    f32x4 s4c[2][QT], dpc[2][QT];
     if (PIPE) score_pair(0, s4c, dpc);
     // NXB > 0: exact tile count -> fully unrolled, immediate LDS offsets, no per-tile guards
 #pragma unroll
     for (int c = 0; c < (NXB ? (NXB + 1) / 2 : nt2); ++c) {
-      f32x4 s4n[2], dpn[2];
+      f32x4 s4n[2][QT], dpn[2][QT];
       if (PIPE) { if (c + 1 < (NXB + 1) / 2) score_pair(c + 1, s4n, dpn); }
       else score_pair(c, s4c, dpc);
-      float ds[2][4];
+      float ds[QT][2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * c + u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ds[u][j] = 0.f;
+        for (int i = 0; i < QT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ds[i][u][j] = 0.f;
         if (NXB ? (t < NXB) : (t < nt)) {
-          const f32x4 s4 = s4c[u], dp4 = dpc[u];
           const int key0 = t * 16 + g * 4;
+          float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (FAST1) k4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rc) + key0);
+#pragma unroll
+          for (int i = 0; i < QT; ++i) {
+          const f32x4 s4 = s4c[u][i], dp4 = dpc[u][i];
           uint32_t w = 0;
           if (DROP) {
-            if ((t & 3) == 0) own = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
-            w = u4_static(own, t & 3);
+            if ((t & 3) == 0) own[i] = quad_transpose(drop_block(p.seed, p.offset, (uint32_t)(seq * heads + h), (uint32_t)(q[i] >> 2), (uint32_t)((t + (lane & 3)) * 4 + g)), lane & 1, lane & 2);
+            w = u4_static(own[i], t & 3);
           }
           if (MODE == 0) {
             const int4 rk = *reinterpret_cast<const int4*>(rc + key0);
@@ -424,18 +458,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
             const int gks[4] = {gk.x, gk.y, gk.z, gk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int bi = rcq - rks[j] + p.rc0;
-              const float s = s4[j] + tab[bi] + (regq != gks[j] ? -100.f : 0.f);
-              const float pr = (key0 + j < L && qv) ? __expf(s - lse) : 0.f;
-              const float d = pr * (dp4[j] * seq_scale - dl);
-              ds[u][j] = d;
-              if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], d);
+              const int bi = rcq[i] - rks[j] + p.rc0;
+              const float sv = s4[j] + tab[bi] + (regq[i] != gks[j] ? -100.f : 0.f);
+              const float pr = (key0 + j < L && qv[i]) ? __expf(sv - lse[i]) : 0.f;
+              const float dd = pr * (dp4[j] * seq_scale - dl[i]);
+              ds[i][u][j] = dd;
+              if (want_dtab && pr != 0.f) atomicAdd(&dtab[bi], dd);
             }
           } else if (FAST1) {
             // log2 domain, two elements per instruction: P = exp2(fma(S, scale*log2e, kbias[key]) - lse*log2e) (lse2 = +inf on padded
             // rows), dS = P * (keep-scaled dP under the dropout mask - delta)
-            const float4 k4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rc) + key0);
-            const f32x2 nl = f32x2{-lse2, -lse2}, ndl = f32x2{-dl, -dl}, c2 = f32x2{cdk, cdk};
+            const f32x2 nl = f32x2{-lse2[i], -lse2[i]}, ndl = f32x2{-dl[i], -dl[i]}, c2 = f32x2{cdk, cdk};
             const f32x2 x01 = __builtin_elementwise_fma(f32x2{s4[0], s4[1]}, f32x2{sc2, sc2}, f32x2{k4.x, k4.y}) + nl;
             const f32x2 x23 = __builtin_elementwise_fma(f32x2{s4[2], s4[3]}, f32x2{sc2, sc2}, f32x2{k4.z, k4.w}) + nl;
             const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
@@ -445,42 +478,65 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const vmvm_attn_bw
 #pragma unroll
               for (int j = 0; j < 4; ++j) dp[j] = (drop_field(w, j) < thr16) ? 0.f : dp[j];
             }
+            if (DROPM == 2) {                              // element j's lane mask back into a scalar pair, applied by one v_cndmask each
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int d0 = t * 8 + 2 * j;
+                const uint32_t lo = __builtin_amdgcn_readlane(mw[d0 >> 6], d0 & 63), hi = __builtin_amdgcn_readlane(mw[(d0 + 1) >> 6], (d0 + 1) & 63);
+                dp[j] = zero_where(dp[j], ((uint64_t)hi << 32) | lo);
+              }
+            }
             const f32x2 o01 = f32x2{pr[0], pr[1]} * (f32x2{dp[0], dp[1]} + ndl), o23 = f32x2{pr[2], pr[3]} * (f32x2{dp[2], dp[3]} + ndl);
-            ds[u][0] = o01[0]; ds[u][1] = o01[1]; ds[u][2] = o23[0]; ds[u][3] = o23[1];
+            ds[i][u][0] = o01[0]; ds[i][u][1] = o01[1]; ds[i][u][2] = o23[0]; ds[i][u][3] = o23[1];
           } else {
             const uchar4 mk = *reinterpret_cast<const uchar4*>(reg + key0);
             const int mks[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               bool ok = mks[j] != 0;
-              if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q >= p.causal_from && key0 + j <= q && key0 + j < L);
-              const float pr = (ok && qv) ? __expf(s4[j] * p.scale - lse) : 0.f;
+              if (CAUSAL) ok = (key0 + j < p.causal_from) ? ok : (q[i] >= p.causal_from && key0 + j <= q[i] && key0 + j < L);
+              const float pr = (ok && qv[i]) ? __expf(s4[j] * p.scale - lse[i]) : 0.f;
               float dpj = dp4[j] * seq_scale;
               if (DROP) dpj = (drop_field(w, j) < thr16) ? 0.f : dpj * keep;
-              ds[u][j] = pr * (dpj - dl);
+              ds[i][u][j] = pr * (dpj - dl[i]);
             }
+          }
           }
         }
       }
-      const bf16x8 dsf = frag_from_f32(ds[0], ds[1]);
+      bf16x8 dsf[QT];
+#pragma unroll
+      for (int i = 0; i < QT; ++i) dsf[i] = frag_from_f32(ds[i][0], ds[i][1]);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         const bf16x8 kf = frag_tokens<HD>(Ksm, dt, c * 32 + g * 4, c * 32 + 16 + g * 4, r);
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) dq[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[i], dq[i][dt], 0, 0, 0);
       }
-      if (PIPE) { s4c[0] = s4n[0]; s4c[1] = s4n[1]; dpc[0] = dpn[0]; dpc[1] = dpn[1]; }
+      if (PIPE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < QT; ++i) { s4c[u][i] = s4n[u][i]; dpc[u][i] = dpn[u][i]; }
+      }
       if (NXB) __builtin_amdgcn_sched_barrier(0);       // exact-tile build: straight-line code -- keep the scheduler from hoisting all pairs' LDS reads / Philox blocks (spills)
     }
-    if (qv) {
-      u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + q) * pb.ld_dqkv + p.q_off + h * HD + g * 4;
-      const float sc = p.scale;
 #pragma unroll
-      for (int dt = 0; dt < HD / 16; ++dt)
-        *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[dt][0] * sc, dq[dt][1] * sc), pack_bf2(dq[dt][2] * sc, dq[dt][3] * sc));
+    for (int i = 0; i < QT; ++i) {
+      if (qv[i]) {
+        u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + ((size_t)seq * L + q[i]) * pb.ld_dqkv + p.q_off + h * HD + g * 4;
+        const float sc = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt)
+          *reinterpret_cast<uint2*>(dqp + dt * 16) = make_uint2(pack_bf2(dq[i][dt][0] * sc, dq[i][dt][1] * sc), pack_bf2(dq[i][dt][2] * sc, dq[i][dt][3] * sc));
+      }
     }
   }
   };
-  if (has_drop) qloop(std::true_type{}); else qloop(std::false_type{});
+  if (has_drop) {
+    if constexpr (QT == 1 && NXB > 0 && FAST1) { if (p.drop_mask) qloop(std::integral_constant<int, 2>{}); else qloop(std::integral_constant<int, 1>{}); }
+    else qloop(std::integral_constant<int, 1>{});
+  } else qloop(std::integral_constant<int, 0>{});
   }   // sequences
   if (MODE == 0 && want_dtab) {
     __syncthreads();
@@ -1121,7 +1177,7 @@ __global__ __launch_bounds__(NQ * NS * 64) void attn_bwd_dq_win2_kernel(const vm
 // ================================================================================================
 // backward B: dK, dV (per key tile; probabilities recomputed from lse; delta from kernel A)
 // ================================================================================================
-template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false>
+template <int HD, int MODE, int NW, int NXB, bool CAUSAL = false, int KTP = 0, bool PIPEP = true>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const vmvm_attn_fwd_desc& p = pb.f;
@@ -1170,9 +1226,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
 
   // each wave owns TWO key tiles at a time: the Q / dO fragments (k = hd) and the transposed Q^T / dO^T fragments
   // (k = tokens) are read from LDS once and feed both tiles -> half the LDS traffic per MFMA.
-  constexpr int KT = (HD == 32) ? 2 : 1;
+  constexpr int KT = KTP ? KTP : (HD == 32) ? 2 : 1;
   auto kloop = [&](auto drop_c) {                       // (compile-time dropout tests, as in attn_bwd_dq_kernel)
-  constexpr bool DROP = decltype(drop_c)::value;
+  constexpr int DROPM = decltype(drop_c)::value;          // 0 no dropout, 1 Philox decisions, 2 the forward's stored decisions (drop_mask; exact-tile fusion build)
+  constexpr bool DROP = DROPM == 1;
+  static_assert(DROPM != 2 || (KT == 1 && NXB > 0 && FAST1), "stored-mask path: one key tile per wave, exact tile count");
   for (int kp = wave; kp * KT < nt; kp += NW) {
     int key[KT]; bool kv[KT];
     bf16x8 kf[KT][HD / 32], vf[KT][HD / 32];
@@ -1196,6 +1254,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
     uint4 own[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) own[t] = make_uint4(0, 0, 0, 0);
+    // stored decisions: record (query tile qt, this key tile) holds element (query 16 qt + r', key 16 kt + 4 g' + j') as bit 16 g' + r' of
+    // word j'; this lane (key r, queries 4g..4g+3) needs word r & 3, bits 16 (r >> 2) + 4 g + j: one dword per query tile, all NXB loaded up front
+    uint32_t wm[NXB ? NXB : 1];
+    const int mshift = 16 * ((r >> 2) & 1) + 4 * g;
+    if (DROPM == 2) {
+      const uint32_t* mcol = p.drop_mask + ((size_t)(seq * heads + h) * nt * nt + kp) * 8 + 2 * (r & 3) + (r >> 3);
+#pragma unroll
+      for (int qt = 0; qt < NXB; ++qt) wm[qt] = mcol[(size_t)qt * nt * 8];
+    }
     // score / dP MFMAs of one pair of query tiles (software-pipelined by one pair in the exact-tile fusion build, as in the dQ kernel)
     auto score_pair = [&](int c, f32x4 (&so)[2][KT], f32x4 (&dpo)[2][KT]) {
 #pragma unroll
@@ -1218,7 +1285,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
         }
       }
     };
-    constexpr bool PIPE = FAST1 && NXB > 0;
+    constexpr bool PIPE = FAST1 && NXB > 0 && PIPEP;
     f32x4 s4c[2][KT], dpc[2][KT];
     if (PIPE) score_pair(0, s4c, dpc);
 #pragma unroll
@@ -1285,6 +1352,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
                     pj[j] = dropped ? 0.f : pj[j];
                   }
                 }
+                if (DROPM == 2) {
+                  const uint32_t kept = ~(wm[NXB ? qt : 0] >> mshift);                     // bit j: element j is kept
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) pj[j] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pj[j]) & (uint32_t)__builtin_amdgcn_sbfe((int)kept, j, 1));
+                }
                 const f32x2 o01 = __builtin_elementwise_fma(f32x2{pj[0], pj[1]}, d01, -(f32x2{pr[0], pr[1]} * f32x2{dls[0], dls[1]}));
                 const f32x2 o23 = __builtin_elementwise_fma(f32x2{pj[2], pj[3]}, d23, -(f32x2{pr[2], pr[3]} * f32x2{dls[2], dls[3]}));
                 pt[t][u][0] = pj[0]; pt[t][u][1] = pj[1]; pt[t][u][2] = pj[2]; pt[t][u][3] = pj[3];
@@ -1349,7 +1421,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const vmvm_attn_b
     }
   }
   };
-  if (has_drop) kloop(std::true_type{}); else kloop(std::false_type{});
+  if (has_drop) {
+    if constexpr (KT == 1 && NXB > 0 && FAST1) { if (p.drop_mask) kloop(std::integral_constant<int, 2>{}); else kloop(std::integral_constant<int, 1>{}); }
+    else kloop(std::integral_constant<int, 1>{});
+  } else kloop(std::integral_constant<int, 0>{});
 }
 
 
@@ -2254,6 +2329,10 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
 }
 
 inline bool use_stream(const vmvm_attn_fwd_desc* d) { return d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len); }
+// stored dropout decisions (vmvm_attn_fwd_desc.drop_mask): the exact-tile fusion kernels only
+inline bool drop_mask_ok(const vmvm_attn_fwd_desc* d) {
+  return d->mode == 1 && d->head_dim == 64 && d->dropout_p > 0.f && d->causal_from <= 0 && !d->att_colsum && !use_stream(d) && (d->L + 15) / 16 == 27;
+}
 
 }  // namespace
 
@@ -2262,6 +2341,7 @@ namespace vmvm_w3 {
 bool applicable(const vmvm_attn_fwd_desc* d);
 int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st);
+int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w3
 
 #define LAUNCH_FWD(HD, MODE, NTM, NW, NX, MASK)                                              \
@@ -2275,6 +2355,7 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->drop_mask && !drop_mask_ok(d)) return VMVM_ENOSUPPORT;
   if (use_stream(d)) {                               // streaming kernels: K / V chunks of 128 tokens, 8 query tiles per workgroup
     constexpr int NWS = 8, KCS = 128;
     const SmemS ss = smem_stream(d->L, d->head_dim, d->mode, d->table_len, 0, KCS);
@@ -2300,7 +2381,10 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     const int npk = (sm.nt + 1) / 2, tl4 = (d->table_len + 3) & ~3, lr4 = (d->L + 3) & ~3;
     const int smem2 = 4 * npk * 32 * 64 + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->nseq % nwin == 0) && (sm.nt == 25 || sm.nt == 13) && d->dropout_p == 0.f && smem2 <= 160 * 1024;
-    if (pers_ok) {
+    if (vmvm_w3::applicable(d) && !d->att_colsum && !getenv("VMVM_NO_WIN3") && !getenv("VMVM_NO_WIN3_FWD")) {
+      int rc_ = vmvm_w3::launch_fwd(d, st);
+      if (rc_) return rc_;
+    } else if (pers_ok) {
       const int nqg = (sm.nt + 6) / 7;
       const int base = d->heads * nqg;
       int nch = 1; float best = 1e30f;
@@ -2335,7 +2419,7 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
       hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 28, 8, 0, true, true>), dim3(nb), dim3(8 * 64), sm.total, st, *d);
     }
     else if (sm.nt <= 16) LAUNCH_FWD(64, 1, 16, 4, 0, true);
-    else if (sm.nt == 27) LAUNCH_FWD(64, 1, 28, 8, 27, true);       // L = 432 (fusion encoder): exact tile count, no per-tile guards
+    else if (sm.nt == 27) LAUNCH_FWD(64, 1, 28, 8, 27, true);       // L = 432 (fusion encoder): exact tile count, no per-tile guards       // L = 432 (fusion encoder): exact tile count, no per-tile guards
     else LAUNCH_FWD(64, 1, 28, 8, 0, true);
   }
   VMVM_CHECK_LAUNCH();
@@ -2364,6 +2448,7 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   int rc = check_desc(&d->f);
   if (rc) return rc;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
+  if (d->f.drop_mask && !drop_mask_ok(&d->f)) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (use_stream(&d->f)) {                           // streaming kernels (see vmvm_attention_fwd)
     constexpr int NWS = 8, KCS = 128;
@@ -2516,6 +2601,9 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, 8, 0, true>), dim3(nb), dim3(8 * 64), s2_.total, st, *d);
       VMVM_CHECK_LAUNCH();
     } else if (sb_.nt == 27) {        // L = 432 (fusion encoder): exact tile count, fully unrolled tile loops
+      // Measured and not kept (round 4, profiles/r04_ab_fusion_attention_variants.txt): two key tiles per wave in dK/dV (KTP = 2), two query
+      // tiles per wave in dQ (QT = 2) -- half the LDS bytes per score tile, same time: these kernels are not LDS-bound --, and 9 waves
+      // (3 full passes over the 27 owner tiles instead of 3 + a 3-wave pass): slower, the 8-wave form already loads the SIMDs 7/7/7/6.
       LAUNCH_BWD_DQ(64, 1, 8, 27);
       LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2, 27);
     } else {
@@ -2524,6 +2612,11 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     }
   }
   return VMVM_OK;
+}
+
+extern "C" int64_t vmvm_attention_drop_mask_size(const vmvm_attn_fwd_desc* d) {
+  if (!d || !drop_mask_ok(d)) return 0;
+  return (int64_t)d->nseq * d->heads * 27 * 27 * 8 * 4;
 }
 
 // `delta` scratch of the backward (f32 [nseq][heads][L])

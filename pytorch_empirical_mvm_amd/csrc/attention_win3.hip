@@ -683,6 +683,209 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
   }
 }
 
+// ================================================================================================
+// forward.  The batch-persistent structure of attn_fwd_win2_kernel (attention.hip: a workgroup = (head, group of 7 query tiles, chunk
+// of clips), a wave = one query tile with the whole 16 x L score block in accumulators, exact two-pass softmax, the bias block of the
+// wave as packed-bf16 registers entering through the score MFMA's C operand, K / V of the next sequence streamed into the other LDS
+// buffer) on the region-major layout: the bias block no longer carries the shift mask, so it is built ONCE per workgroup instead of
+// once per window position, and the score / exp2 / P V work of the key tiles a window type masks for the wave's query class is absent
+// (the tile loops exist once per live-class set, chosen per window position).
+// ================================================================================================
+template <bool MASK>
+__global__ __launch_bounds__(448) void attn_fwd_win3_kernel(const vmvm_attn_fwd_desc p, const int nqg, const int nch) {
+  constexpr int HD = 32, NWV = 7, NX = w3::NT, NPK = (NX + 1) / 2;
+  constexpr int LP32 = NPK * 32, KV = LP32 * HD * 2;                    // 416 rows per image: the last tile PAIR reaches past the window
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const s16x4_ ident = bias_ident_frag(lane);
+  const int L = w3::L, heads = p.heads, nWin = p.n_win, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nqg);
+  const int qg = logical % nqg;
+  const int t1 = logical / nqg;
+  const int ch = t1 % nch;
+  const int h = t1 / nch;
+  float* tabs = reinterpret_cast<float*>(smem + 4 * KV);                // this head's bias-table column
+  int* rcs = reinterpret_cast<int*>(tabs + 15 * 169 + 1);
+  const int qt = qg * NWV + wave;
+  const int q = qt * 16 + r;
+  const bool active = qt < NX;
+  const bool qv = active && (q < L);
+  const int qc = qt < w3::CB[1] ? 0 : qt < w3::CB[2] ? 1 : qt < w3::CB[3] ? 2 : 3;
+
+  for (int i = tid; i < 15 * 169; i += NWV * 64) tabs[i] = p.bias_table[(size_t)i * heads + h];
+  for (int i = tid; i < NX * 16; i += NWV * 64) rcs[i] = i < L ? p.rc[i] : 0;
+  __syncthreads();
+  uint32_t bm[NX * 2];                                    // bias of this wave's score block, packed bf16 (padding keys: PAD_BIAS)
+  {
+    const int rcq = rcs[qv ? q : 0] + p.rc0;
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      const int key0 = t * 16 + g * 4;
+      const int4 rk = *reinterpret_cast<const int4*>(rcs + key0);
+      const int rks[4] = {rk.x, rk.y, rk.z, rk.w};
+      float b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = (t < NX - 1 || key0 + j < L) ? tabs[rcq - rks[j]] : PAD_BIAS;
+      bm[2 * t] = pack_bf2(b4[0], b4[1]);
+      bm[2 * t + 1] = pack_bf2(b4[2], b4[3]);
+      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);                // straight-line code: keep the tiles' reads from piling up (registers)
+    }
+  }
+
+  // this workgroup's sequences: the clips [c0, c1) of every window position, window-major
+  const int cper = (B + nch - 1) / nch;
+  const int c0 = ch * cper, c1 = (c0 + cper < B) ? c0 + cper : B;
+  const int ncl = c1 > c0 ? c1 - c0 : 0, total = ncl * nWin;
+  int w_nx = 0, c_nx = c0;
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == c1) { c_nx = c0; ++w_nx; } };
+  const uint32_t off_q = (uint32_t)q * p.ld_qkv + p.q_off + h * HD + g * 8;
+  const uint32_t off_o = (uint32_t)q * p.ld_out + h * HD + g * 4;
+  const uint32_t off_ls = (uint32_t)h * L + q;
+  constexpr int NF = (LP32 * 4 + NWV * 64 - 1) / (NWV * 64);            // 16-byte DMA requests per thread per image (4)
+  static_assert(NF <= 5, "the fill requests are spread over the live key tiles (the smallest live set is class D: 5 tiles)");
+  uint32_t goff[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int u = i * NWV * 64 + tid, row = u >> 2, chs = u & 3;
+    goff[i] = (u < LP32 * 4) ? (uint32_t)((row * p.ld_qkv + ((chs ^ swz_chunk<32>(row)) << 3)) * 2) : 0xffffffffu;
+  }
+  const unsigned fill_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2);
+  bf16x8 qf;
+  float ss_n = 1.0f;
+  auto fetch = [&](size_t seq) {
+    qf = load_frag_global(reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + off_q, qv);
+    ss_n = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  };
+  if (total > 0) {
+    const u16* kv0 = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    fill_pre<NF, NWV * 64 * 16>(smem + (tid & ~63) * 16, KV, kv0 + p.k_off, kv0 + p.v_off, fill_bytes, goff);
+    fetch(seq_nx());
+    advance();
+  }
+
+  int wprev = -1, w_cu = 0, c_cu = c0, m4 = 15;
+  for (int b = 0; b < total; ++b) {
+    const int cur = b & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    fill_wait();
+    __syncthreads();                                      // sequence b landed for everyone; everyone left the other buffer
+    const int wcur = w_cu;
+    if (++c_cu == c1) { c_cu = c0; ++w_cu; }
+    if (MASK && wcur != wprev) {
+      wprev = wcur;
+      m4 = w3_live_rt(qc, __builtin_amdgcn_readfirstlane(w3_window_type(p.region, wcur)));
+    }
+    const bf16x8 cqf = qf;
+    const float seq_scale = ss_n;
+    const bool has_next = b + 1 < total;
+    const u16* kv_nx = reinterpret_cast<const u16*>(p.qkv) + seq_nx() * L * p.ld_qkv + h * HD;
+    unsigned char* dst_nx = smem + (cur ^ 1) * 2 * KV + (tid & ~63) * 16;
+    if (has_next) {
+      fetch(seq_nx());
+      advance();
+      if (!active) fill_pre<NF, NWV * 64 * 16>(dst_nx, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff);
+    }
+    if (!active) continue;
+    const unsigned char* Ksm = smem + cur * 2 * KV;
+    const unsigned char* kb = Ksm + k_off_swz<HD>(r, g);
+    const unsigned char* tv0 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8;
+    const unsigned char* tv1 = Ksm + KV + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+    const uint32_t tv0a = lds_addr(tv0), tv1a = lds_addr(tv1);
+    const __amdgpu_buffer_rsrc_t rk_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(kv_nx + p.k_off)), 0, __builtin_amdgcn_readfirstlane((int)fill_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(kv_nx + p.v_off)), 0, __builtin_amdgcn_readfirstlane((int)fill_bytes), 0x00020000);
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float mx = NEG_INF, sum = 1.f;
+
+    auto walk = [&](auto mc) {
+      constexpr int M4 = decltype(mc)::value;
+      constexpr w3::TileList LST = w3::list_all(M4);
+      constexpr int NL = LST.n;
+      f32x4 acc[NX];
+      // pass 0: the bias blocks of the live tiles through the matrix core (independent products, NL - 1 >= 4 of them between any block
+      // and the score MFMA that accumulates onto it -- see the hazard note at bias_block_mfma)
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[LST.t[i]] = bias_block_mfma(ident, bm[2 * LST.t[i]], bm[2 * LST.t[i] + 1], f32x4{0.f, 0.f, 0.f, 0.f});
+      __builtin_amdgcn_sched_barrier(0);
+      // pass 1: scores for the live part of the row block
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int t = LST.t[i];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 1024), cqf, acc[t], 0, 0, 0);
+        if (i < NF && has_next) fill_one_r(dst_nx + i * NWV * 64 * 16, KV, rk_nx, rv_nx, goff[i], i == NF - 1);
+      }
+      // (inline-asm maxima: hipcc inserts no MFMA-result wait states in front of inline asm -- the barrier keeps them BEHIND all score
+      // MFMAs, see attn_fwd_win2_kernel)
+      __builtin_amdgcn_sched_barrier(0);
+      float mx1 = NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { const int t = LST.t[i]; mx = max3_f32(mx, acc[t][0], acc[t][1]); mx1 = max3_f32(mx1, acc[t][2], acc[t][3]); }
+      __builtin_amdgcn_sched_barrier(0);
+      mx = fmaxf(mx, mx1);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      f32x2 nm2 = {-mx * LOG2E, -mx * LOG2E};
+      asm volatile("" : "+v"(nm2));                         // real register pair
+      // pass 2: p = exp2((s - max) * log2 e); P V and the row sums (all-ones A operand) through the matrix core, per live tile pair
+      typedef __attribute__((ext_vector_type(8))) short s16x8o;
+      const bf16x8 ones8 = __builtin_bit_cast(bf16x8, s16x8o{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+      f32x4 osum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NL; i += 2) {                      // classes start on even tiles: list entries (i, i + 1) are a tile pair of the image
+        const int c = LST.t[i] >> 1;
+        s16x4 a0, a1, c0_, c1_;
+        tr_read4(a0, a1, c0_, c1_, tv0a, tv1a, c * 2048);
+        uint32_t pw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * c + u;
+          if (t < NX) {
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+              const f32x2 e = __builtin_elementwise_fma(f32x2{acc[t][2 * hj], acc[t][2 * hj + 1]}, f32x2{LOG2E, LOG2E}, nm2);
+              const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+              pw[2 * u + hj] = pack_bf2v(pr);
+            }
+          }
+        }
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+        tr_wait4(a0, a1, c0_, c1_);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const s16x8 v1 = {c0_[0], c0_[1], c0_[2], c0_[3], c1_[0], c1_[1], c1_[2], c1_[3]};
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), pf, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), pf, o[1], 0, 0, 0);
+        osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf, osum, 0, 0, 0);
+      }
+      sum = osum[0];
+    };
+    if (MASK) {
+      switch (m4) {
+        case 15: walk(IC<15>{}); break;
+        case 3: walk(IC<3>{}); break;
+        case 12: walk(IC<12>{}); break;
+        case 5: walk(IC<5>{}); break;
+        case 10: walk(IC<10>{}); break;
+        case 1: walk(IC<1>{}); break;
+        case 2: walk(IC<2>{}); break;
+        case 4: walk(IC<4>{}); break;
+        default: walk(IC<8>{}); break;
+      }
+    } else {
+      walk(IC<15>{});
+    }
+    if (qv) {
+      const float inv = seq_scale / sum;
+      u16* op = reinterpret_cast<u16*>(p.out) + seq * L * p.ld_out + off_o;
+      *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf2(o[0][0] * inv, o[0][1] * inv), pack_bf2(o[0][2] * inv, o[0][3] * inv));
+      *reinterpret_cast<uint2*>(op + 16) = make_uint2(pack_bf2(o[1][0] * inv, o[1][1] * inv), pack_bf2(o[1][2] * inv, o[1][3] * inv));
+      if (g == 0) (p.lse + seq * heads * L)[off_ls] = mx + __builtin_amdgcn_logf(sum) * LN2;
+    }
+  }
+}
+
 template <typename K>
 int w3_set_smem(K kernel, int bytes) {
   if (bytes > 160 * 1024) return VMVM_ENOSUPPORT;
@@ -712,6 +915,25 @@ __attribute__((visibility("hidden"))) bool applicable(const vmvm_attn_fwd_desc* 
   const int nwin = d->n_win > 0 ? d->n_win : 1;
   return d->win_layout == 1 && d->mode == 0 && d->L == w3::L && d->head_dim == 32 && d->table_len == 15 * 169 && d->rc0 == 7 * 169 + 6 * 13 + 6 &&
          d->dropout_p == 0.f && d->nseq % nwin == 0;
+}
+
+__attribute__((visibility("hidden"))) int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st) {
+  constexpr int KV = 416 * 64;
+  const int smem = 4 * KV + (15 * 169 + 1) * 4 + 400 * 4;
+  const int nqg = 4, base = d->heads * nqg;
+  const int nwin = d->n_win > 0 ? d->n_win : 1;
+  const int nch = w3_chunks(base, d->nseq / nwin, nwin, 3.f);
+  if (d->region) {
+    int rc_ = w3_set_smem(attn_fwd_win3_kernel<true>, smem);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_fwd_win3_kernel<true>), dim3(base * nch), dim3(448), smem, st, *d, nqg, nch);
+  } else {
+    int rc_ = w3_set_smem(attn_fwd_win3_kernel<false>, smem);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_fwd_win3_kernel<false>), dim3(base * nch), dim3(448), smem, st, *d, nqg, nch);
+  }
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
 }
 
 __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st) {

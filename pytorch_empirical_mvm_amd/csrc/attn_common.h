@@ -228,6 +228,25 @@ __device__ __forceinline__ uint4 drop_block(uint64_t seed, uint64_t offset, uint
   const uint64_t c = offset + (((uint64_t)sh << 32) | ((uint64_t)qb << 12) | kb);
   return philox4x32_7(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0xa77eu, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
 }
+// a where the lane's bit of the (wave-uniform) mask m is clear, 0 where it is set: v_cndmask_b32 with the mask as a scalar pair
+__device__ __forceinline__ float zero_where(float a, uint64_t m) {
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(m));
+  return d;
+}
+// lanes 0-7 of the result := the four 64-bit lane masks m0..m3 as eight dwords (m0 low, m0 high, m1 low, ...), other lanes 0.
+// HAZARD (measured, tools/probe/writelane_probe.hip): v_writelane_b32 reading an SGPR that the VALU instruction in front of it wrote (a
+// v_cmp into an SGPR pair or VCC) gets the register's PREVIOUS value; hipcc inserts the wait states for its own v_writelane but not in
+// front of inline asm.  One s_nop 4 in front of the eight writes covers every mask (they are all inputs of the block).
+__device__ __forceinline__ uint32_t lane_masks_record(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+  uint32_t v = 0;
+  asm("s_nop 4\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+      "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+      : "+v"(v)
+      : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)), "s"((uint32_t)m2), "s"((uint32_t)(m2 >> 32)),
+        "s"((uint32_t)m3), "s"((uint32_t)(m3 >> 32)));
+  return v;
+}
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 // The four lanes of a quad (4 consecutive query rows in the forward / dQ layout, 4 consecutive keys in the dK/dV layout) need the
 // SAME 4x4 block of random bytes for a tile, so one Philox evaluation per tile wastes 3/4 of the wave's work.  Instead quad lane i

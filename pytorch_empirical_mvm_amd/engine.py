@@ -287,6 +287,7 @@ class VioletEngine:
         # BASELINE config 5 ("fp8 MFMA path"): forward GEMMs of the fusion encoder's qkv and FFN-in projections on e4m3 operands
         # (per-tensor static scales, v_mfma_scale_f32_16x16x128_f8f6f4); backward stays bf16 on the bf16 activations
         self.fp8 = bool(cfg.get("fp8_forward", False)) and self.device.type == "cuda"
+        self.store_drop_mask = os.environ.get("VMVM_DROP_MASK", "1") != "0"      # fusion attention: the backward reads the forward's dropout decisions (44.8 MB per layer at C2) instead of re-evaluating Philox twice
         self.gelu_code8 = bool(cfg.get("gelu_code8", os.environ.get("VMVM_GELU_CODE8", "1") != "0"))         # Swin MLPs keep GELU' as an 8-bit code
         self.A8_SCALE = 16.0
         if self.fp8:
@@ -668,6 +669,8 @@ class VioletEngine:
             qkv = K.gemm(x, Wqkv, bias=bqkv)
         o_att = self._next_offset(nseq * nh * Lq * Lq)
         akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att, causal_from=causal_from)
+        if p_a > 0 and self.store_drop_mask:                     # the forward's keep / drop decisions, read back by both backward kernels
+            akw["drop_mask"] = K.attention_drop_mask(nseq, Lq, nh, Hd // nh, 1, p_a, dev, causal_from=causal_from, att_colsum=att_out)
         ctx, lse = K.attention_fwd(qkv, nseq, Lq, nh, Hd // nh, 1, 1.0 / math.sqrt(Hd // nh), att_colsum=att_out, **akw)
         o1 = self._next_offset(M * Hd)
         a = K.gemm(ctx, S.b(pre + "attention.output.dense.weight"), bias=S.p(pre + "attention.output.dense.bias"), resid=x,

@@ -174,7 +174,7 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
 
 
 def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
-               keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len=0, causal_from=0, att_colsum=None, win_layout=0):
+               keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len=0, causal_from=0, att_colsum=None, win_layout=0, drop_mask=None):
     d = L.AttnFwdDesc()
     d.qkv, d.ld_qkv, d.q_off, d.k_off, d.v_off = qkv.data_ptr(), _ld(qkv), q_off, k_off, v_off
     d.out, d.ld_out, d.lse = out.data_ptr(), _ld(out), lse.data_ptr()
@@ -189,27 +189,37 @@ def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_
     d.causal_from = causal_from
     d.att_colsum, d.att_scale = L.ptr(att_colsum), 1.0 / heads
     d.win_layout = win_layout
+    d.drop_mask = L.ptr(drop_mask)
     return d
 
 
+def attention_drop_mask(nseq, Lq, heads, hd, mode, dropout_p, device, stream_min_len=0, causal_from=0, att_colsum=None):
+    """buffer for the forward's dropout decisions (vmvm_attn_fwd_desc.drop_mask) when this problem has a stored-decision build, else None"""
+    d = L.AttnFwdDesc()
+    d.nseq, d.L, d.heads, d.head_dim, d.mode, d.dropout_p = nseq, Lq, heads, hd, mode, dropout_p
+    d.stream_min_len, d.causal_from, d.att_colsum = stream_min_len, causal_from, L.ptr(att_colsum)
+    n = L.load().vmvm_attention_drop_mask_size(C.byref(d))
+    return torch.empty((n // 4,), device=device, dtype=torch.int32) if n > 0 else None
+
+
 def attention_fwd(qkv, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0, region=None,
-                  n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0, stream_min_len=0, causal_from=0, att_colsum=None, win_layout=0):
+                  n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0, stream_min_len=0, causal_from=0, att_colsum=None, win_layout=0, drop_mask=None):
     out = torch.empty((nseq * Lq, heads * hd), device=qkv.device, dtype=BF16)
     lse = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
     d = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
-                   keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, att_colsum, win_layout)
+                   keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, att_colsum, win_layout, drop_mask)
     L.check(L.load().vmvm_attention_fwd(C.byref(d), L.stream()), "attention_fwd")
     return out, lse
 
 
 def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0,
                   region=None, n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0,
-                  dbias_table=None, stream_min_len=0, causal_from=0, win_layout=0):
+                  dbias_table=None, stream_min_len=0, causal_from=0, win_layout=0, drop_mask=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
     b = L.AttnBwdDesc()
     b.f = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
-                     keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, None, win_layout)
+                     keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, None, win_layout, drop_mask)
     b.dout, b.ld_dout, b.dqkv, b.ld_dqkv = dout.data_ptr(), _ld(dout), dqkv.data_ptr(), _ld(dqkv)
     b.dbias_table, b.delta = L.ptr(dbias_table), delta.data_ptr()
     L.check(L.load().vmvm_attention_bwd(C.byref(b), L.stream()), "attention_bwd")

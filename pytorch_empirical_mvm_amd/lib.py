@@ -61,7 +61,7 @@ class AttnFwdDesc(C.Structure):
                 ("region", c_void_p), ("n_win", c_int),
                 ("keymask", c_void_p),
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
-                ("seq_scale", c_void_p), ("seqs_per_scale", c_int), ("stream_min_len", c_int), ("causal_from", c_int), ("att_colsum", c_void_p), ("att_scale", c_float), ("win_layout", c_int)]
+                ("seq_scale", c_void_p), ("seqs_per_scale", c_int), ("stream_min_len", c_int), ("causal_from", c_int), ("att_colsum", c_void_p), ("att_scale", c_float), ("win_layout", c_int), ("drop_mask", c_void_p)]
 
 
 class AttnBwdDesc(C.Structure):
@@ -125,6 +125,7 @@ _PROTOS = {
     "vmvm_gemm_workspace_size": ([C.POINTER(GemmDesc)], c_i64),
     "vmvm_layernorm_bwd_workspace_size": ([C.POINTER(LnBwdDesc)], c_i64),
     "vmvm_attention_bwd_workspace_size": ([C.POINTER(AttnBwdDesc)], c_i64),
+    "vmvm_attention_drop_mask_size": ([C.POINTER(AttnFwdDesc)], c_i64),
     "vmvm_sumsq_workspace_size": ([c_i64], c_i64),
 }
 

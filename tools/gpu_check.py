@@ -547,6 +547,47 @@ def check_attn_bert():
     rep("bert attn dropout bwd dk", dqkv[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
     rep("bert attn dropout bwd dv", dqkv[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
 
+    # stored dropout decisions (vmvm_attn_fwd_desc.drop_mask, L = 432 exact-tile kernels): the record decodes to the mask the forward applied
+    # (torch reference with that mask), and forward / backward are BIT-identical with and without it
+    nseq, Lq, heads, Hd = 3, 432, 12, 768
+    qkv = rnd(nseq * Lq, 3 * Hd)
+    km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
+    km[1, 400:] = 0
+    kw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=23, offset=77)
+    dm = K.attention_drop_mask(nseq, Lq, heads, 64, 1, 0.1, dev)
+    assert dm is not None and dm.numel() == nseq * heads * 27 * 27 * 8
+    dm.fill_(-1)
+    out0, lse0 = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, **kw)
+    out1, lse1 = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, drop_mask=dm, **kw)
+    RESULTS.append(("bert attn drop_mask fwd bit-identical", float((out0 != out1).sum() + (lse0 != lse1).sum()), 0.0, bool((out0 != out1).any() or (lse0 != lse1).any())))
+    bits = ((dm.view(nseq * heads, 27, 27, 4, 2, 1).to(torch.int64) >> torch.arange(32, device=dev)) & 1)          # [sh, qt, t, j, half, 32]
+    bits = bits.reshape(nseq * heads, 27, 27, 4, 4, 16)                                                              # [sh, qt, t, j, g, r]
+    dropped = bits.permute(0, 1, 5, 2, 4, 3).reshape(nseq, heads, Lq, Lq).float()                                    # [.., q = 16 qt + r, key = 16 t + 4 g + j]
+    frac = dropped.mean().item()
+    RESULTS.append(("bert attn drop_mask drop fraction", frac, 0.1, abs(frac - 0.1) > 0.002))
+    mask = (1.0 - dropped) * (65536.0 / (65536.0 - 6554.0))
+    qf = qkv.float().requires_grad_(True)
+    x = qf.view(nseq, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    kb = torch.where(km.bool(), 0.0, float("-inf"))[:, None, None, :]
+    sc = (x[0] * 0.125) @ x[1].transpose(-1, -2) + kb
+    o = (torch.softmax(sc, -1) * mask) @ x[2]
+    ref = o.transpose(1, 2).reshape(nseq * Lq, Hd)
+    rep("bert attn drop_mask fwd vs torch with the decoded mask", out1, ref)
+    dout = rnd(nseq * Lq, Hd)
+    ref.backward(dout.float())
+    g0 = K.attention_bwd(dout, qkv, out1, lse1, nseq, Lq, heads, 64, 1, 0.125, **kw)
+    g1 = K.attention_bwd(dout, qkv, out1, lse1, nseq, Lq, heads, 64, 1, 0.125, drop_mask=dm, **kw)
+    RESULTS.append(("bert attn drop_mask bwd bit-identical", float((g0 != g1).sum()), 0.0, bool((g0 != g1).any())))
+    rep("bert attn drop_mask bwd dq vs torch", g1[:, :Hd], qf.grad[:, :Hd])
+    rep("bert attn drop_mask bwd dk vs torch", g1[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
+    rep("bert attn drop_mask bwd dv vs torch", g1[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+    # a problem without a stored-decision build refuses the buffer
+    try:
+        K.attention_fwd(qkv[: 2 * 100], 2, 100, heads, 64, 1, 0.125, drop_mask=dm, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=1, offset=0)
+        RESULTS.append(("bert attn drop_mask refused where unsupported", 1.0, 0.0, True))
+    except RuntimeError:
+        RESULTS.append(("bert attn drop_mask refused where unsupported", 0.0, 0.0, False))
+
 
 def check_attn_query_row():
     """vmvm_attn_query_row_fwd / bwd (one query position per sequence: the VTM pass' last fusion layer) against torch fp32 with the
@@ -1063,7 +1104,11 @@ def bench_attn():
     b0 = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.0, seed=1)
     fs = lambda: K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, stream_min_len=1)
     bs = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, stream_min_len=1)
-    for name, fn, mult in (("bert fwd", f, 1), ("bert bwd", b, 2.5), ("bert fwd (no dropout)", f0, 1), ("bert bwd (no dropout)", b0, 2.5),
+    dm = K.attention_drop_mask(nseq, Lq, heads, 64, 1, 0.1, dev)
+    fm = lambda: K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, drop_mask=dm)
+    bm = lambda: K.attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1, drop_mask=dm)
+    for name, fn, mult in (("bert fwd", f, 1), ("bert bwd", b, 2.5), ("bert fwd (stores its dropout decisions)", fm, 1), ("bert bwd (reads them)", bm, 2.5),
+                           ("bert fwd (no dropout)", f0, 1), ("bert bwd (no dropout)", b0, 2.5),
                            ("bert fwd (streaming kernels)", fs, 1), ("bert bwd (streaming kernels)", bs, 2.5)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
