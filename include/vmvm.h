@@ -297,6 +297,9 @@ int vmvm_bert_embed_bwd(const int64_t* txt, const void* dsum, float* dword, floa
 int vmvm_count_valid(const int64_t* target, int32_t M, float* n_valid, void* stream);
 int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, int32_t V, const int64_t* target,
                        const float* n_valid, float* loss_sum, void* dlogits, int32_t ld_d, void* stream);
+/* VTM head (main_pretrain.py:262-263, 566): loss_sum += mean_i CE(logits[i, :], class 0) of the f32 (B, O) matrix of pair scores, and
+ * dlogits f32 [B][O] = (softmax - onehot_0) / B -- kept in f32 (the positive's and the negatives' terms of a clip nearly cancel). */
+int vmvm_vtm_ce(const float* logits, int32_t B, int32_t O, float* loss_sum, float* dlogits, void* stream);
 
 /* MVM pixel / HOG map loss (main_pretrain.py:420-432 pixel, :453-468 hog): pred bf16 [B*T*hw][channels*ps*ps] (1x1-conv output,
  * channel = c*ps*ps+dy*ps+dx, PixelShuffle(ps) video order); target f32 (B,T,channels,H,W) = the un-masked normalised frames

@@ -23,6 +23,7 @@ def _source_hash():
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
     for f in files:
         h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(CSRC, "hooks", "vmvm_probe_hooks.h"), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "vmvm.h"), "rb").read())
     return h.hexdigest()
 
@@ -53,7 +54,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + ["-I", os.path.join(CSRC, "hooks"), "-c", os.path.join(CSRC, s), "-o", o]      # hooks/: the no-op measurement hooks (tools/probe/hooks holds the instrumented twin)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

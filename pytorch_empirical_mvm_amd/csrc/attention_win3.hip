@@ -14,20 +14,12 @@
 //    live-class set with the masked tiles absent at compile time (49 % of the tile pairs of an edge window, 74 % of a corner window).
 #include "attn_common.h"
 #include "attn_win3.h"
+#include <vmvm_probe_hooks.h>
 #include <cstdlib>
 
 namespace {
 
 template <int V> struct IC { static constexpr int value = V; };
-#ifdef W3_TIMELINE
-__device__ unsigned long long w3_dbg[8192];
-#define W3_T(slot) do { if (tl_on) { tl_buf[tl_n++] = ((unsigned long long)(slot) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); } } while (0)
-#else
-#define W3_T(slot) do { } while (0)
-#endif
-#ifndef W3_ABL
-#define W3_ABL 0
-#endif
 
 // windowed copy of one head's table column (stage: the 2535 entries [delta * 169 + rho] in LDS): row rho holds the 12 windows of 4
 // consecutive entries a lane can need.  DIR 0 (a lane's 4 values are consecutive KEYS, delta falls): entry j of window s is
@@ -249,11 +241,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win3_kernel(const vmvm_
     const unsigned char* tq1 = Qs + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8;
     const uint32_t tq0a = lds_addr(tq0), tq1a = lds_addr(tq1);
 
-#ifdef W3_TIMELINE
-    const bool tl_on = blockIdx.x == 8 && b == 2 && lane == 0 && (wave == 0 || wave == 5);
-    unsigned long long* tl_buf = w3_dbg + (wave == 0 ? 0 : 2048);
-    int tl_n = 1;
-#endif
+    vmvm_hook::W3Timeline tl(b, lane, wave);                // (probe builds: cycle stamps of one wave; nothing here)
     // the walk over the live query tiles of class set M4 (compile-time list)
     auto walk = [&](auto m4c) {
       constexpr int M4 = decltype(m4c)::value;
@@ -347,25 +335,25 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win3_kernel(const vmvm_
           dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q1v), dsf, dk[t][1], 0, 0, 0);
         }
       };
-      W3_T(1);
+      tl.stamp(1);
       reads(0);
       mma1(0);
-      W3_T(2);
+      tl.stamp(2);
 #pragma unroll
       for (int c = 0; c < NP; ++c) {
         trreads(c);
         if (c <= NF && has_next) dma_step(sq_nx, cur ^ 1, c);
-        W3_T(10);
+        tl.stamp(10);
         chain(c);
         __builtin_amdgcn_sched_barrier(0);                // (the next pair's fragments once the chain has released its registers: asking
-        W3_T(11);                                         //  for them before the chain costs 40 registers and measured the same -- the
+        tl.stamp(11);                                         //  for them before the chain costs 40 registers and measured the same -- the
         if (c + 1 < NP) reads(c + 1);                     //  LDS pipe is a co-bound of this loop, the requests queue either way)
-        W3_T(12);
+        tl.stamp(12);
         mma2();
-        W3_T(13);
+        tl.stamp(13);
         if (c + 1 < NP) mma1(c + 1);
         __builtin_amdgcn_sched_barrier(0);
-        W3_T(14);
+        tl.stamp(14);
       }
       if (has_next) {                                     // (short walks: the DMA steps the pairs did not cover)
 #pragma unroll
@@ -387,10 +375,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win3_kernel(const vmvm_
         default: walk(IC<8>{}); break;
       }
     }
-    W3_T(20);
-#ifdef W3_TIMELINE
-    if (tl_on) tl_buf[0] = tl_n;
-#endif
+    tl.stamp(20);
+    tl.flush(0);
     const float ssv = seq_scale;
     if (has_next) fetch(sq_nx);                           // the fragment registers are free: the next sequence's K / V (4 loads, before the 8 stores)
     u16* dbase = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv;
@@ -978,9 +964,3 @@ __attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d
 }
 
 }  // namespace vmvm_w3
-
-#ifdef W3_TIMELINE
-extern "C" int vmvm_w3_debug_read(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w3_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -107,13 +107,6 @@ __device__ __forceinline__ f32x2 erf_poly2(f32x2 z) {
   const f32x2 e = p * z;
   return f32x2{__builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f), __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f)};
 }
-#ifdef VMVM_SCALAR_EPI   /* probe builds only (tools/probe): the same math on scalar v_fma_f32, to price the packed-f32 form */
-__device__ __forceinline__ float erf_poly(float z);
-__device__ __forceinline__ float gelu_f(float x);
-__device__ __forceinline__ float gelu_grad_f(float x);
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) { return f32x2{gelu_f(x[0]), gelu_f(x[1])}; }
-__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) { return f32x2{gelu_grad_f(x[0]), gelu_grad_f(x[1])}; }
-#else
 __device__ __forceinline__ f32x2 gelu_sigmoid2(f32x2 x, f32x2 t);
 __device__ __forceinline__ f32x2 gelu2(f32x2 x);
 // 8-bit code of GELU' (vmvm_gemm_desc.aux_code8): g in [-0.129, 1.129] -> round((g + 0.13) * 255 / 1.26), and back
@@ -163,7 +156,6 @@ __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
   const f32x2 cdf = __builtin_elementwise_fma(erf_poly2(x * f32x2{0.70710678118654752f, 0.70710678118654752f}), f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
   return __builtin_elementwise_fma(x, pdf, cdf);
 }
-#endif
 __device__ __forceinline__ float gelu_f(float x) {          // the same logistic form as gelu2 (every GELU forward of the library agrees)
   constexpr float A2 = -1.59982729f * 1.4426950408889634f, B2 = -0.0699463f * 1.4426950408889634f;
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * fmaf(x * x, B2, A2)));

@@ -13,6 +13,7 @@
 // Block -> tile mapping is XCD-aware: the 8 XCDs get contiguous runs of the tile list, and all
 // N-tiles of one M-panel are neighbours, so an activation panel is fetched into one L2 only.
 #include "common.h"
+#include <vmvm_probe_hooks.h>
 #include "gemm_epi.h"
 
 int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* stream);      // misc.hip
@@ -689,17 +690,6 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
 // fragments after the LDS read (fp16 builds: the block-input ReLU of the dVAE's residual path, encoder.py:27-28, without a pass
 // over the activation); one v_pk_max_f16 per MFMA, in its shadow.  F & EF_ARGMAX: instead of storing, each 64-column group of a
 // row leaves its (maximum, column) pair in C (f32 [M][ldc], pairs at 2 * (n / 64)) -- the 8192-wide logits are never written.
-#ifdef VMVM_PROBE_STAGGER_CU
-__device__ unsigned g_probe_cu_arrivals[8 * 256];
-#endif
-#ifdef VMVM_PROBE_TIMELINE   /* probe builds only: 100 MHz timestamps of (main loop start, epilogue start, epilogue end) of the first tiles of every workgroup, per CU */
-constexpr int TL_TILES = 24;
-__device__ unsigned g_tl_arrivals[8 * 256];
-__device__ unsigned long long g_tl[8 * 256][2][TL_TILES][4];
-#endif
-#ifndef VMVM_PROBE_EPI
-#define VMVM_PROBE_EPI 0        /* probe builds only (tools/probe/gemm_probe.hip): 1 = no global stores, 2 = no epilogue math, 3 = neither (re-tiled classes) */
-#endif
 template <bool AK, bool BKM, int F, bool F16 = false, bool CONV = false, bool FP8 = false, int TM = 1, bool ARELU = false>
 __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc p) {
   static_assert(TM == 1 || (TM == 2 && AK && BKM && !FP8 && !(F & EF_COLSUM)), "the 256x64 tile serves k-major x k-major operands");
@@ -742,10 +732,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     const int logical = x_start + w;
     slice = logical / nb;
     int tm, tn;
-#ifndef VMVM_PROBE_GM
-#define VMVM_PROBE_GM 8          /* probe builds only: M panels per raster group of the 128x128 persistent kernel */
-#endif
-    raster(logical - slice * nb, nbm, nbn, VMVM_PROBE_GM, tm, tn);
+    raster(logical - slice * nb, nbm, nbn, vmvm_hook::GM, tm, tn);
     m0 = tm * BM; n0 = tn * BN;
     kt0 = slice * per;
     nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
@@ -805,48 +792,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   if (w >= x_cnt) return;
   int slice, m0, n0, kt0, nk;
   decode(w, slice, m0, n0, kt0, nk);
-#ifdef VMVM_PROBE_TIMELINE
-  unsigned tl_key, tl_slot; int tl_t = 0;
-  {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    tl_key = (blockIdx.x & 7) * 256 + ((hw >> 8) & 0xff);
-    if (tid == 0) *reinterpret_cast<unsigned*>(smem) = atomicAdd(&g_tl_arrivals[tl_key], 1u);
-    __syncthreads();
-    tl_slot = *reinterpret_cast<volatile unsigned*>(smem) & 1;
-    __syncthreads();
-  }
-#endif
-#ifdef VMVM_PROBE_STAGGER_CU   /* probe builds only: the SECOND workgroup to arrive on a compute unit (arrival order per CU through HW_ID) starts a fraction of a tile time late */
-  {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned key = (blockIdx.x & 7) * 256 + ((hw >> 8) & 0xff);
-    if (tid == 0) *reinterpret_cast<unsigned*>(smem) = atomicAdd(&g_probe_cu_arrivals[key], 1u);
-    __syncthreads();
-    const unsigned old = *reinterpret_cast<volatile unsigned*>(smem);
-    __syncthreads();
-    const int tile64 = (nk - kt0) * 17 + 100;           // estimated tile time in 64-cycle units
-    const int wait64 = (old & 1) ? tile64 * VMVM_PROBE_STAGGER_CU / 100 : 0;
-    for (int t = 0; t < wait64; t += 100) __builtin_amdgcn_s_sleep(100);
-  }
-#endif
-#ifdef VMVM_PROBE_STAGGER   /* probe builds only: workgroup i of an XCD starts (i % P) / P of an estimated tile time late (are the two workgroups of a CU in lockstep?) */
-  {
-    const int tile64 = (nk - kt0) * 17 + 100;           // estimated tile time in 64-cycle units
-    const int wait64 = (li % VMVM_PROBE_STAGGER) * tile64 / VMVM_PROBE_STAGGER;
-    for (int t = 0; t < wait64; t += 100) __builtin_amdgcn_s_sleep(100);
-  }
-#endif
+  vmvm_hook::GemmTimeline tl;                           // (probe builds: per-CU stamps / start-up staggers; nothing here)
+  tl.init(smem, tid);
+  vmvm_hook::gemm_stagger(smem, tid, li, nk - kt0);
   unsigned it = 0;                                      // running K-tile counter -> LDS buffer parity
   unsigned voA[NA], voB[NB], nvoA[NA], nvoB[NB];
   int pyA[NA], pxA[NA], npyA[NA], npxA[NA];
   tile_offsets(m0, n0, voA, voB, pyA, pxA);
   issue(voA, voB, pyA, pxA, kt0, it & 1);
   while (true) {
-#ifdef VMVM_PROBE_TIMELINE
-    if (tid == 0 && tl_t < TL_TILES) { g_tl[tl_key][tl_slot][tl_t][0] = wall_clock64(); g_tl[tl_key][tl_slot][tl_t][3] = clock64(); }
-#endif
+    tl.stamp(0, tid);
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -989,9 +944,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
       ++it;
     }
     ec.slice = slice;
-#ifdef VMVM_PROBE_TIMELINE
-    if (tid == 0 && tl_t < TL_TILES) g_tl[tl_key][tl_slot][tl_t][1] = wall_clock64();
-#endif
+    tl.stamp(1, tid);
     // (An LDS-staged, 16-byte-per-lane coalesced epilogue was measured here: correct but 1.4-1.7x SLOWER on every shape --
     //  two extra barriers and an LDS round trip per tile cost more than the 32-byte store fragments; kept direct.)
     if ((F & EF_COLSUM) && do_cs && g == 0) {            // lanes 0-15: column m = m0 + wm*64 + i*16 + r (all 16 rows of the product are equal)
@@ -1077,13 +1030,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
                           acc[i][2 * jb + 1][0], acc[i][2 * jb + 1][1], acc[i][2 * jb + 1][2], acc[i][2 * jb + 1][3]};
             o[ii][jb] = make_uint4(0, 0, 0, 0); pr[ii][jb] = make_uint4(0, 0, 0, 0);
             if (rvalid[i] && n < N) {
-#if (VMVM_PROBE_EPI & 2)
-              o[ii][jb] = pack8<F16>(v);
-              pr[ii][jb] = make_uint4(gelu_code4(v[0], v[1], v[2], v[3]), gelu_code4(v[4], v[5], v[6], v[7]), 0, 0);
-#else
-              if (code8) epi_math8<(F | EF_CODE8), F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
-              else epi_math8<F, F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
-#endif
+              if constexpr (vmvm_hook::EPI & 2) {
+                o[ii][jb] = pack8<F16>(v);
+                pr[ii][jb] = make_uint4(gelu_code4(v[0], v[1], v[2], v[3]), gelu_code4(v[4], v[5], v[6], v[7]), 0, 0);
+              } else {
+                if (code8) epi_math8<(F | EF_CODE8), F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
+                else epi_math8<F, F16>(p, ec, v, m, n, rrs[i], bz[jb], auxv[i][jb], resv[i][jb], o[ii][jb], pr[ii][jb]);
+              }
             }
           }
         }
@@ -1122,10 +1075,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma clang loop unroll(full)
             for (int s2 = 0; s2 < 2; ++s2) {
               const int ms = m0 + wm * 64 + hb * 32 + s2 * 16 + c8r, n_c = n0 + wn * 64 + c8g * 16;
-#if (VMVM_PROBE_EPI & 1)
-              asm volatile("" ::"v"(t2[s2].x), "v"(t2[s2].y), "v"(t2[s2].z), "v"(t2[s2].w));
-              continue;
-#endif
+              if constexpr (vmvm_hook::EPI & 1) { asm volatile("" ::"v"(t2[s2].x), "v"(t2[s2].y), "v"(t2[s2].z), "v"(t2[s2].w)); continue; }
               if (ms < M && n_c + 16 <= N)
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.C2) + (size_t)ms * p.ldc2 + n_c) = t2[s2];
               else if (ms < M && n_c + 8 <= N)
@@ -1146,10 +1096,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma clang loop unroll(full)
           for (int s4 = 0; s4 < 4; ++s4) {
             if (!svalid[s4]) continue;
-#if (VMVM_PROBE_EPI & 1)
-            asm volatile("" ::"v"(t[s4].x), "v"(t[s4].y), "v"(t[s4].z), "v"(t[s4].w));
-            continue;
-#endif
+            if constexpr (vmvm_hook::EPI & 1) { asm volatile("" ::"v"(t[s4].x), "v"(t[s4].y), "v"(t[s4].z), "v"(t[s4].w)); continue; }
             if (pass == 0) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C) + (size_t)sdst[s4] * p.ldc + n_s) = t[s4];
             else *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.C2) + (size_t)srow[s4] * p.ldc2 + n_s) = t[s4];
           }
@@ -1173,10 +1120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
     }
     }
     }
-#ifdef VMVM_PROBE_TIMELINE
-    if (tid == 0 && tl_t < TL_TILES) g_tl[tl_key][tl_slot][tl_t][2] = wall_clock64();
-    ++tl_t;
-#endif
+    tl.stamp(2, tid);
+    tl.next_tile();
     if (!more) break;
     w = wn_; slice = nslice; m0 = nm0; n0 = nn0; kt0 = nkt0; nk = nnk;
 #pragma unroll
@@ -1186,34 +1131,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
   }
 }
 
-#ifdef VMVM_PROBE_TIMELINE
-static void probe_timeline_reset() {
-  static unsigned long long z[8 * 256 * 2 * TL_TILES * 4];
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof(z));
-}
-static void probe_timeline_dump(int n_cus) {
-  static unsigned long long h[8 * 256][2][TL_TILES][4];
-  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof(h));
-  int shown = 0;
-  for (int key = 0; key < 8 * 256 && shown < n_cus; ++key) {
-    if (!h[key][0][0][0] || !h[key][1][0][0]) continue;
-    const unsigned long long t0 = h[key][0][0][0] < h[key][1][0][0] ? h[key][0][0][0] : h[key][1][0][0];
-    printf("CU key %d (xcd %d, hw %d): times in us from the first workgroup's start; per tile: main start | epilogue start | epilogue end\n", key, key >> 8, key & 255);
-    for (int sl = 0; sl < 2; ++sl)
-      if (h[key][sl][TL_TILES - 1][0]) printf("   wg%d shader clock over tiles 0..%d: %.0f MHz\n", sl, TL_TILES - 1,
-                                              (double)(h[key][sl][TL_TILES - 1][3] - h[key][sl][0][3]) / ((h[key][sl][TL_TILES - 1][0] - h[key][sl][0][0]) * 0.01));
-    for (int t = 0; t < TL_TILES; ++t) {
-      for (int sl = 0; sl < 2; ++sl) {
-        if (!h[key][sl][t][0]) { printf("   wg%d t%-2d  -                          ", sl, t); continue; }
-        printf("   wg%d t%-2d %7.2f %7.2f %7.2f (main %5.2f epi %5.2f)", sl, t, (h[key][sl][t][0] - t0) * 0.01, (h[key][sl][t][1] - t0) * 0.01, (h[key][sl][t][2] - t0) * 0.01,
-               (h[key][sl][t][1] - h[key][sl][t][0]) * 0.01, (h[key][sl][t][2] - h[key][sl][t][1]) * 0.01);
-      }
-      printf("\n");
-    }
-    ++shown;
-  }
-}
-#endif
 
 template <bool AK, bool BKM, int F>
 int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
@@ -1224,14 +1141,14 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
     attr_done = true;
   }
   int grid = 2 * vmvm_usable_cus(d.reserve_cus);        // 2 workgroups per CU (64 KiB LDS each), multiple of 8
-#ifdef VMVM_PROBE_ONE_WG    /* probe builds only: ONE workgroup per CU (an LDS request no second workgroup fits beside): how much of the rate is one workgroup's? */
-  grid = vmvm_usable_cus(d.reserve_cus);
-  if (items < grid) grid = ((items + 7) / 8) * 8;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
-  hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), 100 << 10, st, d);
-  VMVM_CHECK_LAUNCH();
-  return VMVM_OK;
-#endif
+  if (vmvm_hook::ONE_WG) {     // (probe builds: ONE workgroup per CU through an LDS request no second workgroup fits beside; false here)
+    grid = vmvm_usable_cus(d.reserve_cus);
+    if (items < grid) grid = ((items + 7) / 8) * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<AK, BKM, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
+    hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), 100 << 10, st, d);
+    VMVM_CHECK_LAUNCH();
+    return VMVM_OK;
+  }
   if (items < grid) grid = ((items + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();

@@ -22,6 +22,7 @@
 // lane's 16 accumulators of a tile are two runs of 8 consecutive output columns (16-byte stores, 32 contiguous bytes per row
 // and instruction), which is what epi_store8 consumes.
 #pragma once
+#include <vmvm_probe_hooks.h>
 #include "gemm_epi.h"
 
 namespace {
@@ -104,10 +105,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
     const int logical = x_start + w;
     slice = logical / nb;
     int tm, tn;
-#ifndef VMVM_PROBE_GM_PP
-#define VMVM_PROBE_GM_PP (16 / WM)   /* probe builds only: M panels per raster group of the ping-pong kernel */
-#endif
-    raster(logical - slice * nb, nbm, nbn, VMVM_PROBE_GM_PP, tm, tn);
+    raster(logical - slice * nb, nbm, nbn, vmvm_hook::GM_PP<WM>, tm, tn);
     m0 = tm * TM; n0 = tn * PP_T;
     kt0 = slice * per;
     nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;

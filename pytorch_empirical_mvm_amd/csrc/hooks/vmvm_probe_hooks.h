@@ -1,0 +1,33 @@
+// vmvm_probe_hooks.h (production): the measurement hooks the kernels call, as no-ops and compile-time constants.  The instrumented twin
+// of this header lives in tools/probe/hooks/ and is put in front of this directory on the include path by the probe builds
+// (tools/probe/*.sh: -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc); the library build (build.py) only ever sees this one,
+// so no production translation unit carries probe code or probe switches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vmvm_hook {
+
+constexpr int EPI = 0;            // epilogue ablation of the 128x128 persistent GEMM: bit 0 = no global stores, bit 1 = no epilogue math
+constexpr int GM = 8;             // M panels per raster group of the 128x128 persistent GEMM
+template <int WM> constexpr int GM_PP = 16 / WM;   // ... of the 256x256 ping-pong GEMM
+constexpr bool ONE_WG = false;    // one workgroup of the persistent GEMM per CU instead of two
+
+// per-workgroup timeline of the persistent GEMM's tiles (main loop start / epilogue start / epilogue end)
+struct GemmTimeline {
+  __device__ __forceinline__ void init(unsigned char*, int) {}
+  __device__ __forceinline__ void stamp(int, int) {}
+  __device__ __forceinline__ void next_tile() {}
+};
+// start-up stagger experiments of the persistent GEMM (second workgroup of a CU / workgroup i of an XCD starts late)
+__device__ __forceinline__ void gemm_stagger(unsigned char*, int, int, int) {}
+
+inline int ln_bwd_per_cu(int per_cu) { return per_cu; }      // workgroups per CU of the LayerNorm backward's resident grid
+
+// per-wave timeline of attn_bwd_dkv_win3_kernel
+struct W3Timeline {
+  __device__ __forceinline__ W3Timeline(int, int, int) {}
+  __device__ __forceinline__ void stamp(int) {}
+  __device__ __forceinline__ void flush(int) {}
+};
+
+}  // namespace vmvm_hook

@@ -8,6 +8,7 @@
 // Backward: a fixed grid of waves walks rows grid-stride, keeps dgamma/dbeta partials in registers,
 // reduces them across the block in LDS and issues one f32 atomic per column per block.
 #include "common.h"
+#include <vmvm_probe_hooks.h>
 #include <cstdlib>
 
 namespace {
@@ -462,10 +463,7 @@ extern "C" int vmvm_layernorm_fwd(const vmvm_ln_fwd_desc* d, void* stream) {
 // resident grid of the backward kernels: workgroups that fit per CU at the variant's VGPR count x 256 CUs, at most one per 4 rows.
 // ONE helper for the launcher and the workspace-size query, so the two plans cannot drift.
 static int ln_bwd_grid(int M, int C, int reserve_cus) {
-  int per_cu = C <= 128 ? 4 : C <= 512 ? 5 : C <= 1024 ? 4 : 2;
-#ifdef VMVM_PROBE_BUILD
-  if (const char* e = getenv("VMVM_LN_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }    // tools/gpu_check.py benchln
-#endif
+  const int per_cu = vmvm_hook::ln_bwd_per_cu(C <= 128 ? 4 : C <= 512 ? 5 : C <= 1024 ? 4 : 2);
   int grid = (M + 3) / 4;
   const int cus = vmvm_usable_cus(reserve_cus);
   if (grid > cus * per_cu) grid = cus * per_cu;

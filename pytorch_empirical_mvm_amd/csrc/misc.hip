@@ -867,6 +867,37 @@ extern "C" int vmvm_cross_entropy(const float* logits, int32_t ld, int32_t M, in
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
+// VTM head: cross entropy of the (B, O) logit matrix against column 0 (main_pretrain.py:262-263, 566) with its gradient kept in f32 --
+// the positive's and the negatives' terms of a clip nearly cancel, a bf16-rounded softmax adds noise of the size of the signal.
+// One workgroup, fixed summation order (the loss is bit-reproducible).
+__global__ __launch_bounds__(256) void vtm_ce_kernel(const float* __restrict__ lg, int B, int O, float* loss_sum, float* dlg) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float* l = lg + (size_t)i * O;
+    float m = l[0];
+    for (int j = 1; j < O; ++j) m = fmaxf(m, l[j]);
+    float s = 0.f;
+    for (int j = 0; j < O; ++j) s += __expf(l[j] - m);
+    const float inv = 1.0f / s;
+    for (int j = 0; j < O; ++j) dlg[(size_t)i * O + j] = (__expf(l[j] - m) * inv - (j == 0 ? 1.0f : 0.0f)) * invB;
+    acc += (m + __logf(s) - l[0]) * invB;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss_sum += red[0];
+}
+extern "C" int vmvm_vtm_ce(const float* logits, int32_t B, int32_t O, float* loss_sum, float* dlogits, void* stream) {
+  if (!logits || !loss_sum || !dlogits || B <= 0 || O <= 0) return VMVM_EINVAL;
+  hipLaunchKernelGGL(vtm_ce_kernel, dim3(1), dim3(256), 0, ST, logits, B, O, loss_sum, dlogits);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
 extern "C" int vmvm_pixel_l1(const void* pred, const float* img, const uint8_t* cov, const float* mask_sum, float* loss_sum, void* dpred,
                              int32_t B, int32_t T, int32_t h, int32_t w, int32_t ps, int32_t channels, float inv_div, void* stream) {
   if (!pred || !img || !cov || !mask_sum || !loss_sum || !dpred || (ps & 3) || channels <= 0 || ((channels * ps * ps) & 7)) return VMVM_EINVAL;

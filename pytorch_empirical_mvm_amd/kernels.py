@@ -343,6 +343,13 @@ def cross_entropy(logits, V, target, loss_sum, want_grad=True, ld_d=None):
     return dlog
 
 
+def vtm_ce(logits, B, O, loss_sum):
+    """loss_sum (f32[1]) += mean CE of the f32 (B, O) pair-score matrix against column 0; returns its gradient, f32 [B * O]"""
+    dlg = torch.empty((B * O,), device=logits.device, dtype=F32)
+    L.check(L.load().vmvm_vtm_ce(logits.data_ptr(), B, O, loss_sum.data_ptr(), dlg.data_ptr(), L.stream()), "vtm_ce")
+    return dlg
+
+
 def pixel_l1(pred, img, cov, mask_sum, loss_sum, B, T, h, w, ps, channels=3, inv_div=1.0 / 3.0):
     dpred = torch.empty_like(pred)
     L.check(L.load().vmvm_pixel_l1(pred.data_ptr(), img.data_ptr(), cov.data_ptr(), mask_sum.data_ptr(), loss_sum.data_ptr(),

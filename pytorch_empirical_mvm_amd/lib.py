@@ -95,6 +95,7 @@ _PROTOS = {
     "vmvm_bert_embed_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_count_valid": ([c_void_p, c_int, c_void_p, c_void_p], c_int),
     "vmvm_cross_entropy": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    "vmvm_vtm_ce": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_pixel_l1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p], c_int),
     "vmvm_feature_l1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
     "vmvm_rowdot": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA lint of attention.hip (compiles it to gfx950 assembly with hipcc --save-temps and inspects the text): properties the
+"""ISA lint of attention.hip and attention_win3.hip (compiles them to gfx950 assembly with hipcc --save-temps and inspects the text): properties the
 compiler does not guarantee and that were each lost once without any test noticing until a flaky run --
 
 1. the hot loops of the batch-persistent window-attention kernels hold no `s_waitcnt vmcnt(0)` (= the wave drains the next
@@ -24,10 +24,13 @@ def assembly():
     if len(sys.argv) > 1:
         return open(sys.argv[1]).read()
     d = tempfile.mkdtemp()
-    src = os.path.join(ROOT, "pytorch_empirical_mvm_amd", "csrc", "attention.hip")
-    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-c", src,
-                    "-o", os.path.join(d, "a.o"), "-save-temps"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return open(os.path.join(d, "attention-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    csrc = os.path.join(ROOT, "pytorch_empirical_mvm_amd", "csrc")
+    out = []
+    for name in ("attention", "attention_win3"):          # both attention translation units (the win_layout = 1 kernels use the same idioms)
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-I", os.path.join(csrc, "hooks"),
+                        "-c", os.path.join(csrc, name + ".hip"), "-o", os.path.join(d, name + ".o"), "-save-temps"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out.append(open(os.path.join(d, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read())
+    return "\n".join(out)
 
 
 def kernels(s):
@@ -43,7 +46,7 @@ def main():
         short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:64]
         mf = [k for k, l in enumerate(ins) if l.startswith("v_mfma")]
         ex = [k for k, l in enumerate(ins) if l.startswith("v_exp_f32")]
-        if "win2_kernel" in name and mf and ex:
+        if ("win2_kernel" in name or "win3_kernel" in name) and mf and ex:
             loop = ins[min(mf[0], ex[0]):max(mf[-1], ex[-1]) + 1]
             n_vm = sum(1 for l in loop if l.startswith("s_waitcnt") and "vmcnt(0)" in l)
             n_wf = sum(1 for k, l in enumerate(loop) if l.startswith("v_cmp_eq_u64") and any(x.startswith("s_and_saveexec") for x in loop[k:k + 5]))

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 for e in 0 1 2 3; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DVMVM_PROBE_EPI=$e -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_e$e &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DVMVM_PROBE_EPI=$e -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_e$e &
 done
 wait
 for rd in 1 2; do

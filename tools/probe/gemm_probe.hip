@@ -1,7 +1,7 @@
 // gemm_probe.hip -- standalone harness for the GEMM main loops of libvmvm (no torch): correctness against a naive f32 reference
 // on sampled rows + HIP-event timing of the 256x256 ping-pong kernel variants next to the 128x128 persistent kernel, on uniform
 // random [-1,1) bf16 operands, interleaved rounds in ONE process.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o tools/probe/gemm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o tools/probe/gemm_probe
 //   tools/probe/gemm_probe [shape-set] [reps]
 #include "../../pytorch_empirical_mvm_amd/csrc/gemm.hip"
 #include "../../pytorch_empirical_mvm_amd/csrc/gemm_pp.hip"

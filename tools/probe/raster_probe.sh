@@ -3,7 +3,7 @@
 # XCD's 64 (32) resident workgroups spread the cold-panel switch?   (run on the GPU box)
 cd "$(dirname "$0")/../.."
 for g in 8 4 6 7 12 16; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DVMVM_PROBE_GM=$g -DVMVM_PROBE_GM_PP=$g -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_gm$g &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DVMVM_PROBE_GM=$g -DVMVM_PROBE_GM_PP=$g -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_gm$g &
 done
 wait
 for rd in 1 2; do

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 for P in 0 2 4 16; do
   D=""; [ $P -gt 0 ] && D="-DVMVM_PROBE_STAGGER=$P"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed $D -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_s$P &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed $D -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_s$P &
 done
 wait
 for rd in 1 2; do

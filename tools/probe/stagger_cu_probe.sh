@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."
 for P in 0 25 50 75; do
   D=""; [ $P -gt 0 ] && D="-DVMVM_PROBE_STAGGER_CU=$P"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed $D -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_sc$P &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed $D -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc tools/probe/gemm_probe.hip -o /tmp/gemm_probe_sc$P &
 done
 wait
 for rd in 1 2; do

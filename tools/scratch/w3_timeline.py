@@ -1,4 +1,5 @@
-"""per-phase cycle stamps of one wave pair of attn_bwd_dkv_win3_kernel (probe build -DW3_TIMELINE loaded through VMVM_LIB)"""
+"""per-phase cycle stamps of one wave pair of attn_bwd_dkv_win3_kernel (probe build loaded through VMVM_LIB:
+hipcc ... -I tools/probe/hooks -I pytorch_empirical_mvm_amd/csrc -DW3_TIMELINE: the stamps live in tools/probe/hooks/vmvm_probe_hooks.h)"""
 import ctypes, os, sys
 import numpy as np
 import torch
