@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x 3 (C2/C3)
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
 
 
 def pmc_traffic_bytes():

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
         constexpr int DROPM = decltype(drop_c)::value;       // 0 no dropout, 1 Philox decisions, 2 Philox decisions + stored for the backward (drop_mask)
         constexpr bool DROP = DROPM != 0;
         uint4 own = make_uint4(0, 0, 0, 0);
-        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(DROPM == 2 ? const_cast<uint32_t*>(uniform_ptr(p.drop_mask + ((size_t)(seq * heads + h) * nt + qt) * nt * 8)) : (uint32_t*)nullptr, 0, NT_MAX * 32, 0x00020000);
+        const uint32_t* mrow = DROPM == 2 ? uniform_ptr(p.drop_mask + ((size_t)(seq * heads + h) * nt + qt) * nt * 8) : nullptr;
 #pragma unroll
         for (int c = 0; c < NT_MAX / 2; ++c) {
           if (PAIR_ON(c)) {
@@ -186,9 +186,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { dr[j] = drop_field(w, j) < thr16; e[u][j] = dr[j] ? 0.f : e[u][j]; }
                 if (DROPM == 2) {                              // the four compares' lane masks ARE the tile's record: 8 dwords, lanes 0-7 store them
-                  const uint32_t rec = lane_masks_record(__builtin_amdgcn_ballot_w64(dr[0]), __builtin_amdgcn_ballot_w64(dr[1]), __builtin_amdgcn_ballot_w64(dr[2]),
-                                                         __builtin_amdgcn_ballot_w64(dr[3]));
-                  __builtin_amdgcn_raw_buffer_store_b32(rec, mrs, lane < 8 ? lane * 4 : 0x7fffffff, t * 32, 0);      // lanes 8-63 fall outside the record (bounds-checked away)
+                  // ... and they are wave-uniform scalar pairs already: four SCALAR stores, no vector instruction (attn_common.h)
+                  store_lane_masks(mrow, t * 32, __builtin_amdgcn_ballot_w64(dr[0]), __builtin_amdgcn_ballot_w64(dr[1]), __builtin_amdgcn_ballot_w64(dr[2]),
+                                   __builtin_amdgcn_ballot_w64(dr[3]));
                 }
               }
             }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const vmvm_attn_fwd_d
           }
         }
       };
-      if (has_drop) { if (p.drop_mask) pairs(std::integral_constant<int, 2>{}); else pairs(std::integral_constant<int, 1>{}); } else pairs(std::integral_constant<int, 0>{});
+      if (has_drop) { if (p.drop_mask) { pairs(std::integral_constant<int, 2>{}); scalar_stores_done(); } else pairs(std::integral_constant<int, 1>{}); } else pairs(std::integral_constant<int, 0>{});
       float sum = sum2[0] + sum2[1];
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);

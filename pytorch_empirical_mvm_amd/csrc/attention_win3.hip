@@ -403,10 +403,11 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_win3_kernel(const vmvm_
 // The running sums of dS (bias-table gradient) stay in registers over the workgroup's whole run, one slot per key tile of the half, and
 // are scattered once at the end: entry (dq - dk + 7) * 169 + A(q) - A(k) + 84 of the head's column.
 // ================================================================================================
-template <bool MASK>
-__global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_bwd_desc pb, const int nqg, const int nch) {
-  constexpr int HD = 32, NQ = 4, NS = 2, NWV = NQ * NS;
-  constexpr int NH = 13;                                                // slots of a half (w3::list_part(15, 0, 2).n)
+template <bool MASK, int NS>
+__global__ __launch_bounds__(4 * NS * 64) void attn_bwd_dq_win3_kernel(const vmvm_attn_bwd_desc pb, const int nqg, const int nch) {
+  constexpr int HD = 32, NQ = 4, NWV = NQ * NS;
+  constexpr int NH = w3::max_part(NS);                                  // running-sum slots of a wave: tiles of the longest key part (13 of 2, 9 of 3)
+  constexpr bool XF32 = NS == 2;                                        // dQ partials cross the workgroup as f32 (two parts) or packed bf16 (three: LDS)
   constexpr int ROWS = w3::NT * 16, KV = ROWS * HD * 2;                 // 400 rows, 25 600 bytes per K or V image
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -419,9 +420,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
   const int t1 = logical / nqg;
   const int ch = t1 % nch;
   const int h = t1 / nch;
-  constexpr int XCH = (NS - 1) * NQ * 64 * 8;
-  float* xch = reinterpret_cast<float*>(smem + 4 * KV);                 // [2][NS-1][NQ][64 lanes][8] f32: dQ partials of split 1, double-buffered by sequence parity
-  unsigned char* TL = smem + 4 * KV + 2 * XCH * 4;
+  constexpr int XCH = (NS - 1) * NQ * 64 * 8;                           // values per parity
+  constexpr int XB = XF32 ? 4 : 2;                                      // bytes per value
+  unsigned char* xch = smem + 4 * KV;                                   // [2][NS-1][NQ][64 lanes][8]: dQ partials of parts 1.., double-buffered by sequence parity
+  unsigned char* TL = smem + 4 * KV + 2 * XCH * XB;
   const bool want_dtab = pb.dbias_table != nullptr;
   const int ql = wave % NQ, kh = wave / NQ;                             // query tile slot, key half
   // query tiles of this group: the 25 tiles are dealt evenly over the nqg groups (nqg = 7: 4,4,4,4,4,4,1 as in win2; nqg = 8: runs of
@@ -495,10 +497,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
   auto flush_prev = [&](size_t seq, int par) {           // split 0: add the other split's partial (in LDS buffer `par`) and store dQ
     if (kh == 0 && qv) {
       float4 x0 = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]), x1 = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
-      const float* x = xch + par * XCH + (ql * 64 + lane) * 8;
-      const float4 y0 = *reinterpret_cast<const float4*>(x), y1 = *reinterpret_cast<const float4*>(x + 4);
-      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
-      x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+#pragma unroll
+      for (int s_ = 0; s_ < NS - 1; ++s_) {
+        const unsigned char* x = xch + ((size_t)par * XCH + ((s_ * NQ + ql) * 64 + lane) * 8) * XB;
+        float4 y0, y1;
+        if (XF32) { y0 = *reinterpret_cast<const float4*>(x); y1 = *reinterpret_cast<const float4*>(x + 16); }
+        else {
+          const uint4 w = *reinterpret_cast<const uint4*>(x);
+          y0 = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+          y1 = make_float4(__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u));
+        }
+        x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+        x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+      }
       u16* dqp = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv + off_dq;
       const float sc = p.scale;
       *reinterpret_cast<uint2*>(dqp) = make_uint2(pack_bf2(x0.x * sc, x0.y * sc), pack_bf2(x0.z * sc, x0.w * sc));
@@ -566,10 +577,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
           }
         }
       };
-      if (NP > 0) reads(0);
+      constexpr bool AHEAD = NS == 2;                       // the next pair's fragments are requested before the chain (three parts: no registers for that -- the third wave of the SIMD covers the wait)
+      if (AHEAD && NP > 0) reads(0);
 #pragma unroll
       for (int c = 0; c < NP; ++c) {
         f32x4 s4[2], dp4[2];
+        if (!AHEAD) reads(c);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (2 * c + u < KL.n) {
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
         s16x4 a0, a1, c0_, c1_;
         tr_read4_2(a0, a1, c0_, c1_, tk0a, tk1a, ta * 1024, tb * 1024);
         if (c < NF && has_next) fill_one(dst_nx + c * NWV * 64 * 16, KV, kv_nx + p.k_off, kv_nx + p.v_off, fill_bytes, goff[c], c == NF - 1);
-        if (c + 1 < NP) reads(c + 1);
+        if (AHEAD && c + 1 < NP) reads(c + 1);
         uint32_t dsw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -628,11 +641,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
         }
       }
     };
-    if (kh == 0) walk_m(IC<0>{}); else walk_m(IC<1>{});
-    if (kh > 0) {                                         // split 1 publishes its partial; split 0 adds it after the next barrier
-      float* x = xch + cur * XCH + (ql * 64 + lane) * 8;
-      *reinterpret_cast<float4*>(x) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
-      *reinterpret_cast<float4*>(x + 4) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+    if (kh == 0) walk_m(IC<0>{}); else if (NS == 2 || kh == 1) walk_m(IC<1>{}); else walk_m(IC<NS - 1>{});
+    if (kh > 0) {                                         // parts 1.. publish their partials; part 0 adds them after the next barrier
+      unsigned char* x = xch + ((size_t)cur * XCH + (((kh - 1) * NQ + ql) * 64 + lane) * 8) * XB;
+      if (XF32) {
+        *reinterpret_cast<float4*>(x) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
+        *reinterpret_cast<float4*>(x + 16) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+      } else {
+        *reinterpret_cast<uint4*>(x) = make_uint4(pack_bf2(dq[0][0], dq[0][1]), pack_bf2(dq[0][2], dq[0][3]), pack_bf2(dq[1][0], dq[1][1]), pack_bf2(dq[1][2], dq[1][3]));
+      }
     }
   }
   __syncthreads();
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_win3_kernel(const vmvm_attn_b
           }
         }
       };
-      if (kh == 0) scatter(IC<0>{}); else scatter(IC<1>{});
+      if (kh == 0) scatter(IC<0>{}); else if (NS == 2 || kh == 1) scatter(IC<1>{}); else scatter(IC<NS - 1>{});
     }
     __syncthreads();
     for (int i = tid; i < 15 * 169; i += NWV * 64) {
@@ -923,22 +940,24 @@ __attribute__((visibility("hidden"))) int launch_fwd(const vmvm_attn_fwd_desc* d
 }
 
 __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st) {
-  constexpr int KV = 400 * 64, XCH = 4 * 64 * 8;
-  const int smem = 4 * KV + 2 * XCH * 4 + w3::TAB_BYTES;
+  constexpr int KV = 400 * 64;
   static const int nqg_env = getenv("VMVM_W3_DQ_GROUPS") ? atoi(getenv("VMVM_W3_DQ_GROUPS")) : 7;
+  // Key parts per query tile: 2.  Three (12 waves = 3 per SIMD, 9 running-sum slots per wave, bf16 partials, no fragment prefetch: 168
+  // registers with 3-20 spilled) measured 15 % SLOWER at every stage (profiles/r04_ab_dq_win3_three_parts.txt); the kernel stays generic in NS.
+  constexpr int ns = 2;
+  const int smem = 4 * KV + 2 * (ns - 1) * 4 * 64 * 8 * (ns == 2 ? 4 : 2) + w3::TAB_BYTES;
   const int nqg = nqg_env == 8 ? 8 : 7;
   const int base = d->f.heads * nqg;
   const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
   const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 10.f);
-  if (d->f.region) {
-    int rc_ = w3_set_smem(attn_bwd_dq_win3_kernel<true>, smem);
-    if (rc_) return rc_;
-    hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<true>), dim3(base * nch), dim3(512), smem, st, *d, nqg, nch);
-  } else {
-    int rc_ = w3_set_smem(attn_bwd_dq_win3_kernel<false>, smem);
-    if (rc_) return rc_;
-    hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<false>), dim3(base * nch), dim3(512), smem, st, *d, nqg, nch);
-  }
+  const bool mask = d->f.region != nullptr;
+#define W3_LAUNCH_DQ(MASK, NS_)                                                                                       \
+  do {                                                                                                               \
+    int rc_ = w3_set_smem(attn_bwd_dq_win3_kernel<MASK, NS_>, smem);                                                  \
+    if (rc_) return rc_;                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<MASK, NS_>), dim3(base * nch), dim3(4 * NS_ * 64), smem, st, *d, nqg, nch); \
+  } while (0)
+  if (mask) W3_LAUNCH_DQ(true, 2); else W3_LAUNCH_DQ(false, 2);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

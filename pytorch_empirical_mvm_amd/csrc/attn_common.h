@@ -234,19 +234,18 @@ __device__ __forceinline__ float zero_where(float a, uint64_t m) {
   asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(m));
   return d;
 }
-// lanes 0-7 of the result := the four 64-bit lane masks m0..m3 as eight dwords (m0 low, m0 high, m1 low, ...), other lanes 0.
-// HAZARD (measured, tools/probe/writelane_probe.hip): v_writelane_b32 reading an SGPR that the VALU instruction in front of it wrote (a
-// v_cmp into an SGPR pair or VCC) gets the register's PREVIOUS value; hipcc inserts the wait states for its own v_writelane but not in
-// front of inline asm.  One s_nop 4 in front of the eight writes covers every mask (they are all inputs of the block).
-__device__ __forceinline__ uint32_t lane_masks_record(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
-  uint32_t v = 0;
-  asm("s_nop 4\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
-      "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
-      : "+v"(v)
-      : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)), "s"((uint32_t)m2), "s"((uint32_t)(m2 >> 32)),
-        "s"((uint32_t)m3), "s"((uint32_t)(m3 >> 32)));
-  return v;
+// The four 64-bit lane masks m0..m3 of a score tile's dropout compares to base[off .. off + 32) -- eight dwords (m0 low, m0 high, m1 low,
+// ...) -- by SCALAR stores: the masks are wave-uniform SGPR pairs (v_cmp destinations), so the record costs no vector instruction.
+// (A first version moved them into lanes 0-7 of a VGPR with eight v_writelane_b32 + one vector store: +17 % on the forward kernel, and
+// it ran into a hardware hazard -- v_writelane_b32 reading an SGPR that the VALU instruction in front of it wrote gets the register's
+// PREVIOUS value, tools/probe/writelane_probe.hip / profiles/r04_probe_writelane_sgpr_hazard.txt.)  s_nop 4: the wait states between a
+// VALU write of an SGPR and a memory instruction that reads it (the compiler does not see inside the asm).  The scalar data cache is
+// written back by scalar_stores_done() before the wave ends; the consumers are later kernels.
+__device__ __forceinline__ void store_lane_masks(const uint32_t* base, const int off, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+  asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %4, %5\n\ts_store_dwordx2 %1, %4, %6\n\ts_store_dwordx2 %2, %4, %7\n\ts_store_dwordx2 %3, %4, %8"
+               :: "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(base), "i"(off), "i"(off + 8), "i"(off + 16), "i"(off + 24) : "memory");
 }
+__device__ __forceinline__ void scalar_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 // The four lanes of a quad (4 consecutive query rows in the forward / dQ layout, 4 consecutive keys in the dK/dV layout) need the
 // SAME 4x4 block of random bytes for a tile, so one Philox evaluation per tile wastes 3/4 of the wave's work.  Instead quad lane i

@@ -50,8 +50,8 @@ constexpr TileList list_all(int m4) {
   return l;
 }
 // the part `part` of `nparts` of every class in m4 (each class is cut into nparts runs whose sizes differ by at most one; which
-// parts get a class's longer runs rotates (ROT) so the parts come out even: 4 parts = 7 / 6 / 6 / 6 tiles, 2 parts = 13 / 12)
-constexpr int ROT[4] = {0, 0, 2, 0};
+// parts get a class's longer runs rotates (ROT) so the parts come out even: 4 parts = 7 / 6 / 6 / 6 tiles, 3 parts = 8 / 9 / 8, 2 parts = 13 / 12)
+constexpr int ROT[4] = {0, 0, 2, 4};             // (used modulo nparts: class D rotates by one only for three parts -> 8 / 9 / 8 tiles)
 constexpr int part_len(int c, int part, int nparts) {
   const int n = CB[c + 1] - CB[c], q = n / nparts, r = n % nparts;
   return q + ((((part + nparts - ROT[c] % nparts) % nparts) < r) ? 1 : 0);
@@ -69,6 +69,11 @@ constexpr TileList list_part(int m4, int part, int nparts) {
   return l;
 }
 // index of tile t inside the part's full (mask 15) list: where its running sums live
+constexpr int max_part(int nparts) {                 // tiles of the longest part (mask 15)
+  int m = 0;
+  for (int p = 0; p < nparts; ++p) { const int n = list_part(15, p, nparts).n; m = n > m ? n : m; }
+  return m;
+}
 constexpr int slot_in_part(int t, int part, int nparts) {
   const TileList l = list_part(15, part, nparts);
   for (int i = 0; i < l.n; ++i)

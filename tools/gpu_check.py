@@ -883,6 +883,15 @@ def check_gemm_fp8():
 
 # ------------------------------------------------------------------ misc
 def check_misc():
+    # VTM pair-score cross entropy + its f32 gradient (vmvm_vtm_ce) against torch in fp32: B clips x O candidates, class 0 = the positive
+    for (B_, O_) in [(32, 4), (5, 3), (700, 4)]:
+        lg = (torch.randn(B_, O_, device=dev) * 3.0).requires_grad_(True)
+        ls = torch.nn.functional.cross_entropy(lg, torch.zeros(B_, dtype=torch.int64, device=dev))
+        ls.backward()
+        acc = torch.full((1,), 0.25, device=dev)
+        dlg = K.vtm_ce(lg.detach().reshape(-1).contiguous(), B_, O_, acc)
+        rep(f"vtm_ce loss B={B_} O={O_} (accumulated onto 0.25)", acc, ls.detach().view(1) + 0.25, tol=1e-5)
+        rep(f"vtm_ce dlogits B={B_} O={O_}", dlg.view(B_, O_), lg.grad, tol=1e-5)
     B, T, H, W = 2, 4, 64, 96
     img = torch.randn(B, T, 3, H, W, device=dev)
     cols = K.patch_im2col(img)
