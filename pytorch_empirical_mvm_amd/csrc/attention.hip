@@ -2344,6 +2344,13 @@ int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w3
 
+// A/B switches of the win_layout = 1 kernels, read once: VMVM_NO_WIN3 (all), VMVM_NO_WIN3_FWD (1), VMVM_NO_WIN3_DQ (2) fall back to the
+// order-agnostic win2 kernels on the same layout (tools/scratch/ab_win3*.sh)
+static bool w3_off(int which) {
+  static const int bits = (getenv("VMVM_NO_WIN3") ? 7 : 0) | (getenv("VMVM_NO_WIN3_FWD") ? 2 : 0) | (getenv("VMVM_NO_WIN3_DQ") ? 4 : 0);
+  return (bits >> which) & 1;
+}
+
 #define LAUNCH_FWD(HD, MODE, NTM, NW, NX, MASK)                                              \
   do {                                                                                       \
     int rc_ = set_smem(attn_fwd_kernel<HD, MODE, NTM, NW, NX, MASK>, sm.total);              \
@@ -2381,7 +2388,7 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     const int npk = (sm.nt + 1) / 2, tl4 = (d->table_len + 3) & ~3, lr4 = (d->L + 3) & ~3;
     const int smem2 = 4 * npk * 32 * 64 + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->nseq % nwin == 0) && (sm.nt == 25 || sm.nt == 13) && d->dropout_p == 0.f && smem2 <= 160 * 1024;
-    if (vmvm_w3::applicable(d) && !d->att_colsum && !getenv("VMVM_NO_WIN3") && !getenv("VMVM_NO_WIN3_FWD")) {
+    if (vmvm_w3::applicable(d) && !d->att_colsum && !w3_off(1)) {
       int rc_ = vmvm_w3::launch_fwd(d, st);
       if (rc_) return rc_;
     } else if (pers_ok) {
@@ -2524,8 +2531,8 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
     const int tl4 = (d->f.table_len + 3) & ~3, lr4 = (d->f.L + 3) & ~3;
     const int smem2 = 4 * lp32 * 64 + 2 * tl4 * 4 + 2 * (ns - 1) * nq * 64 * 8 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && smem2 <= 160 * 1024;
-    const bool w3 = vmvm_w3::applicable(&d->f) && !getenv("VMVM_NO_WIN3");
-    if (w3 && !getenv("VMVM_NO_WIN3_DQ")) {
+    const bool w3 = vmvm_w3::applicable(&d->f) && !w3_off(0);
+    if (w3 && !w3_off(2)) {
       int rc_ = vmvm_w3::launch_dq(d, st);
       if (rc_) return rc_;
     } else if (pers_ok) {
@@ -2561,7 +2568,7 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       const int npq = (s_.nt + 1) / 2, img = npq * 32 * 64;
       const int smem3 = 2 * (2 * img + 2 * 512 * 4) + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
       const bool dkv_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && d->f.L <= 512 && smem3 <= 160 * 1024;
-      if (vmvm_w3::applicable(&d->f) && !getenv("VMVM_NO_WIN3")) {
+      if (vmvm_w3::applicable(&d->f) && !w3_off(0)) {
         int rc_ = vmvm_w3::launch_dkv(d, st);
         if (rc_) return rc_;
       } else if (dkv_ok) {

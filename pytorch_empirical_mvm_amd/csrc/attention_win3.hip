@@ -941,12 +941,11 @@ __attribute__((visibility("hidden"))) int launch_fwd(const vmvm_attn_fwd_desc* d
 
 __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st) {
   constexpr int KV = 400 * 64;
-  static const int nqg_env = getenv("VMVM_W3_DQ_GROUPS") ? atoi(getenv("VMVM_W3_DQ_GROUPS")) : 7;
   // Key parts per query tile: 2.  Three (12 waves = 3 per SIMD, 9 running-sum slots per wave, bf16 partials, no fragment prefetch: 168
   // registers with 3-20 spilled) measured 15 % SLOWER at every stage (profiles/r04_ab_dq_win3_three_parts.txt); the kernel stays generic in NS.
   constexpr int ns = 2;
   const int smem = 4 * KV + 2 * (ns - 1) * 4 * 64 * 8 * (ns == 2 ? 4 : 2) + w3::TAB_BYTES;
-  const int nqg = nqg_env == 8 ? 8 : 7;
+  const int nqg = 7;                      // query groups of 4 tiles (4,4,4,4,4,4,1); 8 groups of 3-4 tiles measured the same (round 4), the kernel takes either
   const int base = d->f.heads * nqg;
   const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
   const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 10.f);
@@ -965,8 +964,9 @@ __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d,
 __attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st) {
   constexpr int IMG = 400 * 64, BUF = 2 * IMG + 2 * 512 * 4;
   const int smem = 2 * BUF + w3::TAB_BYTES;
-  static const int nwv = getenv("VMVM_W3_DKV_WAVES") ? atoi(getenv("VMVM_W3_DKV_WAVES")) : 8;
-  const int base = d->f.heads * (nwv == 12 ? 1 : 2);
+  // 8 waves x two key tiles, two key groups per head.  (12 waves on ONE group -- three waves per SIMD, 24 of the 25 key tiles -- measured
+  // -15 % before the cost of the odd tile, profiles/r04_window_attention_dkv_win3_anatomy.txt section 5; the kernel is generic in NWV.)
+  const int base = d->f.heads * 2;
   const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
   const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 4.f);
   const bool mask = d->f.region != nullptr;
@@ -976,8 +976,7 @@ __attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d
     if (rc_) return rc_;                                                                                             \
     hipLaunchKernelGGL((attn_bwd_dkv_win3_kernel<MASK, NWV>), dim3(base * nch), dim3(NWV * 64), smem, st, *d, nch);   \
   } while (0)
-  if (nwv == 12) { if (mask) W3_LAUNCH_DKV(true, 12); else W3_LAUNCH_DKV(false, 12); }
-  else { if (mask) W3_LAUNCH_DKV(true, 8); else W3_LAUNCH_DKV(false, 8); }
+  if (mask) W3_LAUNCH_DKV(true, 8); else W3_LAUNCH_DKV(false, 8);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
