@@ -1399,7 +1399,9 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     if (!pays && epi_need(dd) == 0 && dd.K >= 768 && dd.N >= 256 && tiles >= 384) pays = true;
     // GELU forward with its second output (saved pre-activation / 8-bit code): the 128x128 kernel's epilogue of one workgroup runs under
     // the main loop of the other one on the CU, and since its stores are re-tiled it beats the ping-pong kernel's exposed store tail at
-    // K < 2048 (55296 x 3072 x 768: 367 -> 348 us, tools/scratch/no_pp_compare.sh)
+    // K < 2048 (55296 x 3072 x 768: 367 -> 348 us, tools/scratch/no_pp_compare.sh).  Re-measured after the round-4 epilogue diet
+    // (tools/scratch/fc1_pp_vs_pers.py): the two kernels are within 1-3 % on this class (69120 x 3072 x 768: 429-454 vs 426-440 us) and the
+    // step does not tell them apart (108.8 ms either way) -- the rule stays.
     if ((epi_need(dd) & EF_ACT1) && dd.C2 && dd.K < 2048) pays = false;
     // Round quantisation of the one-workgroup-per-CU grid: 69120 x 768 is 810 tiles = 3.16 rounds of 256, i.e. a fourth round for 54
     // tiles.  For long reductions the rows that fill WHOLE rounds go to the ping-pong kernel and the remaining rows (a short second
