@@ -1,0 +1,321 @@
+// attention_fused.hip -- the fusion encoder's attention backward (mode 1: 432-token sequences, head_dim 64, key mask, attention dropout
+// with the forward's stored decisions) in ONE pass: scores, probabilities and dS are computed once per score tile and feed dV, dK AND dQ.
+// The two-kernel form of attention.hip computes S and dP twice (14 MFMAs + two softmax chains + two mask evaluations per score tile);
+// here it is 10 + one + one.  HF BertSelfAttention backward via model.py:204-214.
+//
+// STATUS (round 4): parity-green (tools/gpu_check.py attnb under VMVM_FUSED_BWD=1, tests/test_kernels_gpu.py), OPT-IN: 0.62 / 0.70 ms per
+// layer (without / with dropout) against 0.57 / 0.67 of the two-kernel form.  Where its time goes (ablation builds,
+// profiles/r04_fused_attention_backward.txt): 0.16 ms is fixed cost per workgroup -- launch, the delta prologue, two K-image fills and
+// their waits, with ONE workgroup per CU (85 KB of LDS, 200-230 registers) nothing overlaps them --, 0.12 ms the per-pair barrier + the dQ
+// product, 0.35 ms the products and the chain.  What would make it win: workgroups persistent over (sequence, head) items with the next
+// item's K image / fragments / delta requested during the current item's last pairs (the window kernels' structure).
+//
+// A workgroup = one (sequence, head), 8 waves.  The 27 key tiles are walked in two passes (tiles 0-15, 16-26); in a pass wave w owns
+// key tiles w and w + 8 (K / V fragments and the dK / dV accumulators in registers) and walks the 14 query-tile PAIRS, whose Q / dO rows
+// stream through a double-buffered 2 x 8 KB LDS image (through registers, three pairs deep -- see load_pair).  dQ needs dS contracted over
+// KEYS, i.e. across the key-owner waves: every wave leaves its bf16 dS tiles in a [key][32 queries] LDS image (the transposed form costs
+// one 8-byte write per tile), and each of the 8 waves multiplies one (query tile, 16-column head_dim block) of dQ = dS K over the pass's
+// keys -- dS through transposing reads of that image, K through transposing reads of the pass's K rows (32 KB image) -- one pair late, in
+// front of the next pair's barrier.  One barrier per query-tile pair; the second pass adds its dQ to the first one's (the same lane owns
+// the same elements in both passes).  LDS: 16 (Q / dO) + 32 (K rows of the pass) + 32 (dS, double-buffered) + 5.3 (lse, delta, key mask).
+#include "attn_common.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int FH = 64, FNT = 27, FL = 432, FNW = 8, FNP = 14;          // head_dim, tiles, tokens, waves, query-tile pairs
+constexpr int F_QD = 32 * 128;                                          // bytes of one 32-row Q or dO image
+constexpr int F_KP = 256 * 128, F_DS = 256 * 64;
+constexpr int F_OFF_QD = 0, F_OFF_KP = 4 * F_QD, F_OFF_DS = F_OFF_KP + F_KP, F_OFF_LSE = F_OFF_DS + 2 * F_DS;
+constexpr int F_SMEM = F_OFF_LSE + 3 * 448 * 4;
+
+template <int DROPM>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd_desc pb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int heads = p.heads;
+  const int logical = xcd_remap(blockIdx.x, p.nseq * heads);
+  const int seq = logical / heads, h = logical - seq * heads;
+  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * FL * p.ld_qkv;
+  const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * FL * pb.ld_dout + h * FH;
+  const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * FL * p.ld_out + h * FH;
+  u16* dqkv = reinterpret_cast<u16*>(pb.dqkv) + (size_t)seq * FL * pb.ld_dqkv;
+  unsigned char* KP = smem + F_OFF_KP;
+  float* lse_s = reinterpret_cast<float*>(smem + F_OFF_LSE);
+  float* delta_s = lse_s + 448;
+  float* kb_s = delta_s + 448;
+
+  // ---- per-sequence vectors: lse (log2 units; +inf on the padding rows -> P = 0), delta = sum_d dO O, additive key mask.
+  // delta: 8 lanes per row (16 bytes each: whole 128-byte rows per request), 64 rows per sweep of the workgroup, all 7 sweeps in flight
+  {
+    const float* lse_g = p.lse + ((size_t)seq * heads + h) * FL;
+    float part[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int row = i * 64 + (tid >> 3);
+      float dl = 0.f;
+      if (row < FL) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dO + (size_t)row * pb.ld_dout + (tid & 7) * 8));
+        const bf16x8 y = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(O + (size_t)row * p.ld_out + (tid & 7) * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)x[e] * (float)y[e];
+      }
+      part[i] = dl;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      float dl = part[i];
+      dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+      const int row = i * 64 + (tid >> 3);
+      if ((tid & 7) == 0) delta_s[row] = dl;              // (rows 432..447: zero)
+    }
+    for (int i = tid; i < 448; i += FNW * 64) {
+      lse_s[i] = i < FL ? lse_g[i] * 1.4426950408889634f : __builtin_huge_valf();
+      kb_s[i] = (i < FL && (p.keymask ? p.keymask[(size_t)seq * FL + i] != 0 : true)) ? 0.f : NEG_INF;
+    }
+  }
+  const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
+  const uint32_t thr16 = drop_thr16(p.dropout_p);
+  const float keep = DROPM ? 65536.f / (65536.f - (float)thr16) : 1.f;
+  const float sc2 = p.scale * 1.4426950408889634f, cdk = seq_scale * keep;
+  const int mshift = 16 * ((r >> 2) & 1) + 4 * g;         // stored decisions: see attn_bwd_dkv_kernel
+  const uint32_t* mbase = DROPM == 2 ? p.drop_mask + (size_t)(seq * heads + h) * FNT * FNT * 8 + 2 * (r & 3) + (r >> 3) : nullptr;
+  const int qu = wave >> 2, hb = wave & 3;                // dQ phase: this wave's (query tile of the pair, 16-column head_dim block)
+
+  // Q / dO rows of query-tile pair c -> buffer (c & 1): 32 rows x 8 chunks x 2 images = 512 pieces of 16 bytes, one per thread.  They
+  // travel through REGISTERS (a global load at the top of the previous pair, one ds_write_b128 in front of that pair's barrier): a
+  // direct-to-LDS DMA in flight makes the compiler drain vmcnt in front of every LDS read of the main phase, i.e. wait for the prefetch.
+  const int f_img = tid >> 8, f_u = tid & 255, f_row = f_u >> 3, f_ch = f_u & 7;      // threads 0-255: Q, 256-511: dO
+  const u16* f_src = f_img ? dO + f_ch * 8 : qkv + p.q_off + h * FH + f_ch * 8;
+  const int f_ld = f_img ? pb.ld_dout : p.ld_qkv;
+  const int f_dst = F_OFF_QD + f_img * F_QD + k_off_swz<64>(f_row, f_ch);
+  auto load_pair = [&](int c) {
+    const int grow = c * 32 + f_row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (grow < FL) v = *reinterpret_cast<const uint4*>(f_src + (size_t)grow * f_ld);
+    return v;
+  };
+  auto store_pair = [&](int c, const uint4& v) { *reinterpret_cast<uint4*>(smem + f_dst + (c & 1) * 2 * F_QD) = v; };
+
+  // Lane-constant LDS offsets: with the swizzle in them the compiler re-derives every address per access inside the pair loop (measured:
+  // 375 VALU instructions per iteration, two thirds of them address arithmetic); everything below is one of these + an immediate.
+  const int aQ0 = F_OFF_QD + k_off_swz<64>(r, g), aQ1 = F_OFF_QD + k_off_swz<64>(r, 4 + g);              // + 2048 u, + F_QD for dO, + buffer
+  int aT[4];                                                                                                 // transposing reads of the pair images: + 2048 for tokens 16.., + F_QD, + buffer
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) aT[dt] = F_OFF_QD + k_off_swz<64>(g * 4 + (r >> 2), dt * 2 + ((r & 3) >> 1)) + (r & 1) * 8;
+  const int aKP = F_OFF_KP + k_off_swz<64>(g * 4 + (r >> 2), hb * 2 + ((r & 3) >> 1)) + (r & 1) * 8;   // + 4096 ks, + 2048 for tokens 16..
+  const int aDSr = F_OFF_DS + k_off_swz<32>(g * 4 + (r >> 2), qu * 2 + ((r & 3) >> 1)) + (r & 1) * 8;  // + 2048 ks, + 1024 for tokens 16.., + buffer
+  const int aDSw0 = F_OFF_DS + k_off_swz<32>(wave * 16 + r, g >> 1) + (g & 1) * 8;                        // + 8192 t, + buffer
+  const int aDSw1 = F_OFF_DS + k_off_swz<32>(wave * 16 + r, 2 + (g >> 1)) + (g & 1) * 8;
+  const int aL = F_OFF_LSE + g * 16;                                                                         // + 128 c + 64 u; delta: + 1792
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr2 = [&](const unsigned char* pa, const int off) {                                                  // k-slots 0-3: 4 rows at pa + off, 4-7: 16 rows further
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + off + 2048));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto tr2h = [&](const unsigned char* pa, const int off) {                                                 // the same on the 64-byte rows of the dS image
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + off + 1024));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  for (int ps = 0; ps < 2; ++ps) {
+    __syncthreads();                                      // (pass 1: every wave has left pass 0's images; pass 0: the vectors above are written)
+    {                                                     // K rows [256 ps, 256 ps + 256) of this head (rows >= 432 read as zeros)
+      const int base = ps * 256;
+      fill_rowmajor<64>(KP, qkv + (size_t)base * p.ld_qkv + p.k_off + h * FH, p.ld_qkv, FL - base, 256, tid, FNW * 64);
+    }
+    const uint4 nq0 = load_pair(0);
+    uint4 nq1 = load_pair(1), nq2 = load_pair(2);         // register queue: pairs c + 1 and c + 2 (an iteration is shorter than a memory latency)
+    int kt[2]; bool kv[2];
+    bf16x8 kf[2][2], vf[2][2];
+    float kbk[2];
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      kt[t] = ps * 16 + wave + 8 * t;
+      kv[t] = kt[t] < FNT;
+      const int key = kt[t] * 16 + r;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kf[t][s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.k_off + h * FH + g * 8 + s * 32, kv[t]);
+        vf[t][s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.v_off + h * FH + g * 8 + s * 32, kv[t]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    auto load_words = [&](int c, uint32_t (&w)[2][2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          w[u][t] = 0u;
+          if (DROPM == 2 && 2 * c + u < FNT && kv[t]) w[u][t] = mbase[((size_t)(2 * c + u) * FNT + kt[t]) * 8];
+        }
+    };
+    uint32_t wq1[2][2], wq2[2][2];
+    load_words(0, wq1); load_words(1, wq2);
+    store_pair(0, nq0);
+    fill_wait();
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) kbk[t] = kv[t] ? kb_s[kt[t] * 16 + r] : NEG_INF;
+    const int nks = ps == 0 ? 8 : 6;                      // 32-key steps of the dQ product over this pass's key slots
+
+    auto dq_phase = [&](const int cc) {
+      // ---- dQ of (query tile 2 cc + qu, head_dim block hb) over this pass's keys: runs one pair LATE (after the next pair's main phase, in
+      // front of its barrier), so the barrier does not stand between a pair's products and its dQ work
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) {                   // (pass 1: key slots 12-15 hold zeros in both images -- steps 6, 7 add nothing)
+        if (ks < nks) {
+          const unsigned char* pk = smem + aKP;
+          const unsigned char* pd = smem + aDSr + (cc & 1) * F_DS;
+          const bf16x8 kT = tr2(pk, ks * 4096), dsT = tr2h(pd, ks * 2048);
+          const bf16x8 kT1 = tr2(pk, ks * 4096 + 4096), dsT1 = tr2h(pd, ks * 2048 + 2048);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsT, acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT1, dsT1, acc1, 0, 0, 0);
+        }
+      }
+      acc += acc1;
+      const int q = cc * 32 + qu * 16 + r;                 // lane: head_dim hb * 16 + 4 g + j of query q
+      if (q < FL) {
+        u16* dqp = dqkv + (size_t)q * pb.ld_dqkv + p.q_off + h * FH + hb * 16 + g * 4;
+        float v0 = acc[0] * p.scale, v1 = acc[1] * p.scale, v2 = acc[2] * p.scale, v3 = acc[3] * p.scale;
+        if (ps == 1) {
+          const uint2 old = *reinterpret_cast<const uint2*>(dqp);
+          v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+          v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2*>(dqp) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+      }
+    };
+#pragma unroll 1
+    for (int c = 0; c < FNP; ++c) {
+      uint4 nq3 = make_uint4(0, 0, 0, 0);
+      if (c + 3 < FNP) nq3 = load_pair(c + 3);
+      const int bq = (c & 1) * 2 * F_QD, bd = (c & 1) * F_DS;
+      const unsigned char* pQ0 = smem + aQ0 + bq;
+      const unsigned char* pQ1 = smem + aQ1 + bq;
+      const unsigned char* pL = smem + aL + c * 128;
+      unsigned char* pW0 = smem + aDSw0 + bd;
+      unsigned char* pW1 = smem + aDSw1 + bd;
+      // stored dropout decisions of the four score tiles of this pair (requested two pairs ahead)
+      uint32_t wm[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { wm[u][t] = wq1[u][t]; wq1[u][t] = wq2[u][t]; }
+      load_words(c + 2, wq2);
+      float pt[2][2][4], ds[2][2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 s4[2], dp4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { s4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp4[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned char* pq = (s ? pQ1 : pQ0) + u * 2048;
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(pq);
+          const bf16x8 dof = *reinterpret_cast<const bf16x8*>(pq + F_QD);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            s4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[t][s], s4[t], 0, 0, 0);
+            dp4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[t][s], dp4[t], 0, 0, 0);
+          }
+        }
+        // lane holds (query = 32 c + 16 u + 4 g + j, key of tile t = r)
+        const float4 l4 = *reinterpret_cast<const float4*>(pL + u * 64);
+        const float4 d4 = *reinterpret_cast<const float4*>(pL + u * 64 + 448 * 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x2 off01 = f32x2{kbk[t], kbk[t]} - f32x2{l4.x, l4.y}, off23 = f32x2{kbk[t], kbk[t]} - f32x2{l4.z, l4.w};
+          const f32x2 x01 = __builtin_elementwise_fma(f32x2{s4[t][0], s4[t][1]}, f32x2{sc2, sc2}, off01);
+          const f32x2 x23 = __builtin_elementwise_fma(f32x2{s4[t][2], s4[t][3]}, f32x2{sc2, sc2}, off23);
+          const float pr[4] = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1]), __builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+          const f32x2 c2 = f32x2{cdk, cdk};
+          const f32x2 d01 = f32x2{dp4[t][0], dp4[t][1]} * c2, d23 = f32x2{dp4[t][2], dp4[t][3]} * c2;
+          float pj[4] = {pr[0], pr[1], pr[2], pr[3]};
+          if (DROPM == 2) {
+            const uint32_t kept = ~(wm[u][t] >> mshift);                     // bit j: element j is kept
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pj[j] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pj[j]) & (uint32_t)__builtin_amdgcn_sbfe((int)kept, j, 1));
+          }
+          // dS = (mask * P) * dP - P * delta
+          const f32x2 o01 = __builtin_elementwise_fma(f32x2{pj[0], pj[1]}, d01, -(f32x2{pr[0], pr[1]} * f32x2{d4.x, d4.y}));
+          const f32x2 o23 = __builtin_elementwise_fma(f32x2{pj[2], pj[3]}, d23, -(f32x2{pr[2], pr[3]} * f32x2{d4.z, d4.w}));
+          pt[t][u][0] = pj[0]; pt[t][u][1] = pj[1]; pt[t][u][2] = pj[2]; pt[t][u][3] = pj[3];
+          ds[t][u][0] = o01[0]; ds[t][u][1] = o01[1]; ds[t][u][2] = o23[0]; ds[t][u][3] = o23[1];
+          // dS^T into the exchange image: row = this lane's key slot, 4 consecutive queries = 8 bytes
+          *reinterpret_cast<uint2*>((u ? pW1 : pW0) + t * 8192) = make_uint2(pack_bf2(o01[0], o01[1]), pack_bf2(o23[0], o23[1]));
+        }
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { pf[t] = frag_from_f32(pt[t][0], pt[t][1]); dsf[t] = frag_from_f32(ds[t][0], ds[t][1]); }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned char* pt_ = smem + aT[dt] + bq;
+        const bf16x8 doT = tr2(pt_, F_QD);
+        const bf16x8 qT = tr2(pt_, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pf[t], dv[t][dt], 0, 0, 0);
+          dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsf[t], dk[t][dt], 0, 0, 0);
+        }
+      }
+      if (c > 0) dq_phase(c - 1);
+      if (c + 1 < FNP) store_pair(c + 1, nq1);             // (that buffer was last read in the main phase of pair c - 1: every wave is past its barrier)
+      nq1 = nq2; nq2 = nq3;
+      __syncthreads();                                    // the pair's dS tiles and pair c + 1's Q / dO rows are complete
+    }
+    dq_phase(FNP - 1);
+    // ---- dK / dV of this pass's key tiles
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (kv[t]) {
+        u16* base = dqkv + (size_t)(kt[t] * 16 + r) * pb.ld_dqkv + h * FH + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
+              make_uint2(pack_bf2(dk[t][dt][0] * p.scale, dk[t][dt][1] * p.scale), pack_bf2(dk[t][dt][2] * p.scale, dk[t][dt][3] * p.scale));
+          *reinterpret_cast<uint2*>(base + p.v_off + dt * 16) =
+              make_uint2(pack_bf2(dv[t][dt][0] * cdk, dv[t][dt][1] * cdk), pack_bf2(dv[t][dt][2] * cdk, dv[t][dt][3] * cdk));
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // pass 0's dQ stores are complete before pass 1 reads them back
+  }
+}
+
+}  // namespace
+
+namespace vmvm_fused {
+
+// the problems this kernel takes: the fusion encoder's exact shape, plain key mask, dropout off or with the forward's stored decisions
+__attribute__((visibility("hidden"))) bool applicable(const vmvm_attn_bwd_desc* d) {
+  const vmvm_attn_fwd_desc& f = d->f;
+  return f.mode == 1 && f.head_dim == 64 && f.L == FL && f.causal_from <= 0 && !(f.stream_min_len > 0 && f.L >= f.stream_min_len) &&
+         (f.dropout_p == 0.f || f.drop_mask != nullptr) && !d->dbias_table && (f.ld_qkv & 7) == 0 && (d->ld_dout & 7) == 0 && (f.ld_out & 7) == 0;
+}
+
+__attribute__((visibility("hidden"))) int launch(const vmvm_attn_bwd_desc* d, hipStream_t st) {
+  const int nb = d->f.nseq * d->f.heads;
+  if (d->f.dropout_p > 0.f) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess) return VMVM_EHIP;
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<2>), dim3(nb), dim3(512), F_SMEM, st, *d);
+  } else {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess) return VMVM_EHIP;
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<0>), dim3(nb), dim3(512), F_SMEM, st, *d);
+  }
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
+}  // namespace vmvm_fused
