@@ -3,14 +3,16 @@
 // The two-kernel form of attention.hip computes S and dP twice (14 MFMAs + two softmax chains + two mask evaluations per score tile);
 // here it is 10 + one + one.  HF BertSelfAttention backward via model.py:204-214.
 //
-// STATUS (round 4): parity-green (tools/gpu_check.py attnb under VMVM_FUSED_BWD=1, tests/test_kernels_gpu.py), OPT-IN: 0.62 / 0.70 ms per
-// layer (without / with dropout) against 0.57 / 0.67 of the two-kernel form.  Where its time goes (ablation builds,
-// profiles/r04_fused_attention_backward.txt): 0.16 ms is fixed cost per workgroup -- launch, the delta prologue, two K-image fills and
-// their waits, with ONE workgroup per CU (85 KB of LDS, 200-230 registers) nothing overlaps them --, 0.12 ms the per-pair barrier + the dQ
-// product, 0.35 ms the products and the chain.  What would make it win: workgroups persistent over (sequence, head) items with the next
-// item's K image / fragments / delta requested during the current item's last pairs (the window kernels' structure).
+// STATUS (round 4): parity-green (tools/gpu_check.py attnb under VMVM_FUSED_BWD=1), OPT-IN: 0.63 / 0.68 ms per layer (without / with
+// dropout) against 0.57 / 0.67 of the two-kernel form -- on a par with dropout, 10 % slower without.  profiles/r04_fused_attention_backward.txt
+// has the history: the first version spent a quarter of its time in fixed cost per workgroup (launch, delta prologue, two K-image fills
+// with nothing to overlap them: one workgroup per CU), so the workgroups are now PERSISTENT over (sequence, head) items and request the
+// next stage's prologue piece by piece during the current stage's pairs -- which moved the time into the pair loop instead of removing
+// it (240-255 registers, a vmcnt(0) in front of every prologue write): per pair 3.0 us against ~1.3 us of MFMA + VALU + LDS work.  What
+// the two-kernel form has and this one lacks registers for: fully unrolled tile loops with the next pair's score MFMAs in flight under
+// the current pair's chain.  (dK / dV accumulators and K / V fragments of two key tiles per wave are 96 registers.)
 //
-// A workgroup = one (sequence, head), 8 waves.  The 27 key tiles are walked in two passes (tiles 0-15, 16-26); in a pass wave w owns
+// A persistent workgroup (one per CU) walks its (sequence, head) items; per item, 8 waves.  The 27 key tiles are walked in two passes (tiles 0-15, 16-26); in a pass wave w owns
 // key tiles w and w + 8 (K / V fragments and the dK / dV accumulators in registers) and walks the 14 query-tile PAIRS, whose Q / dO rows
 // stream through a double-buffered 2 x 8 KB LDS image (through registers, three pairs deep -- see load_pair).  dQ needs dS contracted over
 // KEYS, i.e. across the key-owner waves: every wave leaves its bf16 dS tiles in a [key][32 queries] LDS image (the transposed form costs
@@ -25,9 +27,9 @@ namespace {
 
 constexpr int FH = 64, FNT = 27, FL = 432, FNW = 8, FNP = 14;          // head_dim, tiles, tokens, waves, query-tile pairs
 constexpr int F_QD = 32 * 128;                                          // bytes of one 32-row Q or dO image
-constexpr int F_KP = 256 * 128, F_DS = 256 * 64;
-constexpr int F_OFF_QD = 0, F_OFF_KP = 4 * F_QD, F_OFF_DS = F_OFF_KP + F_KP, F_OFF_LSE = F_OFF_DS + 2 * F_DS;
-constexpr int F_SMEM = F_OFF_LSE + 3 * 448 * 4;
+constexpr int F_KP = 256 * 128, F_DS = 256 * 64, F_VEC = 3 * 448 * 4;   // K rows of a pass; dS^T exchange image; lse | delta | key mask of an item
+constexpr int F_OFF_QD = 0, F_OFF_KP = 4 * F_QD, F_OFF_DS = F_OFF_KP + 2 * F_KP, F_OFF_VEC = F_OFF_DS + 2 * F_DS;
+constexpr int F_SMEM = F_OFF_VEC + 2 * F_VEC;                           // 16 + 64 + 32 + 10.5 KB = 122.5 KB: one workgroup per CU
 
 template <int DROPM>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd_desc pb) {
@@ -36,80 +38,34 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int heads = p.heads;
-  const int logical = xcd_remap(blockIdx.x, p.nseq * heads);
-  const int seq = logical / heads, h = logical - seq * heads;
-  const u16* qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * FL * p.ld_qkv;
-  const u16* dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * FL * pb.ld_dout + h * FH;
-  const u16* O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * FL * p.ld_out + h * FH;
-  u16* dqkv = reinterpret_cast<u16*>(pb.dqkv) + (size_t)seq * FL * pb.ld_dqkv;
-  unsigned char* KP = smem + F_OFF_KP;
-  float* lse_s = reinterpret_cast<float*>(smem + F_OFF_LSE);
-  float* delta_s = lse_s + 448;
-  float* kb_s = delta_s + 448;
+  // ---- this workgroup's items (sequence, head): XCD x = blockIdx % 8 owns a contiguous range of items (the heads of a sequence share its
+  // qkv rows in that XCD's L2), its workgroups take them round-robin
+  const int nitems = p.nseq * heads;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int xs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xc = q8 + (xcd < r8 ? 1 : 0);
+  const int nmine = li < xc ? (xc - li + per_xcd - 1) / per_xcd : 0;
+  if (nmine == 0) return;
 
-  // ---- per-sequence vectors: lse (log2 units; +inf on the padding rows -> P = 0), delta = sum_d dO O, additive key mask.
-  // delta: 8 lanes per row (16 bytes each: whole 128-byte rows per request), 64 rows per sweep of the workgroup, all 7 sweeps in flight
-  {
-    const float* lse_g = p.lse + ((size_t)seq * heads + h) * FL;
-    float part[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int row = i * 64 + (tid >> 3);
-      float dl = 0.f;
-      if (row < FL) {
-        const bf16x8 x = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dO + (size_t)row * pb.ld_dout + (tid & 7) * 8));
-        const bf16x8 y = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(O + (size_t)row * p.ld_out + (tid & 7) * 8));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)x[e] * (float)y[e];
-      }
-      part[i] = dl;
-    }
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      float dl = part[i];
-      dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
-      const int row = i * 64 + (tid >> 3);
-      if ((tid & 7) == 0) delta_s[row] = dl;              // (rows 432..447: zero)
-    }
-    for (int i = tid; i < 448; i += FNW * 64) {
-      lse_s[i] = i < FL ? lse_g[i] * 1.4426950408889634f : __builtin_huge_valf();
-      kb_s[i] = (i < FL && (p.keymask ? p.keymask[(size_t)seq * FL + i] != 0 : true)) ? 0.f : NEG_INF;
-    }
-  }
-  const float seq_scale = p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f;
   const uint32_t thr16 = drop_thr16(p.dropout_p);
   const float keep = DROPM ? 65536.f / (65536.f - (float)thr16) : 1.f;
-  const float sc2 = p.scale * 1.4426950408889634f, cdk = seq_scale * keep;
+  const float sc2 = p.scale * 1.4426950408889634f;
   const int mshift = 16 * ((r >> 2) & 1) + 4 * g;         // stored decisions: see attn_bwd_dkv_kernel
-  const uint32_t* mbase = DROPM == 2 ? p.drop_mask + (size_t)(seq * heads + h) * FNT * FNT * 8 + 2 * (r & 3) + (r >> 3) : nullptr;
-  const int qu = wave >> 2, hb = wave & 3;                // dQ phase: this wave's (query tile of the pair, 16-column head_dim block)
-
-  // Q / dO rows of query-tile pair c -> buffer (c & 1): 32 rows x 8 chunks x 2 images = 512 pieces of 16 bytes, one per thread.  They
-  // travel through REGISTERS (a global load at the top of the previous pair, one ds_write_b128 in front of that pair's barrier): a
-  // direct-to-LDS DMA in flight makes the compiler drain vmcnt in front of every LDS read of the main phase, i.e. wait for the prefetch.
-  const int f_img = tid >> 8, f_u = tid & 255, f_row = f_u >> 3, f_ch = f_u & 7;      // threads 0-255: Q, 256-511: dO
-  const u16* f_src = f_img ? dO + f_ch * 8 : qkv + p.q_off + h * FH + f_ch * 8;
-  const int f_ld = f_img ? pb.ld_dout : p.ld_qkv;
-  const int f_dst = F_OFF_QD + f_img * F_QD + k_off_swz<64>(f_row, f_ch);
-  auto load_pair = [&](int c) {
-    const int grow = c * 32 + f_row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (grow < FL) v = *reinterpret_cast<const uint4*>(f_src + (size_t)grow * f_ld);
-    return v;
-  };
-  auto store_pair = [&](int c, const uint4& v) { *reinterpret_cast<uint4*>(smem + f_dst + (c & 1) * 2 * F_QD) = v; };
+  const int qu = wave >> 2, hb = wave & 3;                // dQ product: this wave's (query tile of the pair, 16-column head_dim block)
 
   // Lane-constant LDS offsets: with the swizzle in them the compiler re-derives every address per access inside the pair loop (measured:
   // 375 VALU instructions per iteration, two thirds of them address arithmetic); everything below is one of these + an immediate.
+  const int f_img = tid >> 8, f_u = tid & 255, f_row = f_u >> 3, f_ch = f_u & 7;      // pair images: threads 0-255 carry Q, 256-511 dO
+  const int f_dst = F_OFF_QD + f_img * F_QD + k_off_swz<64>(f_row, f_ch);
   const int aQ0 = F_OFF_QD + k_off_swz<64>(r, g), aQ1 = F_OFF_QD + k_off_swz<64>(r, 4 + g);              // + 2048 u, + F_QD for dO, + buffer
   int aT[4];                                                                                                 // transposing reads of the pair images: + 2048 for tokens 16.., + F_QD, + buffer
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) aT[dt] = F_OFF_QD + k_off_swz<64>(g * 4 + (r >> 2), dt * 2 + ((r & 3) >> 1)) + (r & 1) * 8;
-  const int aKP = F_OFF_KP + k_off_swz<64>(g * 4 + (r >> 2), hb * 2 + ((r & 3) >> 1)) + (r & 1) * 8;   // + 4096 ks, + 2048 for tokens 16..
+  const int aKP = F_OFF_KP + k_off_swz<64>(g * 4 + (r >> 2), hb * 2 + ((r & 3) >> 1)) + (r & 1) * 8;   // + 4096 ks, + 2048 for tokens 16.., + buffer
   const int aDSr = F_OFF_DS + k_off_swz<32>(g * 4 + (r >> 2), qu * 2 + ((r & 3) >> 1)) + (r & 1) * 8;  // + 2048 ks, + 1024 for tokens 16.., + buffer
   const int aDSw0 = F_OFF_DS + k_off_swz<32>(wave * 16 + r, g >> 1) + (g & 1) * 8;                        // + 8192 t, + buffer
   const int aDSw1 = F_OFF_DS + k_off_swz<32>(wave * 16 + r, 2 + (g >> 1)) + (g & 1) * 8;
-  const int aL = F_OFF_LSE + g * 16;                                                                         // + 128 c + 64 u; delta: + 1792
+  const int aL = F_OFF_VEC + g * 16;                                                                         // + 128 c + 64 u, + buffer; delta: + 1792
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   auto tr2 = [&](const unsigned char* pa, const int off) {                                                  // k-slots 0-3: 4 rows at pa + off, 4-7: 16 rows further
@@ -125,12 +81,91 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  for (int ps = 0; ps < 2; ++ps) {
-    __syncthreads();                                      // (pass 1: every wave has left pass 0's images; pass 0: the vectors above are written)
-    {                                                     // K rows [256 ps, 256 ps + 256) of this head (rows >= 432 read as zeros)
-      const int base = ps * 256;
-      fill_rowmajor<64>(KP, qkv + (size_t)base * p.ld_qkv + p.k_off + h * FH, p.ld_qkv, FL - base, 256, tid, FNW * 64);
+  // ---- everything an item's prologue needs, as functions of the item: the FIRST item runs them back to back, every later item's are
+  // spread over the pair loop of the stage in front of it (requests at one pair, LDS writes two pairs later)
+  struct Item { const u16* qkv; const u16* dO; const u16* O; u16* dqkv; const float* lse; const uint8_t* km; const uint32_t* mb; float cdk; };
+  auto item_of = [&](int k) {
+    const int it = xs + li + k * per_xcd;
+    const int seq = it / heads, h = it - seq * heads;
+    Item I;
+    I.qkv = reinterpret_cast<const u16*>(p.qkv) + (size_t)seq * FL * p.ld_qkv + h * FH;
+    I.dO = reinterpret_cast<const u16*>(pb.dout) + (size_t)seq * FL * pb.ld_dout + h * FH;
+    I.O = reinterpret_cast<const u16*>(p.out) + (size_t)seq * FL * p.ld_out + h * FH;
+    I.dqkv = reinterpret_cast<u16*>(pb.dqkv) + (size_t)seq * FL * pb.ld_dqkv + h * FH;
+    I.lse = p.lse + ((size_t)seq * heads + h) * FL;
+    I.km = p.keymask ? p.keymask + (size_t)seq * FL : nullptr;
+    I.mb = DROPM == 2 ? p.drop_mask + (size_t)it * FNT * FNT * 8 + 2 * (r & 3) + (r >> 3) : nullptr;
+    I.cdk = (p.seq_scale ? p.seq_scale[seq / p.seqs_per_scale] : 1.0f) * keep;
+    return I;
+  };
+  // K rows [256 ps, 256 ps + 256) of an item as 2048 16-byte pieces, piece u = 512 i + tid -> LDS slot u of the image (slot order = the
+  // swizzled chunk order of attn_common.h: slot (row, chs) holds source chunk chs ^ swz(row)); rows >= 432 are zeros
+  auto kimg_load = [&](const Item& I, int ps, int i) {
+    const int u = i * 512 + tid, row = u >> 3, chs = u & 7;
+    const int grow = ps * 256 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (grow < FL) v = *reinterpret_cast<const uint4*>(I.qkv + (size_t)grow * p.ld_qkv + p.k_off + ((chs ^ swz_chunk<64>(row)) << 3));
+    return v;
+  };
+  auto kimg_store = [&](int buf, int i, const uint4& v) { *reinterpret_cast<uint4*>(smem + F_OFF_KP + buf * F_KP + (size_t)(i * 512 + tid) * 16) = v; };
+  // delta = sum_d dO O: 8 lanes per row (16 bytes each), 64 rows per sweep, 7 sweeps
+  auto delta_load = [&](const Item& I, int sweep, uint4& x, uint4& y) {
+    const int row = sweep * 64 + (tid >> 3);
+    x = make_uint4(0, 0, 0, 0); y = make_uint4(0, 0, 0, 0);
+    if (row < FL) {
+      x = *reinterpret_cast<const uint4*>(I.dO + (size_t)row * pb.ld_dout + (tid & 7) * 8);
+      y = *reinterpret_cast<const uint4*>(I.O + (size_t)row * p.ld_out + (tid & 7) * 8);
     }
+  };
+  auto delta_store = [&](int vbuf, int sweep, const uint4& x, const uint4& y) {
+    const bf16x8 a = __builtin_bit_cast(bf16x8, x), b = __builtin_bit_cast(bf16x8, y);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)b[e];
+    dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+    if ((tid & 7) == 0) reinterpret_cast<float*>(smem + F_OFF_VEC + vbuf * F_VEC)[448 + sweep * 64 + (tid >> 3)] = dl;
+  };
+  // lse (log2 units; +inf on the padding rows -> P = 0) and the additive key mask: one entry per thread (tid < 448)
+  auto vec_load = [&](const Item& I, float& l, float& kb) {
+    l = __builtin_huge_valf(); kb = NEG_INF;
+    if (tid < FL) { l = I.lse[tid] * 1.4426950408889634f; kb = (I.km ? I.km[tid] != 0 : true) ? 0.f : NEG_INF; }
+  };
+  auto vec_store = [&](int vbuf, float l, float kb) {
+    if (tid < 448) { float* v = reinterpret_cast<float*>(smem + F_OFF_VEC + vbuf * F_VEC); v[tid] = l; v[896 + tid] = kb; }
+  };
+
+  Item cur = item_of(0);
+  {                                                       // first item: the whole prologue, back to back
+    uint4 kx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kx[i] = kimg_load(cur, 0, i);
+    float l, kb;
+    vec_load(cur, l, kb);
+#pragma unroll
+    for (int sw = 0; sw < 7; ++sw) { uint4 x, y; delta_load(cur, sw, x, y); delta_store(0, sw, x, y); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kimg_store(0, i, kx[i]);
+    vec_store(0, l, kb);
+  }
+
+  const int nstage = 2 * nmine;
+#pragma unroll 1
+  for (int st = 0; st < nstage; ++st) {
+    const int k = st >> 1, ps = st & 1;
+    const bool more = st + 1 < nstage;
+    const Item nxt = (ps == 1 && more) ? item_of(k + 1) : cur;          // the item of stage st + 1
+    const int kbuf = st & 1, vbuf = k & 1;
+    const u16* qsrc = f_img ? cur.dO + f_ch * 8 : cur.qkv + p.q_off + f_ch * 8;
+    const int f_ld = f_img ? pb.ld_dout : p.ld_qkv;
+    auto load_pair = [&](int c) {
+      const int grow = c * 32 + f_row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (grow < FL) v = *reinterpret_cast<const uint4*>(qsrc + (size_t)grow * f_ld);
+      return v;
+    };
+    auto store_pair = [&](int c, const uint4& v) { *reinterpret_cast<uint4*>(smem + f_dst + (c & 1) * 2 * F_QD) = v; };
+
+    // ---- stage set-up: this wave's key tiles, pair 0, the first dropout words
     const uint4 nq0 = load_pair(0);
     uint4 nq1 = load_pair(1), nq2 = load_pair(2);         // register queue: pairs c + 1 and c + 2 (an iteration is shorter than a memory latency)
     int kt[2]; bool kv[2];
@@ -144,8 +179,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
       const int key = kt[t] * 16 + r;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        kf[t][s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.k_off + h * FH + g * 8 + s * 32, kv[t]);
-        vf[t][s] = load_frag_global(qkv + (size_t)key * p.ld_qkv + p.v_off + h * FH + g * 8 + s * 32, kv[t]);
+        kf[t][s] = load_frag_global(cur.qkv + (size_t)key * p.ld_qkv + p.k_off + g * 8 + s * 32, kv[t]);
+        vf[t][s] = load_frag_global(cur.qkv + (size_t)key * p.ld_qkv + p.v_off + g * 8 + s * 32, kv[t]);
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -156,27 +191,28 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           w[u][t] = 0u;
-          if (DROPM == 2 && 2 * c + u < FNT && kv[t]) w[u][t] = mbase[((size_t)(2 * c + u) * FNT + kt[t]) * 8];
+          if (DROPM == 2 && 2 * c + u < FNT && kv[t]) w[u][t] = cur.mb[((size_t)(2 * c + u) * FNT + kt[t]) * 8];
         }
     };
     uint32_t wq1[2][2], wq2[2][2];
     load_words(0, wq1); load_words(1, wq2);
     store_pair(0, nq0);
-    fill_wait();
-    __syncthreads();
+    __syncthreads();                                      // pair 0, this stage's K image and (pass 0) the item's vectors are complete; every wave has left the previous stage
+    const float* vec = reinterpret_cast<const float*>(smem + F_OFF_VEC + vbuf * F_VEC);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) kbk[t] = kv[t] ? kb_s[kt[t] * 16 + r] : NEG_INF;
+    for (int t = 0; t < 2; ++t) kbk[t] = kv[t] ? vec[896 + kt[t] * 16 + r] : NEG_INF;
     const int nks = ps == 0 ? 8 : 6;                      // 32-key steps of the dQ product over this pass's key slots
+    const float cdk = cur.cdk;
+    const unsigned char* pk = smem + aKP + kbuf * F_KP;
 
+    // dQ of (query tile 2 cc + qu, head_dim block hb) over this pass's keys: runs one pair LATE (after the next pair's products, in front
+    // of its barrier), so the barrier does not stand between a pair's products and its dQ work
     auto dq_phase = [&](const int cc) {
-      // ---- dQ of (query tile 2 cc + qu, head_dim block hb) over this pass's keys: runs one pair LATE (after the next pair's main phase, in
-      // front of its barrier), so the barrier does not stand between a pair's products and its dQ work
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const unsigned char* pd = smem + aDSr + (cc & 1) * F_DS;
 #pragma unroll
       for (int ks = 0; ks < 8; ks += 2) {                   // (pass 1: key slots 12-15 hold zeros in both images -- steps 6, 7 add nothing)
         if (ks < nks) {
-          const unsigned char* pk = smem + aKP;
-          const unsigned char* pd = smem + aDSr + (cc & 1) * F_DS;
           const bf16x8 kT = tr2(pk, ks * 4096), dsT = tr2h(pd, ks * 2048);
           const bf16x8 kT1 = tr2(pk, ks * 4096 + 4096), dsT1 = tr2h(pd, ks * 2048 + 2048);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsT, acc, 0, 0, 0);
@@ -186,7 +222,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
       acc += acc1;
       const int q = cc * 32 + qu * 16 + r;                 // lane: head_dim hb * 16 + 4 g + j of query q
       if (q < FL) {
-        u16* dqp = dqkv + (size_t)q * pb.ld_dqkv + p.q_off + h * FH + hb * 16 + g * 4;
+        u16* dqp = cur.dqkv + (size_t)q * pb.ld_dqkv + p.q_off + hb * 16 + g * 4;
         float v0 = acc[0] * p.scale, v1 = acc[1] * p.scale, v2 = acc[2] * p.scale, v3 = acc[3] * p.scale;
         if (ps == 1) {
           const uint2 old = *reinterpret_cast<const uint2*>(dqp);
@@ -196,14 +232,30 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
         *reinterpret_cast<uint2*>(dqp) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
       }
     };
+
+    uint4 px = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);      // in-flight pieces of the NEXT stage's prologue
+    float pl = 0.f, pkb = 0.f;
 #pragma unroll 1
     for (int c = 0; c < FNP; ++c) {
+      // ---- the next stage's prologue, one request per pair: its K image (2 x 2 pieces, pairs 0-1) and, in front of a new item, that
+      // item's delta (7 sweeps, pairs 2-8) and lse / key mask (pair 9); each is written to LDS at the top of the following pair
+      if (more) {                                         // LDS writes of what the previous pair requested (px / py carry one request at a time)
+        if (c == 1 || c == 2) { kimg_store(kbuf ^ 1, 2 * (c - 1), px); kimg_store(kbuf ^ 1, 2 * (c - 1) + 1, py); }
+        if (ps == 1 && c >= 3 && c <= 9) delta_store(vbuf ^ 1, c - 3, px, py);
+        if (ps == 1 && c == 10) vec_store(vbuf ^ 1, pl, pkb);
+      }
+      if (more) {                                         // requests of the next stage's prologue (written to LDS at the top of the next pair: a whole pair of compute later, so the
+                                                          // vmcnt(0) the compiler puts in front of those writes finds every older request complete)
+        if (c <= 1) { px = kimg_load(nxt, ps ^ 1, 2 * c); py = kimg_load(nxt, ps ^ 1, 2 * c + 1); }
+        if (ps == 1 && c >= 2 && c <= 8) delta_load(nxt, c - 2, px, py);
+        if (ps == 1 && c == 9) vec_load(nxt, pl, pkb);
+      }
       uint4 nq3 = make_uint4(0, 0, 0, 0);
       if (c + 3 < FNP) nq3 = load_pair(c + 3);
       const int bq = (c & 1) * 2 * F_QD, bd = (c & 1) * F_DS;
       const unsigned char* pQ0 = smem + aQ0 + bq;
       const unsigned char* pQ1 = smem + aQ1 + bq;
-      const unsigned char* pL = smem + aL + c * 128;
+      const unsigned char* pL = smem + aL + vbuf * F_VEC + c * 128;
       unsigned char* pW0 = smem + aDSw0 + bd;
       unsigned char* pW1 = smem + aDSw1 + bd;
       // stored dropout decisions of the four score tiles of this pair (requested two pairs ahead)
@@ -271,7 +323,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
         }
       }
       if (c > 0) dq_phase(c - 1);
-      if (c + 1 < FNP) store_pair(c + 1, nq1);             // (that buffer was last read in the main phase of pair c - 1: every wave is past its barrier)
+      if (c + 1 < FNP) store_pair(c + 1, nq1);             // (that buffer was last read in the products of pair c - 1: every wave is past its barrier)
       nq1 = nq2; nq2 = nq3;
       __syncthreads();                                    // the pair's dS tiles and pair c + 1's Q / dO rows are complete
     }
@@ -280,7 +332,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (kv[t]) {
-        u16* base = dqkv + (size_t)(kt[t] * 16 + r) * pb.ld_dqkv + h * FH + g * 4;
+        u16* base = cur.dqkv + (size_t)(kt[t] * 16 + r) * pb.ld_dqkv + g * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           *reinterpret_cast<uint2*>(base + p.k_off + dt * 16) =
@@ -291,6 +343,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const vmvm_attn_bwd
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // pass 0's dQ stores are complete before pass 1 reads them back
+    if (ps == 1) cur = nxt;
   }
 }
 
@@ -306,13 +359,15 @@ __attribute__((visibility("hidden"))) bool applicable(const vmvm_attn_bwd_desc* 
 }
 
 __attribute__((visibility("hidden"))) int launch(const vmvm_attn_bwd_desc* d, hipStream_t st) {
-  const int nb = d->f.nseq * d->f.heads;
+  const int nitems = d->f.nseq * d->f.heads;
+  int grid = 256;                                         // one persistent workgroup per CU (122.5 KB of LDS), a multiple of 8
+  if (nitems < grid) grid = ((nitems + 7) / 8) * 8;
   if (d->f.dropout_p > 0.f) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess) return VMVM_EHIP;
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<2>), dim3(nb), dim3(512), F_SMEM, st, *d);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<2>), dim3(grid), dim3(512), F_SMEM, st, *d);
   } else {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess) return VMVM_EHIP;
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<0>), dim3(nb), dim3(512), F_SMEM, st, *d);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<0>), dim3(grid), dim3(512), F_SMEM, st, *d);
   }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
