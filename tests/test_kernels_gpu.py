@@ -41,4 +41,4 @@ def test_one_pass_fusion_attention_backward_opt_in():
     env = dict(os.environ, VMVM_FUSED_BWD="1")
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py"), "attnb"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     out = p.stdout + p.stderr
-    assert p.returncode == 0 and "0 FAILED" in out and "one-pass kernel vs the two-kernel form" in out, out[-3000:]
+    assert p.returncode == 0 and ", 0 FAILED" in out and "one-pass kernel vs the two-kernel form" in out, out[-3000:]
