@@ -43,6 +43,8 @@ if "bert" in which:                                               # fusion-encod
     qkv = rnd(nseq * Lq, 3 * Hd)
     km = torch.ones(nseq, Lq, dtype=torch.uint8, device=dev)
     kw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km, dropout_p=0.1, seed=1)
+    if os.environ.get("VMVM_PMC_DROPMASK", "0") == "1":            # the forward records its dropout decisions, the backward reads them
+        kw["drop_mask"] = K.attention_drop_mask(nseq, Lq, heads, 64, 1, 0.1, dev)
     for _ in range(3):
         out, lse = K.attention_fwd(qkv, nseq, Lq, heads, 64, 1, 0.125, **kw)
         K.attention_bwd(rnd(nseq * Lq, Hd), qkv, out, lse, nseq, Lq, heads, 64, 1, 0.125, **kw)
