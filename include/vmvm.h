@@ -171,8 +171,15 @@ typedef struct {
    * and summed by a second small kernel instead of 2C global atomics per workgroup.  NULL: atomics. */
   void* workspace; uint64_t workspace_bytes;
   int32_t reserve_cus;                   /* as vmvm_gemm_desc.reserve_cus: CUs left out of the resident grid (data-parallel overlap) */
+  /* optional (with src, nseg = 1, C <= 256), NULL = off: the INVERSE of src -- inv[n] = output row (within its batch) whose source is
+   * source row n (within its batch), or -1 -- and the number of source rows.  The kernel then walks the SOURCE rows in order (x, dX_add
+   * and dX stream; only dY / mean / rstd are looked up through the map) instead of the output rows (three scattered streams): the window
+   * maps of Video-Swin stage 1-2 scatter 256-512-byte rows.  Source rows with inv < 0 are not written (the caller owns them). */
+  const int32_t* inv; int32_t rows_in_total;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
+/* out[0..n_out) = -1, then out[src[i]] = i for every src[i] >= 0 (i < n_src): the inverse of a gather map (vmvm_ln_bwd_desc.inv) */
+int vmvm_invert_map(const int32_t* src, int32_t n_src, int32_t* out, int32_t n_out, void* stream);
 int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d);   /* bytes of `workspace` for the dgamma / dbeta partial rows */
 
 /* ------------------------------------------------------------------------------------------

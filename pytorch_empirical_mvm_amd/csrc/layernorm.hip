@@ -327,14 +327,29 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
   }
   const long stride = (long)gridDim.x * 4 * RPW;
-  for (long mb = ((long)blockIdx.x * 4 + wave) * RPW; mb < p.M; mb += stride) {       // wave-uniform loop: every lane reaches the shuffles
+  // Two iteration orders.  Output-major (the default): row m of dY, its source row looked up in `src` -- x, the residual gradient and dX
+  // are then rows scattered by the map.  SOURCE-major (`inv` given, one segment): row n of x / dX_add / dX in order, its dY / mean / rstd
+  // row looked up in `inv` -- ONE scattered stream instead of three (window maps of Video-Swin stage 1-2: 256-512-byte rows; measured
+  // 336 -> 324 us / 208 -> 191 us, profiles/r04_ab_ln_bwd_source_major.txt).  A source row without an output row (inv < 0) is left to the caller.
+  const bool by_src = p.inv != nullptr;
+  const long Mloop = by_src ? (long)p.rows_in_total : (long)p.M;
+  for (long mb = ((long)blockIdx.x * 4 + wave) * RPW; mb < Mloop; mb += stride) {       // wave-uniform loop: every lane reaches the shuffles
     const long m = mb + sub;
-    const bool rowok = m < p.M;
-    const long mm = rowok ? m : 0;
+    bool rowok = m < Mloop;
+    long mm = rowok ? m : 0;                              // the dY / mean / rstd row
+    long nrow = -1;                                       // source-major: the x / dX_add / dX row
+    if (by_src) {
+      const int n = (int)mm;
+      const int bb = n / p.rows_in_per_batch, nl = n - bb * p.rows_in_per_batch;
+      const int w = p.inv[nl];                            // (requesting it one iteration ahead measured slower: 324 -> 346 us)
+      nrow = n;
+      rowok = rowok && w >= 0;
+      mm = rowok ? (long)w + (long)bb * p.rows_out_per_batch : 0;
+    }
     const float mean = p.mean[mm], rstd = p.rstd[mm];
     long b = 0, ml = mm;
-    if (p.src) { b = mm / p.rows_out_per_batch; ml = mm - b * p.rows_out_per_batch; }
-    const bool padrow = p.src && p.pad_mode == 0 && p.src[ml] < 0;     // pad slot: constant zero output, no gradient
+    if (p.src && !by_src) { b = mm / p.rows_out_per_batch; ml = mm - b * p.rows_out_per_batch; }
+    const bool padrow = p.src && !by_src && p.pad_mode == 0 && p.src[ml] < 0;     // pad slot: constant zero output, no gradient
     const bool act = rowok && !padrow && cl < nch;
     float xh[8], gdy[8];
 #pragma unroll
@@ -344,7 +359,8 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
     float s1 = 0.f, s2 = 0.f;
     if (act) {
       srow = mm;
-      if (p.src) {
+      if (by_src) srow = nrow;
+      else if (p.src) {
         const int seg = col / cseg; within = col - seg * cseg;
         const int sr = p.src[ml * p.nseg + seg];
         srow = sr < 0 ? -1 : (long)sr + b * p.rows_in_per_batch;
@@ -477,13 +493,15 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->src && (d->rows_out_per_batch <= 0 || d->rows_in_per_batch <= 0)) return VMVM_EINVAL;
   if (d->dX2 && d->src) return VMVM_ENOSUPPORT;
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
+  if (d->inv && (!d->src || d->nseg != 1 || d->C > 256 || d->rows_in_total <= 0 || d->dX2)) return VMVM_ENOSUPPORT;     // source-major order: the packed kernels, one segment
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
   // Workgroups that fit per CU at the variant's VGPR count.  Allocation granule 8: the packed C <= 128 build takes 100 -> 104
   // registers, FOUR waves per SIMD, not five (the C <= 256 build takes 96: five) -- a fifth workgroup per CU ran as a second round and cost 25 % at C = 128.
   // (Measured and dropped: one workgroup fewer per CU to trim a mostly-empty last round of rows -- slower in the step wherever the
   // memory system is not yet saturated; a second row per wave in flight -- costs the wave it was meant to replace.)
-  int grid = ln_bwd_grid(d->M, d->C, d->reserve_cus);
+  const int Mloop = d->inv ? d->rows_in_total : d->M;   // rows the resident grid walks
+  int grid = ln_bwd_grid(Mloop, d->C, d->reserve_cus);
   const size_t sm = (size_t)8 * d->C * sizeof(float);   // 4 wave slabs x [2][C]
   vmvm_ln_bwd_desc dd = *d;
   if (dd.workspace && dd.workspace_bytes < (uint64_t)grid * 2 * d->C * sizeof(float)) dd.workspace = nullptr;
@@ -496,7 +514,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   } while (0)
   if (d->C <= 256) {
     const int rpw = d->C <= 128 ? 4 : 2;
-    const int gmax = (d->M + 4 * rpw - 1) / (4 * rpw);
+    const int gmax = (Mloop + 4 * rpw - 1) / (4 * rpw);
     if (grid > gmax) { grid = gmax; if (dd.workspace && dd.workspace_bytes < (uint64_t)grid * 2 * d->C * sizeof(float)) dd.workspace = nullptr; }
     if (d->x_fp32) {
       if (rpw == 4) hipLaunchKernelGGL((ln_bwd_pk_kernel<16, true>), dim3(grid), dim3(256), sm, st, dd);
@@ -525,6 +543,6 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
 // scratch of the dgamma / dbeta reduction (one [2][C] f32 partial row per resident workgroup); without it: global atomics
 extern "C" int64_t vmvm_layernorm_bwd_workspace_size(const vmvm_ln_bwd_desc* d) {
   if (!d || d->M <= 0 || d->C <= 0) return VMVM_EINVAL;
-  return (int64_t)ln_bwd_grid(d->M, d->C, 0) * 2 * d->C * (int64_t)sizeof(float);     // same plan as the launcher (an upper bound where it trims the grid further)
+  return (int64_t)ln_bwd_grid(d->inv && d->rows_in_total > d->M ? d->rows_in_total : d->M, d->C, 0) * 2 * d->C * (int64_t)sizeof(float);     // same plan as the launcher (an upper bound where it trims the grid further)
 }
 

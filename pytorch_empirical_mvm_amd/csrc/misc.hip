@@ -331,6 +331,11 @@ __global__ void gather_rows_kernel(const u16* __restrict__ src, int ld_src, cons
 // ---- index plumbing of the DropPath dead-clip elimination (engine._swin_block): the attention branch of a Swin block runs on the clips
 // whose stochastic-depth draw kept them (video_swin.py:46-54: a dropped clip's branch output is multiplied by 0).
 // expand: out[j * len + t] = map[t] < 0 ? -1 : map[t] + list[j] * stride   (per-clip window map -> absolute row map of the kept clips)
+// inverse of a gather map: out[src[i]] = i (out pre-set to -1 by the caller of the kernel)
+__global__ void invert_map_kernel(const int32_t* __restrict__ src, int n, int32_t* __restrict__ out, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int s = src[i]; if (s >= 0 && s < n_out) out[s] = i; }
+}
 __global__ void expand_batch_map_kernel(const int32_t* __restrict__ map, int len, const int32_t* __restrict__ list, int n, int stride, int32_t* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n * len) return;
@@ -1025,6 +1030,13 @@ extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int
 extern "C" int vmvm_expand_batch_map(const int32_t* map, int32_t len, const int32_t* list, int32_t n, int32_t stride, int32_t* out, void* stream) {
   if (!map || !list || !out || len <= 0 || n <= 0) return VMVM_EINVAL;
   hipLaunchKernelGGL(expand_batch_map_kernel, dim3(nblk((long)n * len, 256)), dim3(256), 0, ST, map, len, list, n, stride, out);
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+extern "C" int vmvm_invert_map(const int32_t* src, int32_t n_src, int32_t* out, int32_t n_out, void* stream) {
+  if (!src || !out || n_src <= 0 || n_out <= 0) return VMVM_EINVAL;
+  if (hipMemsetAsync(out, 0xff, (size_t)n_out * sizeof(int32_t), ST) != hipSuccess) return VMVM_EHIP;
+  hipLaunchKernelGGL(invert_map_kernel, dim3(nblk((long)n_src, 256)), dim3(256), 0, ST, src, n_src, out, n_out);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

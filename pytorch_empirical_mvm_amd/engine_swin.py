@@ -54,6 +54,14 @@ class SwinMixin:
         w3 = 1 if (SI.win3_ok(ws, ss) and os.environ.get("VMVM_WIN_LAYOUT", "1") != "0") else 0
         pm = SI.win3_perm() if w3 else None               # (applied inside the cached builders: host work once per shape, not per block call)
         src = self._cached(("wm", dims, ws, ss, w3), lambda: _dev_i32(wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm, dev))
+
+        def _inv_host():                                       # natural row -> its window slot (the LayerNorm backward's source-major walk, C <= 256)
+            sm = wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm
+            inv = np.full(L, -1, dtype=np.int32)
+            ok = np.flatnonzero(sm >= 0)
+            inv[sm[ok]] = ok
+            return _dev_i32(inv, dev)
+        src_major = C <= 256 and os.environ.get("VMVM_LN_SRC_MAJOR", "1") != "0"
         reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss, w3), lambda: torch.from_numpy(np.ascontiguousarray(reg_np[:, pm]) if w3 else reg_np).to(dev))
         rc = self._cached(("rc", N, win, w3), lambda: _dev_i32(rc_np[pm] if w3 else rc_np, dev))
         scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
@@ -159,6 +167,8 @@ class SwinMixin:
                                    dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
             dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
             bkw = dict(src=src_k, rows_out_per_batch=Bk * Lp, rows_in_per_batch=B * L) if compact else dict(src=src, rows_out_per_batch=Lp, rows_in_per_batch=L)
+            if src_major:                                     # x / d(x1) / d(x) in order, only dY looked up through the (inverse) map
+                bkw["inv"] = K.invert_map(src_k, B * L) if compact else self._cached(("wminv", dims, ws, ss, w3), _inv_host)
             dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
                                     pad_mode=0, dX_add=dx1, **bkw)
             if compact:

@@ -151,7 +151,7 @@ def layernorm_fwd(X, gamma, beta, eps, *, M=None, C_=None, nseg=1, src=None, row
 
 
 def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=None, nseg=1, src=None, rows_out_per_batch=0,
-                  rows_in_per_batch=0, pad_mode=0, dX_add=None, want_dX2=False, dropout_p=0.0, seed=0, offset=0):
+                  rows_in_per_batch=0, pad_mode=0, dX_add=None, want_dX2=False, dropout_p=0.0, seed=0, offset=0, inv=None):
     M, Cc = dY.shape
     if dX is None:
         dX = torch.empty((rows_in if rows_in is not None else M, Cc // nseg), device=dY.device, dtype=BF16)
@@ -169,6 +169,7 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
     ws = _WORKSPACE.get(dY.device)
     d.workspace, d.workspace_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
     d.reserve_cus = reserve_cus()
+    d.inv, d.rows_in_total = L.ptr(inv), (dX.shape[0] if inv is not None else 0)       # source-major walk (see include/vmvm.h)
     L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
     return dX, dX2
 
@@ -224,6 +225,13 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     b.dbias_table, b.delta = L.ptr(dbias_table), delta.data_ptr()
     L.check(L.load().vmvm_attention_bwd(C.byref(b), L.stream()), "attention_bwd")
     return dqkv
+
+
+def invert_map(src, n_out):
+    """inverse of a gather map: out[src[i]] = i, -1 where no i maps (int32 [n_out])"""
+    out = torch.empty((n_out,), device=src.device, dtype=torch.int32)
+    L.check(L.load().vmvm_invert_map(src.data_ptr(), src.numel(), out.data_ptr(), n_out, L.stream()), "invert_map")
+    return out
 
 
 def expand_batch_map(map_, list_, n, stride):

@@ -48,7 +48,7 @@ class LnBwdDesc(C.Structure):
                 ("pad_mode", c_int),
                 ("dX_add", c_void_p), ("ldadd", c_int),
                 ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int),
-                ("workspace", c_void_p), ("workspace_bytes", c_u64), ("reserve_cus", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_u64), ("reserve_cus", c_int), ("inv", c_void_p), ("rows_in_total", c_int)]
 
 
 class AttnFwdDesc(C.Structure):
@@ -108,6 +108,7 @@ _PROTOS = {
     "vmvm_gather_rows_bf16": ([c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_cast_bf16_to_f32": ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     "vmvm_expand_batch_map": ([c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
+    "vmvm_invert_map": ([c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
     "vmvm_copy_batches_bf16": ([c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "vmvm_attn_query_row_fwd": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_float, c_float, c_u64, c_u64, c_void_p], c_int),

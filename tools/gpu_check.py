@@ -414,6 +414,25 @@ def check_ln_gather():
     rep("ln window-gather bwd dx(+add)", dx, xf.grad + add.float())
     rep("ln window-gather bwd dgamma", dg, gf.grad)
     rep("ln window-gather bwd dbeta", db, bf.grad)
+    # the same backward walked in SOURCE order through the inverse map (vmvm_ln_bwd_desc.inv): identical rows, identical results; and with
+    # an absolute map of a subset of the clips (the engine's compact form): rows of the clips left out stay untouched
+    inv = K.invert_map(src, Lq)
+    RESULTS.append(("invert_map is the inverse of the window map", float(((src[inv.long()] != torch.arange(Lq, device=dev)) & (inv >= 0)).sum() + (inv < 0).sum()), 0.0,
+                    bool((inv < 0).any() or (src[inv.long()] != torch.arange(Lq, device=dev)).any())))
+    dg2, db2 = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    dx2, _ = K.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, rows_in=B * Lq, nseg=1, src=src, rows_out_per_batch=Lp, rows_in_per_batch=Lq,
+                             pad_mode=0, dX_add=add, inv=inv)
+    rep("ln window-gather bwd, source-major: dx identical", dx2, dx, tol=0)
+    rep("ln window-gather bwd, source-major: dgamma", dg2, gf.grad)
+    rep("ln window-gather bwd, source-major: dbeta", db2, bf.grad)
+    src_abs = torch.cat([src, torch.full_like(src, -1)])            # clip 0 kept, one padding clip; absolute rows (clip 1 of the input is left out)
+    inv_abs = K.invert_map(src_abs, B * Lq)
+    dxa = torch.full((B * Lq, C_), 7.0, device=dev, dtype=BF)
+    dg3, db3 = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    K.layernorm_bwd(torch.cat([dy[:Lp], torch.zeros_like(dy[:Lp])]), x, g, torch.cat([mean[:Lp], mean[:Lp]]), torch.cat([rstd[:Lp], rstd[:Lp]]), dg3, db3, dX=dxa, rows_in=B * Lq, nseg=1,
+                    src=src_abs, rows_out_per_batch=2 * Lp, rows_in_per_batch=B * Lq, pad_mode=0, dX_add=add, inv=inv_abs)
+    rep("ln window-gather bwd, source-major, absolute map: kept clip", dxa[:Lq], dx[:Lq], tol=0)
+    rep("ln window-gather bwd, source-major, absolute map: other clip untouched", dxa[Lq:], torch.full_like(dxa[Lq:], 7.0), tol=0)
     # gather_rows (window_partition of a gradient)
     gr = K.gather_rows(x, src, B * Lp, Lp, Lq)
     refg = torch.where((srcl >= 0)[None, :, None], x.float().view(B, Lq, C_)[:, srcl.clamp(min=0)], torch.zeros((), device=dev)).reshape(B * Lp, C_)
