@@ -304,6 +304,12 @@ class Agent_Pretrain:
             # (fusion encoder, heads, embeddings), their W^T copies and the zeroing of their gradients run on the engine's second stream
             # beside it; engine.encode() waits for `other_ready` before the first non-Swin parameter is read.  (The clip coefficient is
             # read from _sumsq by both halves: the side stream starts behind the norm.)
+            # Round 4: the side stream's half starts BEHIND the Swin half (VMVM_OPT_ORDER=swin_first, default): side by side the two updates only
+            # share the HBM they are both bound by, and the Swin half -- the one the next forward waits for -- took 1.2 ms instead of 0.6;
+            # behind it, the other half runs beside the forward's first kernels, of which the stage-1 window attention is VALU-bound.
+            swin_first = os.environ.get("VMVM_OPT_ORDER", "swin_first") == "swin_first"
+            if swin_first:
+                update((0, 2))
             eng.wstream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(eng.wstream):
                 update((1, 3))
@@ -314,7 +320,8 @@ class Agent_Pretrain:
                 eng.other_ready = torch.cuda.Event()
                 eng.other_ready.record()
                 S.pending = eng.other_ready              # (ParamStore.sync_pending: every reader of the non-Swin arena waits for this)
-            update((0, 2))
+            if not swin_first:
+                update((0, 2))
             S.refresh_transposed("swin")
             for gi in (0, 2):
                 a, e = S.segments[gi]
