@@ -2343,6 +2343,10 @@ int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w3
+// key-blocked win_layout = 1 kernels (attention_win4.hip, round 5): the same problems as vmvm_w3::applicable
+namespace vmvm_w4 {
+int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
+}  // namespace vmvm_w4
 // one-pass backward of the fusion encoder's attention (attention_fused.hip)
 namespace vmvm_fused {
 bool applicable(const vmvm_attn_bwd_desc* d);
@@ -2357,6 +2361,12 @@ static bool w3_off(int which) {
   return (bits >> which) & 1;
 }
 
+// A/B switches of the key-blocked kernels, read once: VMVM_NO_WIN4 (all), VMVM_NO_WIN4_FWD / _DQ / _DKV fall back to the round-4 win3 kernels
+static bool w4_off(int which) {
+  static const int bits = (getenv("VMVM_NO_WIN4") ? 7 : 0) | (getenv("VMVM_NO_WIN4_FWD") ? 1 : 0) | (getenv("VMVM_NO_WIN4_DQ") ? 2 : 0) | (getenv("VMVM_NO_WIN4_DKV") ? 4 : 0);
+  return (bits >> which) & 1;
+}
+
 #define LAUNCH_FWD(HD, MODE, NTM, NW, NX, MASK)                                              \
   do {                                                                                       \
     int rc_ = set_smem(attn_fwd_kernel<HD, MODE, NTM, NW, NX, MASK>, sm.total);              \
@@ -2368,7 +2378,9 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifndef W4_TIMELINE                                    // (probe builds pass their stamp buffer as drop_mask, tools/scratch/w4_timeline.py)
   if (d->drop_mask && !drop_mask_ok(d)) return VMVM_ENOSUPPORT;
+#endif
   if (use_stream(d)) {                               // streaming kernels: K / V chunks of 128 tokens, 8 query tiles per workgroup
     constexpr int NWS = 8, KCS = 128;
     const SmemS ss = smem_stream(d->L, d->head_dim, d->mode, d->table_len, 0, KCS);
@@ -2394,7 +2406,10 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     const int npk = (sm.nt + 1) / 2, tl4 = (d->table_len + 3) & ~3, lr4 = (d->L + 3) & ~3;
     const int smem2 = 4 * npk * 32 * 64 + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
     const bool pers_ok = (d->nseq % nwin == 0) && (sm.nt == 25 || sm.nt == 13) && d->dropout_p == 0.f && smem2 <= 160 * 1024;
-    if (vmvm_w3::applicable(d) && !d->att_colsum && !w3_off(1)) {
+    if (vmvm_w3::applicable(d) && !d->att_colsum && !w3_off(1) && !w4_off(0)) {
+      int rc_ = vmvm_w4::launch_fwd(d, st);
+      if (rc_) return rc_;
+    } else if (vmvm_w3::applicable(d) && !d->att_colsum && !w3_off(1)) {
       int rc_ = vmvm_w3::launch_fwd(d, st);
       if (rc_) return rc_;
     } else if (pers_ok) {

@@ -521,6 +521,63 @@ def check_attn_window():
             rep(tag + " bwd dtable", dtab, tf.grad)
 
 
+def check_attn_window_spike():
+    """win_layout = 1 kernels with scores that OVERFLOW against a first-key-block softmax reference (attention_win4.hip keeps a fixed
+    reference per query row and repeats a sequence with the exact row maximum when l / O come out non-finite): a few (query, key) pairs
+    get q.k ~ 8 |q|^2 ~ 250 with the key in a LATE block, one of them in the first block (no overflow there), forward and backward."""
+    dims, B, heads, win = (8, 14, 14), 2, 2, (8, 7, 7)
+    D, H, W = dims
+    for shifted in (False, True):
+        ws, ss = SI.get_window_size(dims, win, (4, 3, 3) if shifted else (0, 0, 0))
+        m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+        N = ws[0] * ws[1] * ws[2]
+        nW = m.size // N
+        reg = SI.region_ids(Dp, Hp, Wp, ws, ss)
+        rc, rc0 = SI.rc_codes(N, win)
+        pm = SI.win3_perm()
+        rc = np.ascontiguousarray(rc[pm])
+        reg = None if reg is None else np.ascontiguousarray(reg[:, pm])
+        C_ = heads * 32
+        nseq = B * nW
+        qkv = rnd(nseq * N, 3 * C_, scale=1.0)
+        q3 = qkv.view(nseq, N, 3, heads, 32)
+        # (sequence, head, query slot, key slot): same mask region needed for the pair to be live -> use neighbours inside one tile pair
+        for (sq, hh, qi, kj) in [(0, 0, 5, 390), (1, 1, 200, 201), (nseq - 1, 0, 391, 388), (2, 1, 17, 3), (3, 0, 300, 310)]:
+            q3[sq, kj, 1, hh] = (q3[sq, qi, 0, hh].float() * (4.5 if shifted else 8.0)).to(BF)    # (shifted: cross terms with MASKED queries must stay << 100 -- the kernels skip masked pairs, the reference adds -100)
+        table = (torch.randn((2 * 8 - 1) * 13 * 13, heads, device=dev) * 0.5)
+        rc_t = torch.from_numpy(rc).to(dev)
+        reg_t = torch.from_numpy(reg).to(dev) if reg is not None else None
+        out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t,
+                                   rc0=rc0, region=reg_t, n_win=nW, win_layout=1)
+        qf = qkv.float().requires_grad_(True)
+        tf = table.clone().requires_grad_(True)
+        x = qf.view(nseq, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        idx = (rc_t[:, None] - rc_t[None, :] + rc0).long()
+        bias = tf[idx.reshape(-1)].view(N, N, heads).permute(2, 0, 1)[None]
+        if reg is not None:
+            mk = torch.where(reg_t[:, :, None] != reg_t[:, None, :], -100.0, 0.0)
+            bias = bias + mk.repeat(B, 1, 1)[:, None]
+        s_ = x[0] @ x[1].transpose(-1, -2) + bias
+        o = s_.softmax(-1) @ x[2]
+        ref = o.transpose(1, 2).reshape(nseq * N, C_)
+        ref_lse = torch.logsumexp(s_, -1)                                                 # (nseq, heads, N)
+        tag = f"win attn spike shifted={shifted}"
+        print(f"     (max score {s_.max().item():.1f}, rows with max > 100: {(s_.amax(-1) > 100).sum().item()})")
+        rep(tag + " fwd", out, ref)
+        rep(tag + " lse", lse.view(nseq, heads, N), ref_lse, tol=1e-3)
+        dout = rnd(nseq * N, C_)
+        ref.backward(dout.float())
+        dtab = torch.zeros_like(table)
+        dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table,
+                               rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, dbias_table=dtab, win_layout=1)
+        gq = qf.grad.clone()
+        gq[:, :C_] *= 32 ** -0.5
+        rep(tag + " bwd dq", dqkv[:, :C_], gq[:, :C_])
+        rep(tag + " bwd dk", dqkv[:, C_:2 * C_], gq[:, C_:2 * C_])
+        rep(tag + " bwd dv", dqkv[:, 2 * C_:], gq[:, 2 * C_:])
+        rep(tag + " bwd dtable", dtab, tf.grad)
+
+
 def check_attn_bert():
     for (nseq, Lq, heads) in [(3, 432, 12), (24, 432, 12), (2, 232, 4), (2, 100, 2)]:      # (24 x 12 = 288 items: more than one per CU -- the persistent one-pass backward walks several)
         Hd = heads * 64
@@ -1122,6 +1179,8 @@ def bench_attn():
             ms = e0.elapsed_time(e1) / 5
             print(f"     {name}: {ms:.3f} ms  {fl * mult / ms / 1e9:.1f} TF ({label} shape, B={B})")
         del qkv, out, lse, dout
+    if os.environ.get("VMVM_BENCH_WINDOW_ONLY"):
+        return
     nseq, Lq, heads = 160, 432, 12
     Hd = 768
     qkv = rnd(nseq * Lq, 3 * Hd)
@@ -1229,9 +1288,9 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnb", "attns", "attnc", "attna", "misc", "bench"]
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnsp", "attnb", "attns", "attnc", "attna", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc, dvae=check_dvae_passes, pool=check_pool_grad)
+                 attnw=check_attn_window, attnsp=check_attn_window_spike, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc, dvae=check_dvae_passes, pool=check_pool_grad)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)
