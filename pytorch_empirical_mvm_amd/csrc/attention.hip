@@ -2346,6 +2346,7 @@ int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
 // key-blocked win_layout = 1 kernels (attention_win4.hip, round 5): the same problems as vmvm_w3::applicable
 namespace vmvm_w4 {
 int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
+int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w4
 // one-pass backward of the fusion encoder's attention (attention_fused.hip)
 namespace vmvm_fused {
@@ -2476,7 +2477,9 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   int rc = check_desc(&d->f);
   if (rc) return rc;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
+#ifndef W4_TIMELINE
   if (d->f.drop_mask && !drop_mask_ok(&d->f)) return VMVM_ENOSUPPORT;
+#endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (use_stream(&d->f)) {                           // streaming kernels (see vmvm_attention_fwd)
     constexpr int NWS = 8, KCS = 128;
@@ -2589,7 +2592,13 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       const int npq = (s_.nt + 1) / 2, img = npq * 32 * 64;
       const int smem3 = 2 * (2 * img + 2 * 512 * 4) + tl4 * 4 + lr4 * 4 + ((lr4 + 15) & ~15);
       const bool dkv_ok = (d->f.nseq % nwin == 0) && (s_.nt == 25 || s_.nt == 13) && d->f.L <= 512 && smem3 <= 160 * 1024;
-      if (vmvm_w3::applicable(&d->f) && !w3_off(0)) {
+      // key-blocked dK / dV for the UN-shifted blocks only (-14 % there; its masked build -- 9 walk variants at 128 registers -- spills
+      // and measured 5-9 % slower than the win3 kernel: profiles/r05_window_attention_win4_ab.txt); VMVM_WIN4_DKV_MASKED=1 forces it
+      static const bool dkv_masked = getenv("VMVM_WIN4_DKV_MASKED") != nullptr;
+      if (vmvm_w3::applicable(&d->f) && !w3_off(0) && !w4_off(2) && (!d->f.region || dkv_masked)) {
+        int rc_ = vmvm_w4::launch_dkv(d, st);
+        if (rc_) return rc_;
+      } else if (vmvm_w3::applicable(&d->f) && !w3_off(0)) {
         int rc_ = vmvm_w3::launch_dkv(d, st);
         if (rc_) return rc_;
       } else if (dkv_ok) {

@@ -28,7 +28,7 @@ namespace {
 // Probe builds (-DW4_TIMELINE, tools/scratch/w4_timeline.py): s_memtime stamps of every wave of workgroup 0 for sequences 2..5 into
 // the buffer passed as vmvm_attn_fwd_desc.drop_mask ([4 sequences][13 waves][32 stamps] u64).  Production builds: nothing.
 #ifdef W4_TIMELINE
-#define W4_STAMP(idx) do { if (blockIdx.x == 0 && b >= 2 && b < 6 && lane == 0) reinterpret_cast<unsigned long long*>(p.drop_mask)[((b - 2) * 13 + wave) * 32 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#define W4_STAMP(idx) do { if (p.drop_mask && blockIdx.x == 0 && b >= 2 && b < 6 && lane == 0) reinterpret_cast<unsigned long long*>(p.drop_mask)[((b - 2) * 13 + wave) * 32 + (idx)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W4_STAMP(idx) do { } while (0)
 #endif
@@ -408,6 +408,292 @@ __global__ __launch_bounds__(832) void attn_fwd_win4_kernel(const vmvm_attn_fwd_
   }
 }
 
+// ================================================================================================
+// dK / dV.  The mirror of the forward: workgroup = (head, chunk of clips, residue class of window positions), 13 waves, wave w = key
+// tiles 2w, 2w + 1 (wave 12: tile 24 alone, the NK = 1 walks) with their K / V fragments and the dK^T / dV^T accumulators in registers;
+// it walks the LIVE query blocks (two query tiles = one 32-deep dK / dV MFMA) of the window type.  Q / dO images + lse / delta of the next
+// sequence stream into the other LDS buffer by DMA.  Lane (r, g): key r of each tile, queries 4g..4g+3 of each query tile (S = Q K^T,
+// rows = queries: P and dS feed the dV^T = dO^T P and dK^T = Q^T dS products as B operands straight from the accumulator layout).
+// Per block: 12 b128 reads (Q / dO fragments, lse, delta, bias) -> 8 MFMAs (S, dP) -> chain (P = 2^(S log2 e - lse log2 e),
+// dS = P (dP scale - delta)) -> 8 transposing reads (Q^T, dO^T) -> 8 MFMAs (dV^T, dK^T).  delta comes from the dQ kernel (launched first).
+// ================================================================================================
+constexpr int W4_LV = 2048;                                // bytes reserved per lse / delta image (two 1-KiB DMA requests)
+constexpr int W4_BBUF = 2 * W4_IMG + 2 * W4_LV;            // one backward LDS buffer: Q image, dO image, lse, delta = 57 344 bytes
+
+template <int N>
+__device__ __forceinline__ void w4_wait6(bf16x8& a, bf16x8& b, f32x4& c, f32x4& d, f32x4& e0, f32x4& e1) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e0), "+v"(e1) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void w4_wait5(bf16x8& a, bf16x8& b, f32x4& c, f32x4& d, f32x4& e0) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e0) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void w4_wait12(bf16x8& a0, bf16x8& a1, bf16x8& b0, bf16x8& b1, f32x4& c0, f32x4& c1, f32x4& d0, f32x4& d1, f32x4& e0, f32x4& e1, f32x4& e2, f32x4& e3) {
+  asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void w4_wait10(bf16x8& a0, bf16x8& a1, bf16x8& b0, bf16x8& b1, f32x4& c0, f32x4& c1, f32x4& d0, f32x4& d1, f32x4& e0, f32x4& e1) {
+  asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "+v"(e0), "+v"(e1) : "i"(N));
+}
+__device__ __forceinline__ void w4_wait_tr8(s16x4& a0, s16x4& a1, s16x4& c0, s16x4& c1, s16x4& e0, s16x4& e1, s16x4& f0, s16x4& f1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1), "+v"(e0), "+v"(e1), "+v"(f0), "+v"(f1));
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(832) void attn_bwd_dkv_win4_kernel(const vmvm_attn_bwd_desc pb, const int nch, const int nwg) {
+  constexpr int HD = 32, NWV = 13, IMG = W4_IMG, BUF = W4_BBUF;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const vmvm_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = w3::L, heads = p.heads, nWin = p.n_win > 0 ? p.n_win : 1, B = p.nseq / nWin;
+  const int logical = xcd_remap(blockIdx.x, heads * nch * nwg);
+  const int wg = logical % nwg;
+  const int ch = (logical / nwg) % nch;
+  const int h = logical / (nwg * nch);
+  unsigned char* TL = smem + 2 * BUF;
+  {                                                       // windowed table of this head, consecutive QUERIES per read (staged through the second buffer)
+    float* stage = reinterpret_cast<float*>(smem + BUF);
+    for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
+    __syncthreads();
+    w4_build_table<1>(TL, stage, tid, NWV * 64);
+    __syncthreads();
+  }
+  const bool odd = !MASK && wave == NWV - 1;              // (the masked build runs wave 12 as a two-tile job with the all-padding tile 25: 18 walk variants spill where 9 do not)
+  const int kt[2] = {2 * wave, odd ? 2 * wave : (2 * wave + 1 < w3::NT ? 2 * wave + 1 : w3::NT - 1)};
+  const int kc = w3::cls_of(kt[0]);
+  const int cper = (B + nch - 1) / nch;
+  const int c0 = ch * cper, c1 = (c0 + cper < B) ? c0 + cper : B;
+  const int ncl = c1 > c0 ? c1 - c0 : 0, total = ncl * ((nWin - wg + nwg - 1) / nwg);
+  int w_nx = wg, c_nx = c0;
+  auto seq_nx = [&]() { return (size_t)c_nx * nWin + w_nx; };
+  auto advance = [&]() { if (++c_nx == c1) { c_nx = c0; w_nx += nwg; } };
+  constexpr int NF = (W4_ROWS * 4) / (NWV * 64);          // 2 requests per thread per image
+  const unsigned q_bytes = (unsigned)(((size_t)(L - 1) * p.ld_qkv + HD) * 2), do_bytes = (unsigned)(((size_t)(L - 1) * pb.ld_dout + HD) * 2);
+  struct LaneAddr { uint32_t off_k[2], goq[NF], god[NF]; };
+  auto lane_addr = [&](int ln) __attribute__((always_inline)) {
+    LaneAddr a;
+    const int r_ = ln & 15, g_ = ln >> 4, tid_ = wave * 64 + ln;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int key = kt[u] * 16 + r_;
+      a.off_k[u] = (uint32_t)(key < L ? key : L - 1) * p.ld_qkv + h * HD + g_ * 8;     // padding keys read row L - 1 (finite, never stored)
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int u = i * NWV * 64 + tid_, row = u >> 2, chs = u & 3, cs = (chs ^ swz_chunk<32>(row)) << 3;
+      a.goq[i] = (uint32_t)((row * p.ld_qkv + cs) * 2);
+      a.god[i] = (uint32_t)((row * pb.ld_dout + cs) * 2);
+    }
+    return a;
+  };
+  // DMA requests of one sequence's images: step i < NF = image chunk i of Q and dO, step NF = lse (waves 0-1) / delta (waves 2-3)
+  auto dma_step = [&](size_t seq, int buf, int i, const LaneAddr& a) __attribute__((always_inline)) {
+    unsigned char* dst = smem + buf * BUF;
+    if (i < NF) {
+      const u16* qsrc = uniform_ptr(reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv + p.q_off + h * HD);
+      const u16* dsrc = uniform_ptr(reinterpret_cast<const u16*>(pb.dout) + seq * L * pb.ld_dout + h * HD);
+      dma16_pair(dst + wave * 1024 + i * NWV * 64 * 16, IMG, qsrc, q_bytes, a.goq[i], dsrc, do_bytes, a.god[i], false);
+    } else if (wave < 4) {
+      const float* src = uniform_ptr(((wave < 2) ? p.lse : pb.delta) + (seq * heads + h) * L);
+      dma16_one(dst + 2 * IMG + (wave >> 1) * W4_LV + (wave & 1) * 1024, src, (unsigned)(L * 4), (uint32_t)(((wave & 1) * 64 + lane) * 16));
+    }
+  };
+  bf16x8 kf[2], vf[2];
+  auto fetch = [&](size_t seq, const LaneAddr& a, bf16x8 (&kd)[2], bf16x8 (&vd)[2]) __attribute__((always_inline)) {
+    const u16* qb = reinterpret_cast<const u16*>(p.qkv) + seq * L * p.ld_qkv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kd[u] = *reinterpret_cast<const bf16x8*>(qb + p.k_off + a.off_k[u]);
+      vd[u] = *reinterpret_cast<const bf16x8*>(qb + p.v_off + a.off_k[u]);
+    }
+  };
+  if (total > 0) {
+    const LaneAddr a0 = lane_addr(lane);
+#pragma unroll
+    for (int i = 0; i <= NF; ++i) dma_step(seq_nx(), 0, i, a0);
+    fetch(seq_nx(), a0, kf, vf);
+    advance();
+    w4_need(kf[0], kf[1]);
+    w4_need(vf[0], vf[1]);
+    fill_wait();
+  }
+
+  int wprev = -1, w_cu = wg, c_cu = c0, m4 = 15;
+  for (int b = 0; b < total; ++b) {
+    const int cur = b & 1;
+    const size_t seq = (size_t)c_cu * nWin + w_cu;
+    W4_STAMP(0);
+    __syncthreads();                                      // sequence b landed for everyone (each wave waited for its requests in the epilogue); the other buffer is free
+    W4_STAMP(1);
+    const int wcur = w_cu;
+    if (++c_cu == c1) { c_cu = c0; w_cu += nwg; }
+    if (MASK && wcur != wprev) {
+      wprev = wcur;
+      m4 = w3_live_rt(kc, __builtin_amdgcn_readfirstlane(w3_window_type(p.region, wcur)));
+    }
+    const float seq_scale = p.seq_scale ? p.seq_scale[(uint32_t)seq / (uint32_t)p.seqs_per_scale] : 1.0f;
+    const bool has_next = b + 1 < total;
+    const size_t seq_n = seq_nx();
+    if (has_next) advance();
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                            // opaque per sequence (see the forward)
+    const int r = ln & 15, g = ln >> 4;
+    const unsigned char* Qs = smem + cur * BUF;
+    f32x4 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) { dk[u][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x2 ss2 = {seq_scale, seq_scale};
+    asm volatile("" : "+v"(ss2));
+
+    auto walk = [&](auto mc, auto nkc) __attribute__((always_inline)) {
+      constexpr int M4 = decltype(mc)::value, NK = decltype(nkc)::value;
+      constexpr w3::TileList QL = w3::list_all(M4);
+      constexpr int NP = (QL.n + 1) / 2;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      // (per-lane bases rebuilt here from an opaque lane id: as values live across the switch over the walks they get spilled)
+      int lw = lane;
+      asm volatile("" : "+v"(lw));
+      const int r = lw & 15, g = lw >> 4;
+      // lane bases into the table: row = A(q) - A(k) + 84, window s = 4 (g & 1) - (r & 7) + 7; A(q) = tile immediate + lq * step
+      const int lk = r >> 3, lq = g >> 1, sw = 4 * (g & 1) - (r & 7) + 7;
+      const uint32_t tl0 = lds_addr(TL) + sw * 16;
+      const uint32_t tbpad = tl0 + 169 * W4_ROWB;
+      uint32_t tb1[2], tb13[2], tb24[2];
+  #pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ak = w3_posA_rt(2 * kt[u] + lk);
+        const uint32_t bb = tl0 + (84 - ak) * W4_ROWB;
+        tb1[u] = bb + lq * W4_ROWB;
+        tb13[u] = bb + 13 * lq * W4_ROWB;
+        tb24[u] = lq ? tbpad : bb + w3::tileA0(w3::NT - 1) * W4_ROWB;          // query tile 24: its second position is padding
+      }
+      const uint32_t qba = lds_addr(Qs + k_off_swz<HD>(r, g));                    // Q fragment of tile 0 (dO: + IMG); every tile an immediate away
+      const uint32_t tq0a = lds_addr(Qs + k_off_swz<HD>(g * 4 + (r >> 2), (r & 3) >> 1) + (r & 1) * 8);
+      const uint32_t tq1a = lds_addr(Qs + k_off_swz<HD>(g * 4 + (r >> 2), 2 + ((r & 3) >> 1)) + (r & 1) * 8);
+      const uint32_t lsa = lds_addr(Qs + 2 * IMG) + g * 16;                       // lse of queries 4g..4g+3 of tile 0 (delta: + W4_LV)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int t = QL.t[2 * i];                           // query tiles t, t + 1 (t + 1 = 25: the all-padding tile)
+        if (i < NF + 1 && has_next) { int l2 = lane; asm volatile("" : "+v"(l2)); dma_step(seq_n, cur ^ 1, i, lane_addr(l2)); }     // (addresses built here: not live across the walk)
+        uint32_t pw[2][4], dw[2][4];
+        // one query tile at a time (its 4 + NK reads, 2 NK MFMAs and chain): both tiles' fragments, scores and dP at once are 64 registers
+        // next to the 48 of the accumulators and K / V fragments -- a spilling loop
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int qt = t + x;
+          bf16x8 qf, dof;
+          f32x4 l4, d4, s[2], dp[2];
+          w4_read_frag(qf, qba, qt * 1024);
+          w4_read_frag(dof, qba, IMG + qt * 1024);
+          w4_read_b128(l4, lsa, qt * 64);
+          w4_read_b128(d4, lsa, W4_LV + qt * 64);
+#pragma unroll
+          for (int u = 0; u < NK; ++u) {
+            if (qt >= w3::NT) w4_read_b128(s[u], tbpad, 0);
+            else if (qt == w3::NT - 1) w4_read_b128(s[u], tb24[u], 0);
+            else if (w3::tileStep(qt < w3::NT ? qt : 0) == 13) w4_read_b128(s[u], tb13[u], w3::tileA0(qt < w3::NT ? qt : 0) * W4_ROWB);
+            else w4_read_b128(s[u], tb1[u], w3::tileA0(qt < w3::NT ? qt : 0) * W4_ROWB);
+          }
+          if (NK == 2) w4_wait6<0>(qf, dof, l4, d4, s[0], s[1]); else w4_wait5<0>(qf, dof, l4, d4, s[0]);
+#pragma unroll
+          for (int u = 0; u < NK; ++u) {
+            s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[u], s[u], 0, 0, 0);
+            dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+          const f32x2 nl[2] = {f32x2{l4[0], l4[1]} * f32x2{-LOG2E, -LOG2E}, f32x2{l4[2], l4[3]} * f32x2{-LOG2E, -LOG2E}};
+#pragma unroll
+          for (int u = 0; u < NK; ++u)
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+              const f32x2 e = __builtin_elementwise_fma(f32x2{s[u][2 * hj], s[u][2 * hj + 1]}, f32x2{LOG2E, LOG2E}, nl[hj]);
+              const f32x2 pr = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+              const f32x2 dd = pr * __builtin_elementwise_fma(f32x2{dp[u][2 * hj], dp[u][2 * hj + 1]}, ss2, -f32x2{d4[2 * hj], d4[2 * hj + 1]});
+              pw[u][2 * x + hj] = pack_bf2v(pr);
+              dw[u][2 * x + hj] = pack_bf2v(dd);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // (the transposed operands are requested BEHIND the chain: in front of it their 16 registers are the difference between 128 and a
+        // spilling loop; the other waves of the SIMD cover the wait)
+        s16x4 a0, a1, c0_, c1_, e0, e1, f0, f1;
+        tr_read4(a0, a1, c0_, c1_, tq0a, tq1a, (t >> 1) * 2048);
+        tr_read4(e0, e1, f0, f1, tq0a, tq1a, IMG + (t >> 1) * 2048);
+        // the next sequence's K / V fragments go into the SAME registers, behind their last use (plain loads: they land under this
+        // block's products and the epilogue; a second register set was spilled -- with a wait for the loads in front of the spill)
+        if (i == NP - 1 && has_next) { int l2 = lane; asm volatile("" : "+v"(l2)); fetch(seq_n, lane_addr(l2), kf, vf); }
+        w4_wait_tr8(a0, a1, c0_, c1_, e0, e1, f0, f1);
+        const s16x8 q0v = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const s16x8 q1v = {c0_[0], c0_[1], c0_[2], c0_[3], c1_[0], c1_[1], c1_[2], c1_[3]};
+        const s16x8 d0v = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        const s16x8 d1v = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[u][0], pw[u][1], pw[u][2], pw[u][3]));
+          const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(dw[u][0], dw[u][1], dw[u][2], dw[u][3]));
+          dv[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d0v), pf, dv[u][0], 0, 0, 0);
+          dv[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d1v), pf, dv[u][1], 0, 0, 0);
+          dk[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q0v), dsf, dk[u][0], 0, 0, 0);
+          dk[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q1v), dsf, dk[u][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // (keep these products in front of the next block's reads: sunk behind them they hold 32 registers too many)
+        W4_STAMP(3 + i);
+      }
+      if (has_next) {                                       // (short walks: the DMA steps the blocks did not cover)
+#pragma unroll
+        for (int i = NP; i <= NF; ++i) dma_step(seq_n, cur ^ 1, i, lane_addr(ln));
+      }
+    };
+    auto walk_n = [&](auto nkc) __attribute__((always_inline)) {
+      if (MASK) {
+        switch (m4) {
+          case 15: walk(IC4<15>{}, nkc); break;
+          case 3: walk(IC4<3>{}, nkc); break;
+          case 12: walk(IC4<12>{}, nkc); break;
+          case 5: walk(IC4<5>{}, nkc); break;
+          case 10: walk(IC4<10>{}, nkc); break;
+          case 1: walk(IC4<1>{}, nkc); break;
+          case 2: walk(IC4<2>{}, nkc); break;
+          case 4: walk(IC4<4>{}, nkc); break;
+          default: walk(IC4<8>{}, nkc); break;
+        }
+      } else {
+        walk(IC4<15>{}, nkc);
+      }
+    };
+    W4_STAMP(2);
+    if (!MASK && odd) walk_n(IC4<1>{}); else walk_n(IC4<2>{});
+    {
+      // epilogue: straight-line buffer stores (padding keys / the odd wave's second tile: out-of-range offsets), then the wait for the
+      // next sequence's fragments and DMA requests only (the compiler counts the stores)
+      u16* db = reinterpret_cast<u16*>(pb.dqkv) + seq * L * pb.ld_dqkv + h * HD;
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(uniform_ptr(db)), 0, __builtin_amdgcn_readfirstlane((int)(((L - 1) * pb.ld_dqkv + 3 * heads * HD) * 2)), 0x00020000);
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int key = (2 * wave + u) * 16 + r;
+        const bool ok = key < L && (u == 0 || !odd);
+        const uint32_t vo = ok ? (uint32_t)(key * pb.ld_dqkv + g * 4) * 2u : 0x80000000u;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_{pack_bf2(dk[u][d][0], dk[u][d][1]), pack_bf2(dk[u][d][2], dk[u][d][3])}, rd, vo + (uint32_t)(p.k_off + d * 16) * 2u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_{pack_bf2(dv[u][d][0] * seq_scale, dv[u][d][1] * seq_scale), pack_bf2(dv[u][d][2] * seq_scale, dv[u][d][3] * seq_scale)}, rd,
+                                                vo + (uint32_t)(p.v_off + d * 16) * 2u, 0, 0);
+        }
+      }
+    }
+    W4_STAMP(20);
+    if (has_next) {
+      w4_need(kf[0], kf[1]);
+      w4_need(vf[0], vf[1]);
+    }
+    W4_STAMP(21);
+  }
+}
+
 template <typename K>
 int w4_set_smem(K kernel, int bytes) {
   if (bytes > 160 * 1024) return VMVM_ENOSUPPORT;
@@ -448,6 +734,24 @@ __attribute__((visibility("hidden"))) int launch_fwd(const vmvm_attn_fwd_desc* d
     int rc_ = w4_set_smem(attn_fwd_win4_kernel<false>, smem);
     if (rc_) return rc_;
     hipLaunchKernelGGL((attn_fwd_win4_kernel<false>), dim3(d->heads * nch * nwg), dim3(832), smem, st, *d, nch, nwg);
+  }
+  VMVM_CHECK_LAUNCH();
+  return VMVM_OK;
+}
+
+__attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st) {
+  const int smem = 2 * W4_BBUF + W4_TAB_BYTES;
+  const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
+  int nch, nwg;
+  w4_chunks(d->f.heads, d->f.nseq / nwin, nwin, 2.f, 256, &nch, &nwg);
+  if (d->f.region) {
+    int rc_ = w4_set_smem(attn_bwd_dkv_win4_kernel<true>, smem);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_bwd_dkv_win4_kernel<true>), dim3(d->f.heads * nch * nwg), dim3(832), smem, st, *d, nch, nwg);
+  } else {
+    int rc_ = w4_set_smem(attn_bwd_dkv_win4_kernel<false>, smem);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_bwd_dkv_win4_kernel<false>), dim3(d->f.heads * nch * nwg), dim3(832), smem, st, *d, nch, nwg);
   }
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;

@@ -14,9 +14,13 @@ table = torch.randn(2535, heads, device=dev) * 0.1
 reg = None
 if shifted:
     reg = torch.from_numpy(np.ascontiguousarray(SI.region_ids(8, 14, 14, (8, 7, 7), (0, 3, 3))[:, pm])).to(dev)
+which = os.environ.get("WHICH", "fwd")
+dout = torch.randn(nseq * N, C_, device=dev).to(torch.bfloat16)
 buf = torch.zeros(4 * 13 * 32 * 2, dtype=torch.int32, device=dev)
 for _ in range(3):
-    out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, win_layout=1, drop_mask=buf)
+    out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, win_layout=1, drop_mask=(buf if which == "fwd" else None))
+    if which != "fwd":
+        K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t, rc0=rc0, region=reg, n_win=nW, dbias_table=None, win_layout=1, drop_mask=buf)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().view(np.uint64).reshape(4, 13, 32).astype(np.int64)
 t0 = t[0, :, 0].min()
