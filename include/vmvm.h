@@ -174,7 +174,10 @@ typedef struct {
   /* optional (with src, nseg = 1, C <= 256), NULL = off: the INVERSE of src -- inv[n] = output row (within its batch) whose source is
    * source row n (within its batch), or -1 -- and the number of source rows.  The kernel then walks the SOURCE rows in order (x, dX_add
    * and dX stream; only dY / mean / rstd are looked up through the map) instead of the output rows (three scattered streams): the window
-   * maps of Video-Swin stage 1-2 scatter 256-512-byte rows.  Source rows with inv < 0 are not written (the caller owns them). */
+   * maps of Video-Swin stage 1-2 scatter 256-512-byte rows.  Source rows with inv < 0 are not written (the caller owns them).
+   * Requires pad_mode == 0 (pad slots are constant zero: the walk never visits output rows without a source) and an INJECTIVE src
+   * (every source row gathered by at most one output row: vmvm_invert_map keeps one of several and the others' dY would be lost);
+   * anything else is refused / undefined. */
   const int32_t* inv; int32_t rows_in_total;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);

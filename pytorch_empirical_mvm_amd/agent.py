@@ -281,35 +281,35 @@ class Agent_Pretrain:
         gscale = 1.0 / self.world_size
         self._sumsq.zero_()
         z1 = self.comm is not None and getattr(self.comm, "zero1", False)
-        oa, oe = self.comm.own if z1 else (0, S.n_trainable)
+        own = self.comm.own if z1 else [(0, S.n_trainable)]       # (ZeRO-1: the parts of every reduction range this rank owns, dist.GradReducer.owned_ranges)
         if self.args.max_grad_norm > 0:
-            if oe > oa:
-                K.sumsq(S.grad[oa:oe], self._sumsq)
+            for oa, oe in own:
+                if oe > oa:
+                    K.sumsq(S.grad[oa:oe], self._sumsq)
             if z1:
-                D.all_reduce_(self._sumsq)               # the global norm: every rank holds the reduced gradient of its shard only
+                D.all_reduce_(self._sumsq)               # the global norm: every rank holds the reduced gradient of its parts only
         lrs = self.current_lrs()
 
         def update(groups):
             for gi in groups:
-                a, e = S.segments[gi]
-                a, e = max(a, oa), min(e, oe)            # (ZeRO-1: this rank's shard of the group; otherwise the whole group)
-                if e > a:
-                    K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
-                            beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
-                            grad_scale=gscale)
+                ga, ge = S.segments[gi]
+                for oa, oe in own:
+                    a, e = max(ga, oa), min(ge, oe)      # (ZeRO-1: this rank's parts of the group; otherwise the whole group)
+                    if e > a:
+                        K.adamw(S.flat[a:e], S.grad[a:e], S.m[a:e], S.v[a:e], S.shadow[a:e], lr=lrs[gi], weight_decay=(self.args.decay if gi < 2 else 0.0),
+                                beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
+                                grad_scale=gscale)
         eng = self.engine
-        split = getattr(eng, "wstream", None) is not None and getattr(S, "shadow8", None) is None and os.environ.get("VMVM_OPT_OVERLAP", "1") != "0" and not z1
+        split = getattr(eng, "wstream", None) is not None and getattr(S, "shadow8", None) is None and eng.sw.opt_overlap and not z1
         if split:
             # The next forward starts with the Video-Swin backbone, which reads Swin parameters only: the update of the other 137 M parameters
             # (fusion encoder, heads, embeddings), their W^T copies and the zeroing of their gradients run on the engine's second stream
             # beside it; engine.encode() waits for `other_ready` before the first non-Swin parameter is read.  (The clip coefficient is
             # read from _sumsq by both halves: the side stream starts behind the norm.)
-            # Round 4: the side stream's half starts BEHIND the Swin half (VMVM_OPT_ORDER=swin_first, default): side by side the two updates only
-            # share the HBM they are both bound by, and the Swin half -- the one the next forward waits for -- took 1.2 ms instead of 0.6;
-            # behind it, the other half runs beside the forward's first kernels, of which the stage-1 window attention is VALU-bound.
-            swin_first = os.environ.get("VMVM_OPT_ORDER", "swin_first") == "swin_first"
-            if swin_first:
-                update((0, 2))
+            # The side stream's half starts BEHIND the Swin half: side by side the two updates only share the HBM they are both bound by, and
+            # the Swin half -- the one the next forward waits for -- took 1.2 ms instead of 0.6; behind it, the other half runs beside the
+            # forward's first kernels.  (Round 4 kept the other order behind VMVM_OPT_ORDER; its A/B was 0.07-0.16 ms: removed in round 5.)
+            update((0, 2))
             eng.wstream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(eng.wstream):
                 update((1, 3))
@@ -320,8 +320,6 @@ class Agent_Pretrain:
                 eng.other_ready = torch.cuda.Event()
                 eng.other_ready.record()
                 S.pending = eng.other_ready              # (ParamStore.sync_pending: every reader of the non-Swin arena waits for this)
-            if not swin_first:
-                update((0, 2))
             S.refresh_transposed("swin")
             for gi in (0, 2):
                 a, e = S.segments[gi]

@@ -2331,7 +2331,7 @@ int check_desc(const vmvm_attn_fwd_desc* d) {
 inline bool use_stream(const vmvm_attn_fwd_desc* d) { return d->L > 448 || (d->stream_min_len > 0 && d->L >= d->stream_min_len); }
 // stored dropout decisions (vmvm_attn_fwd_desc.drop_mask): the exact-tile fusion kernels only
 inline bool drop_mask_ok(const vmvm_attn_fwd_desc* d) {
-  return d->mode == 1 && d->head_dim == 64 && d->dropout_p > 0.f && d->causal_from <= 0 && !d->att_colsum && !use_stream(d) && (d->L + 15) / 16 == 27;
+  return d->mode == 1 && d->head_dim == 64 && d->dropout_p > 0.f && d->causal_from <= 0 && !d->att_colsum && !use_stream(d) && d->L == 432;      // exact tiles only: the stored-decision kernels have no per-tile guards (a ragged 27th tile would record rows / keys >= L)
 }
 
 }  // namespace
@@ -2348,15 +2348,9 @@ namespace vmvm_w4 {
 int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
 int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
 }  // namespace vmvm_w4
-// one-pass backward of the fusion encoder's attention (attention_fused.hip)
-namespace vmvm_fused {
-bool applicable(const vmvm_attn_bwd_desc* d);
-int launch(const vmvm_attn_bwd_desc* d, hipStream_t st);
-}  // namespace vmvm_fused
 
 // A/B switches of the win_layout = 1 kernels, read once: VMVM_NO_WIN3 (all), VMVM_NO_WIN3_FWD (1), VMVM_NO_WIN3_DQ (2) fall back to the
 // order-agnostic win2 kernels on the same layout (tools/scratch/ab_win3*.sh)
-static bool fused_on() { static const bool on = getenv("VMVM_FUSED_BWD") != nullptr; return on; }
 static bool w3_off(int which) {
   static const int bits = (getenv("VMVM_NO_WIN3") ? 7 : 0) | (getenv("VMVM_NO_WIN3_FWD") ? 2 : 0) | (getenv("VMVM_NO_WIN3_DQ") ? 4 : 0);
   return (bits >> which) & 1;
@@ -2637,8 +2631,6 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       if (rc_) return rc_;
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, 8, 0, true>), dim3(nb), dim3(8 * 64), s2_.total, st, *d);
       VMVM_CHECK_LAUNCH();
-    } else if (sb_.nt == 27 && fused_on() && vmvm_fused::applicable(d)) {
-      return vmvm_fused::launch(d, st);
     } else if (sb_.nt == 27) {        // L = 432 (fusion encoder): exact tile count, fully unrolled tile loops
       // Measured and not kept (round 4, profiles/r04_ab_fusion_attention_variants.txt): two key tiles per wave in dK/dV (KTP = 2), two query
       // tiles per wave in dQ (QT = 2) -- half the LDS bytes per score tile, same time: these kernels are not LDS-bound --, and 9 waves

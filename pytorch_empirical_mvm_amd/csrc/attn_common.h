@@ -216,9 +216,10 @@ __device__ __forceinline__ void tr_wait4(s16x4& a0, s16x4& a1, s16x4& c0, s16x4&
 
 // Attention-probability dropout threshold: p is quantised to 1/65536 (0.1 -> 6554/65536 = 0.10001, the rate of the GEMM-epilogue
 // and query-row streams) although a 4 x 4 block still draws 16 random BYTES from one Philox evaluation: element j of a word compares the
-// 16-bit field (byte j+1 mod 4 : byte j) -- its own byte decides unless it equals the threshold's high byte (1 element in 256), where
-// the neighbour's byte is the tie-break.  Every element's marginal drop probability is exactly thr16 / 65536; the fields of neighbours
-// overlap in one byte, which only couples decisions at that 1-in-256 boundary.  (Rounds 1-3: an 8-bit compare, p_eff = 26/256 = 0.1016.)
+// 16-bit field (byte j+1 mod 4 : byte j), i.e. its NEIGHBOUR's byte j+1 is the high byte and decides; its own byte j is the low byte
+// and only breaks the tie when the high byte equals the threshold's high byte (1 element in 256).  The high bytes of the four elements
+// are a permutation of the word's bytes, so every element's marginal drop probability is exactly thr16 / 65536 and neighbouring
+// decisions are coupled only through that 1-in-256 tie-break.  (Rounds 1-3: an 8-bit compare, p_eff = 26/256 = 0.1016.)
 __device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
 __device__ __forceinline__ uint32_t drop_field(uint32_t w, int j) {      // j in 0..3 (compile- or run-time): v_alignbit + mask
   return __builtin_amdgcn_alignbit(w, w, (uint32_t)(8 * j)) & 0xffffu;

@@ -493,7 +493,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->src && (d->rows_out_per_batch <= 0 || d->rows_in_per_batch <= 0)) return VMVM_EINVAL;
   if (d->dX2 && d->src) return VMVM_ENOSUPPORT;
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
-  if (d->inv && (!d->src || d->nseg != 1 || d->C > 256 || d->rows_in_total <= 0 || d->dX2)) return VMVM_ENOSUPPORT;     // source-major order: the packed kernels, one segment
+  if (d->inv && (!d->src || d->nseg != 1 || d->C > 256 || d->rows_in_total <= 0 || d->dX2 || d->pad_mode != 0)) return VMVM_ENOSUPPORT;     // source-major order: the packed kernels, one segment, pad slots constant zero (the walk never visits rows without a source, and with pad_mode != 0 those rows contribute dY to dgamma / dbeta)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
   // Workgroups that fit per CU at the variant's VGPR count.  Allocation granule 8: the packed C <= 128 build takes 100 -> 104

@@ -30,21 +30,17 @@ import os
 import torch
 import torch.distributed as dist
 
+from .switches import Switches
+
 CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 (128 MiB of bf16) per collective
 
 
 def comm_cus():
-    try:
-        return max(0, min(128, int(os.environ.get("VMVM_COMM_CUS", "16"))))
-    except ValueError:
-        return 16
+    return Switches.from_env().comm_cus
 
 
 def grad_wire():
-    w = os.environ.get("VMVM_GRAD_WIRE", "bf16").lower()
-    if w not in ("bf16", "f32"):
-        raise RuntimeError(f"VMVM_GRAD_WIRE={w!r}: expected bf16 or f32")
-    return w
+    return Switches.from_env().grad_wire
 
 
 def init_from_env(backend=None):
@@ -110,13 +106,72 @@ def broadcast_(t, src=0):
 
 
 def zero1():
-    return os.environ.get("VMVM_ZERO1", "0") == "1"
+    return Switches.from_env().zero1
 
 
 def shard_bounds(n, world, align=256):
     """`world` contiguous shards of [0, n), boundaries on multiples of `align` elements"""
     per = -(-(-(-n // world)) // align) * align
     return [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+
+
+def scatter_parts(a, e, world, align=256):
+    """ZeRO-1 ownership of ONE reduction range [a, e) (round 5): `world` equal, `align`-ed parts -- part r = [a + r per, a + (r + 1) per)
+    is what reduce_scatter_tensor hands to rank r and what it contributes to all_gather_into_tensor -- plus a tail of fewer than
+    world * align elements owned by rank 0 (reduced with one small rooted reduce).  Returns (per, tail_start)."""
+    per = ((e - a) // (world * align)) * align
+    return per, a + world * per
+
+
+def reduce_scatter_range_(buf, a, e, rank, world):
+    """sum of buf[a:e] over the ranks, each rank left with ITS parts (scatter_parts) in place; returns the number of collectives.
+    One reduce_scatter_tensor per CHUNK_ELEMS * world elements (in place: output = the rank's slice of the input, which is NCCL's /
+    RCCL's in-place form) drives all links of every GPU, where `world` rooted reduces drive one destination's links each."""
+    per, tail = scatter_parts(a, e, world)
+    n = 0
+    step = min(per, CHUNK_ELEMS) if per else 0
+    if per:
+        # the range is cut into `world` parts of `per`; a chunk takes the same [o, o + step) window of every part -> the windows are not
+        # adjacent in memory unless step == per, so chunking re-packs nothing: it loops over windows of a strided view
+        if step == per:
+            dist.reduce_scatter_tensor(buf[a + rank * per:a + (rank + 1) * per], buf[a:a + world * per])
+            n += 1
+        else:
+            view = buf[a:a + world * per].view(world, per)
+            for o in range(0, per, step):
+                w_ = min(step, per - o)
+                inp = view[:, o:o + w_].contiguous()
+                out = torch.empty(w_, dtype=buf.dtype, device=buf.device)
+                dist.reduce_scatter_tensor(out, inp.view(-1))
+                view[rank, o:o + w_].copy_(out)
+                n += 1
+    if e > tail:
+        dist.reduce(buf[tail:e], 0)
+        n += 1
+    return n
+
+
+def all_gather_range_(buf, a, e, rank, world):
+    """every rank's parts of buf[a:e] (scatter_parts) to every rank, in place; returns the number of collectives."""
+    per, tail = scatter_parts(a, e, world)
+    n = 0
+    if per:
+        step = min(per, CHUNK_ELEMS)
+        if step == per:
+            dist.all_gather_into_tensor(buf[a:a + world * per], buf[a + rank * per:a + (rank + 1) * per])
+            n += 1
+        else:
+            view = buf[a:a + world * per].view(world, per)
+            for o in range(0, per, step):
+                w_ = min(step, per - o)
+                out = torch.empty(world * w_, dtype=buf.dtype, device=buf.device)
+                dist.all_gather_into_tensor(out, view[rank, o:o + w_].contiguous())
+                view[:, o:o + w_].copy_(out.view(world, w_))
+                n += 1
+    if e > tail:
+        dist.broadcast(buf[tail:e], 0)
+        n += 1
+    return n
 
 
 def reduce_chunks_(flat, a, e, dst):
@@ -147,27 +202,62 @@ class GradReducer:
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
         self.pending = False
         self.tail_done = False
-        self.wire = grad_wire() if wire is None else wire
+        self.sw = Switches.from_env()             # read once, at construction (the spawned test ranks set their environment first)
+        self.wire = self.sw.grad_wire if wire is None else wire
         self.wire_buf = torch.empty_like(store.grad, dtype=torch.bfloat16) if self.wire == "bf16" else None       # bf16 image of the arena, same offsets
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
         # (VMVM_COMM_CUS_ANY_BACKEND: test hook -- the shared-GPU gloo test runs the short grids too)
-        on = nccl or bool(os.environ.get("VMVM_COMM_CUS_ANY_BACKEND"))
-        self.reserve_cus = (comm_cus() if (on and self.cuda) else 0) if reserve_cus is None else int(reserve_cus)
-        self.zero1 = zero1() and dist.is_available() and dist.is_initialized()
-        self.shards = shard_bounds(store.n_trainable, dist.get_world_size(), 256) if self.zero1 else None
-        self.own = self.shards[dist.get_rank()] if self.zero1 else (0, store.n_trainable)
+        on = nccl or self.sw.comm_cus_any_backend
+        self.reserve_cus = (self.sw.comm_cus if (on and self.cuda) else 0) if reserve_cus is None else int(reserve_cus)
+        self.release_at_end = self.sw.comm_cus_release == "end"
+        self.zero1 = self.sw.zero1 and dist.is_available() and dist.is_initialized()
+        # ZeRO-1 (round 5): ownership follows the REDUCTION RANGES -- every range the three phases reduce (the two non-Swin groups; the
+        # head and the tail of the two Swin groups) is cut into `world` equal parts, so each phase is ONE reduce_scatter_tensor per range
+        # and the parameter exchange one all_gather_into_tensor per range (utils/deepspeed.py:42-44, ZeRO stage 1).  Round 4 cut the
+        # whole arena into `world` contiguous shards and needed `world` rooted reduces + `world` broadcasts per phase.
+        self.world = dist.get_world_size() if self.zero1 else 1
+        self.rank = dist.get_rank() if self.zero1 else 0
+        self.ranges = self._reduction_ranges() if self.zero1 else [(0, store.n_trainable)]
+        self.own = self.owned_ranges(self.rank) if self.zero1 else [(0, store.n_trainable)]
         self.wait_streams = []                    # further producer streams (the engine's weight-gradient stream) a reduction must wait for
         self.collectives = 0                      # issued so far (tests / profiling)
         self.wire_bytes = 0
 
+    def _reduction_ranges(self):
+        """the disjoint ranges the phases reduce, in arena order (they cover [0, n_trainable))"""
+        S = self.store
+        tails = {e: a for a, e in (S.swin_tail or [])}
+        out = []
+        for gi in range(4):
+            a, e = S.segments[gi]
+            if e <= a:
+                continue
+            t = tails.get(e) if gi in (0, 2) else None
+            if t is not None and a < t < e:
+                out += [(a, t), (t, e)]
+            else:
+                out.append((a, e))
+        return sorted(out)
+
+    def owned_ranges(self, rank):
+        """the parts of the arena rank `rank` owns under ZeRO-1 (reduced gradient, AdamW, master update), in arena order"""
+        out = []
+        for a, e in self.ranges:
+            per, tail = scatter_parts(a, e, self.world)
+            if per:
+                out.append((a + rank * per, a + (rank + 1) * per))
+            if e > tail and rank == 0:
+                out.append((tail, e))
+        return sorted(out)
+
     # ---- one contiguous range of the arena
     def _reduce_range(self, a, e):
-        if self.zero1:                            # every shard's piece of the range goes to its owner only
-            me = dist.get_rank()
-            for r, (sa, se) in enumerate(self.shards):
-                lo, hi = max(a, sa), min(e, se)
-                if hi > lo:
-                    self._reduce_piece(lo, hi, r, r == me)
+        if self.zero1:                            # the range must be one of self.ranges (or a union of them): each goes to its owners by reduce-scatter
+            for ra, re in self.ranges:
+                if ra >= a and re <= e:
+                    self._reduce_scatter(ra, re)
+                else:
+                    assert re <= a or ra >= e, ("ZeRO-1: a reduction cut through an ownership range", (a, e), (ra, re))
             return
         g = self.store.grad
         if self.wire_buf is None:
@@ -186,38 +276,38 @@ class GradReducer:
             g[a:e].copy_(w[a:e])
         self.wire_bytes += 2 * (e - a)
 
-    def _reduce_piece(self, a, e, dst, mine):
+    def _reduce_scatter(self, a, e):
+        """ZeRO-1: the sum of one ownership range, each rank left with its parts (f32 in the gradient arena)"""
         g, w = self.store.grad, self.wire_buf
+        mine = [(lo, hi) for lo, hi in self.own if lo >= a and hi <= e]
         if w is None:
-            self.collectives += reduce_chunks_(g, a, e, dst)
+            self.collectives += reduce_scatter_range_(g, a, e, self.rank, self.world)
             self.wire_bytes += 4 * (e - a)
             return
         if self.cuda:
             from . import kernels as K
             K.cast_bf16(g[a:e], w[a:e])
-            self.collectives += reduce_chunks_(w, a, e, dst)
-            if mine:
-                K.cast_f32(w[a:e], g[a:e])
+            self.collectives += reduce_scatter_range_(w, a, e, self.rank, self.world)
+            for lo, hi in mine:
+                K.cast_f32(w[lo:hi], g[lo:hi])
         else:
             w[a:e].copy_(g[a:e])
-            self.collectives += reduce_chunks_(w, a, e, dst)
-            if mine:
-                g[a:e].copy_(w[a:e])
+            self.collectives += reduce_scatter_range_(w, a, e, self.rank, self.world)
+            for lo, hi in mine:
+                g[lo:hi].copy_(w[lo:hi])
         self.wire_bytes += 2 * (e - a)
 
     def gather_params(self, flat):
-        """ZeRO-1: every owner broadcasts its updated f32 master shard (an all-gather as `world` broadcasts); returns the shards the
-        caller did NOT own (their bf16 compute copies have to be re-cast)."""
-        others = []
-        me = dist.get_rank()
-        for r, (sa, se) in enumerate(self.shards):
-            if se > sa:
-                for s0 in range(sa, se, CHUNK_ELEMS):
-                    dist.broadcast(flat[s0:min(se, s0 + CHUNK_ELEMS)], r)
-                    self.collectives += 1
-                self.wire_bytes += 4 * (se - sa)
-                if r != me:
-                    others.append((sa, se))
+        """ZeRO-1: every owner contributes its updated f32 master parts (one all_gather_into_tensor per ownership range); returns the
+        ranges the caller did NOT own (their bf16 compute copies have to be re-cast)."""
+        for a, e in self.ranges:
+            self.collectives += all_gather_range_(flat, a, e, self.rank, self.world)
+            self.wire_bytes += 4 * (e - a)
+        others, pos = [], 0
+        for lo, hi in self.own + [(self.store.n_trainable, self.store.n_trainable)]:
+            if lo > pos:
+                others.append((pos, lo))
+            pos = max(pos, hi)
         return others
 
     def _side(self, ranges):
@@ -236,8 +326,10 @@ class GradReducer:
             self.pending = True
             if self.reserve_cus > 0:
                 from . import kernels as K
-                ev = torch.cuda.Event()
-                ev.record(self.stream)            # behind the last collective queued so far: kernels.reserve_cus() polls it and gives the
+                ev = None
+                if not self.release_at_end:       # VMVM_COMM_CUS_RELEASE=end: the reservation ends at a FIXED point (reduce_swin_and_wait), so the
+                    ev = torch.cuda.Event()       # grids -- and the order of the LayerNorm / split-K partial sums -- do not depend on timing
+                    ev.record(self.stream)        # behind the last collective queued so far: kernels.reserve_cus() polls it and gives the
                 K.RESERVE_CUS, K.RESERVE_EVENT = self.reserve_cus, ev      # CUs back as soon as it has completed (not at the end of the backward)
         else:
             for a, e in ranges:

@@ -22,6 +22,7 @@ from .engine_downstream import DownstreamMixin
 from .engine_fusion import FusionMixin
 from .engine_heads import HeadsMixin
 from .engine_swin import SwinMixin
+from .switches import Switches
 from .store import BF16, F32, DropScale, ParamStore, V, _acc, _dev_i32, _gout, _h2d      # noqa: F401  (re-exported: tests and tools import them from here)
 
 
@@ -46,8 +47,9 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         # BASELINE config 5 ("fp8 MFMA path"): forward GEMMs of the fusion encoder's qkv and FFN-in projections on e4m3 operands
         # (per-tensor static scales, v_mfma_scale_f32_16x16x128_f8f6f4); backward stays bf16 on the bf16 activations
         self.fp8 = bool(cfg.get("fp8_forward", False)) and self.device.type == "cuda"
-        self.store_drop_mask = os.environ.get("VMVM_DROP_MASK", "1") != "0"      # fusion attention: the backward reads the forward's dropout decisions (44.8 MB per layer at C2) instead of re-evaluating Philox twice
-        self.gelu_code8 = bool(cfg.get("gelu_code8", os.environ.get("VMVM_GELU_CODE8", "1") != "0"))         # Swin MLPs keep GELU' as an 8-bit code
+        self.sw = Switches.from_env()       # every VMVM_* switch of the step path, read once (switches.py)
+        self.store_drop_mask = self.sw.drop_mask      # fusion attention: the backward reads the forward's dropout decisions (44.8 MB per layer at C2) instead of re-evaluating Philox twice
+        self.gelu_code8 = bool(cfg.get("gelu_code8", self.sw.gelu_code8))         # Swin MLPs keep GELU' as an 8-bit code
         self.A8_SCALE = 16.0
         if self.fp8:
             self.store.enable_fp8()
@@ -61,8 +63,8 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
             K.set_workspace(self.workspace)
-            if bool(cfg.get("wgrad_stream", os.environ.get("VMVM_WGRAD_STREAM", "1") != "0")):
-                self.wstream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("VMVM_WGRAD_PRIO", "0")))
+            if bool(cfg.get("wgrad_stream", self.sw.wgrad_stream)):
+                self.wstream = torch.cuda.Stream(device=self.device)
                 self.workspace_w = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)  # the side stream's own split-K slabs
 
     # -------------------------------------------------------------- small helpers

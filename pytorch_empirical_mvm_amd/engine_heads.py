@@ -118,7 +118,7 @@ class HeadsMixin:
         # In the LAST layer only the text [CLS] row of the VTM sequences is alive (the VTM head reads nothing else, :260): it runs as
         # `_bert_layer_qrow` on n2 rows instead of n2 * Lq (`go_cross(qrow_split=...)`); results are those of the full layer.
         ntape = len(self.tape)
-        qrow = os.environ.get("VMVM_QROW", "1") != "0"                             # (0: the whole last layer for every sequence, for A/B runs)
+        qrow = self.sw.qrow                             # (0: the whole last layer for every sequence, for A/B runs)
         if qrow:
             (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), qrow_split=(n1, Lv))
             if backward:

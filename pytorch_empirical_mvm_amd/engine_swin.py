@@ -51,7 +51,7 @@ class SwinMixin:
         # win_layout = 1 (include/vmvm.h, swin_index.win3_perm): the order of the tokens INSIDE a window is free -- one gather map serves
         # the LayerNorm, the projection's un-gather epilogue and the backward -- so (8,7,7) windows are laid out d-fastest and region-major,
         # which is what the win3 attention kernels assume (Toeplitz bias reads, masked score tiles skipped); rc / region follow the slots
-        w3 = 1 if (SI.win3_ok(ws, ss) and os.environ.get("VMVM_WIN_LAYOUT", "1") != "0") else 0
+        w3 = 1 if (SI.win3_ok(ws, ss) and self.sw.win_layout) else 0
         pm = SI.win3_perm() if w3 else None               # (applied inside the cached builders: host work once per shape, not per block call)
         src = self._cached(("wm", dims, ws, ss, w3), lambda: _dev_i32(wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm, dev))
 
@@ -61,7 +61,7 @@ class SwinMixin:
             ok = np.flatnonzero(sm >= 0)
             inv[sm[ok]] = ok
             return _dev_i32(inv, dev)
-        src_major = C <= 256 and os.environ.get("VMVM_LN_SRC_MAJOR", "1") != "0"
+        src_major = C <= 256 and self.sw.ln_src_major
         reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss, w3), lambda: torch.from_numpy(np.ascontiguousarray(reg_np[:, pm]) if w3 else reg_np).to(dev))
         rc = self._cached(("rc", N, win, w3), lambda: _dev_i32(rc_np[pm] if w3 else rc_np, dev))
         scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
@@ -77,7 +77,7 @@ class SwinMixin:
         ds2 = dp2 if (isinstance(dp2, DropScale) or dp2 is None) else DropScale(dp2)
         dp2 = None if ds2 is None else ds2.dev
         Bk, compact = B, False                                 # clips the attention branch runs on
-        if ds is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") != "0":
+        if ds is not None and self.sw.droppath_dce != "0":
             Bk, kept_a, dpk_a = ds.take(math.gcd(L, Lp), B)                   # (both row counts, Bk * L and Bk * Lp, in whole K tiles)
             drop_a, nd_a = ds.dropped, B - ds.n_kept
             compact = Bk < B and ds.scale is not None
@@ -114,7 +114,7 @@ class SwinMixin:
         # the MLP branch on ITS kept clips (the second, independent draw): LayerNorm through an absolute identity map of the kept clips'
         # rows, fc1 compact, fc2 scattering back through the same map (+ residual); one extra gather of d(x2) in the backward
         Bm, compact2 = B, False
-        if ds2 is not None and os.environ.get("VMVM_DROPPATH_DCE", "1") not in ("0", "attn"):
+        if ds2 is not None and self.sw.droppath_dce not in ("0", "attn"):
             Bm, kept_m, dpk_m = ds2.take(L, B)
             drop_m, nd_m = ds2.dropped, B - ds2.n_kept
             compact2 = Bm < B and ds2.scale is not None

@@ -117,8 +117,8 @@ def test_two_phase_gradient_reduction_world2_gloo(wire):
 
 def _worker_zero1(rank, world, port, q):
     """ZeRO-1 shape (VMVM_ZERO1=1; the reference's default engine, utils/deepspeed.py:42-44): after the three phases a rank holds the
-    rank-sum of ITS shard only, 2 bytes per trainable element crossed the wire for the gradients, and gather_params makes the f32
-    masters identical again from the owners' shards."""
+    rank-sum of ITS parts only (reduce_scatter_tensor per reduction range), 2 bytes per trainable element crossed the wire for the
+    gradients, and gather_params (all_gather_into_tensor per range) makes the f32 masters identical again from the owners' parts."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VMVM_GRAD_WIRE="bf16",
                       VMVM_ZERO1="1")
     from pytorch_empirical_mvm_amd import config as CFG
@@ -131,23 +131,36 @@ def _worker_zero1(rank, world, port, q):
     S.grad[:S.total].copy_(torch.randn(S.total, generator=torch.Generator().manual_seed(100 + rank)))
     mine = S.grad[:S.total].clone()
     red = D.GradReducer(S, "cpu")
-    ok = red.zero1 and len(red.shards) == world and red.shards[0][0] == 0 and red.shards[-1][1] == S.n_trainable
-    ok &= all(red.shards[i][1] == red.shards[i + 1][0] and red.shards[i][1] % 256 == 0 for i in range(world - 1))
+    # ownership (round 5): every reduction range is cut into `world` equal 256-aligned parts (+ a tail of < world * 256 elements on rank 0);
+    # the ranks' parts are disjoint and cover [0, n_trainable)
+    owned = [red.owned_ranges(r_) for r_ in range(world)]
+    flat_cover = sorted(x for o in owned for x in o)
+    ok = red.zero1 and red.own == owned[rank] and flat_cover[0][0] == 0 and flat_cover[-1][1] == S.n_trainable
+    ok &= all(flat_cover[i][1] == flat_cover[i + 1][0] for i in range(len(flat_cover) - 1))
+    ok &= all((hi - lo) % 256 == 0 or r_ == 0 for r_ in range(world) for lo, hi in owned[r_])
+    ok &= abs(sum(hi - lo for lo, hi in owned[0]) - sum(hi - lo for lo, hi in owned[1])) < 256 * world * len(red.ranges)
+    nc0 = red.collectives
     red.reduce_other(); red.reduce_swin_tail(); red.reduce_swin_and_wait()
+    ok &= red.collectives - nc0 <= 2 * len(red.ranges)                               # ONE reduce-scatter (+ at most one tail reduce) per range, not `world` rooted reduces
     locals_ = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)).to(torch.bfloat16) for k in range(world)]
     want = (locals_[0].float() + locals_[1].float()).to(torch.bfloat16).float()
-    oa, oe = red.own
-    ok &= oe > oa and torch.equal(S.grad[oa:oe], want[oa:oe])                        # my shard: the sum
+    for oa, oe in red.own:
+        ok &= oe > oa and torch.equal(S.grad[oa:oe], want[oa:oe])                    # my parts: the sum
     ok &= red.wire_bytes == 2 * S.n_trainable
     a, e = S.segments[4]
     ok &= torch.equal(S.grad[a:e], mine[a:e])                                         # frozen segment untouched
-    # the "optimizer": every rank rewrites its own master shard, then the shards travel
+    # the "optimizer": every rank rewrites its own master parts, then the parts travel (one all_gather_into_tensor per range)
     S.flat[:S.total].fill_(-1.0)
-    S.flat[oa:oe] = torch.arange(oa, oe, dtype=torch.float32) * (rank + 1)
+    for oa, oe in red.own:
+        S.flat[oa:oe] = torch.arange(oa, oe, dtype=torch.float32) * (rank + 1)
+    nc1 = red.collectives
     others = red.gather_params(S.flat)
-    ok &= sorted(others + [red.own]) == sorted(red.shards)
-    for r_, (sa, se) in enumerate(red.shards):
-        ok &= torch.equal(S.flat[sa:se], torch.arange(sa, se, dtype=torch.float32) * (r_ + 1))
+    ok &= red.collectives - nc1 <= 2 * len(red.ranges)
+    cover = sorted(others + red.own)
+    ok &= cover[0][0] == 0 and cover[-1][1] == S.n_trainable and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    for r_ in range(world):
+        for sa, se in owned[r_]:
+            ok &= torch.equal(S.flat[sa:se], torch.arange(sa, se, dtype=torch.float32) * (r_ + 1))
     q.put((rank, bool(ok)))
     D.barrier()
     torch.distributed.destroy_process_group()

@@ -29,16 +29,3 @@ def test_kernel_group(gc, group):
     torch.cuda.synchronize()
     bad = [r for r in gc.RESULTS if r[3]]
     assert gc.RESULTS and not bad, bad
-
-
-def test_one_pass_fusion_attention_backward_opt_in():
-    """csrc/attention_fused.hip (opt-in, VMVM_FUSED_BWD=1: the switch is read once per process, hence the child process): the fusion
-    attention checks -- 432-token sequences against torch fp32 with and without the stored dropout decisions, 288 items on 256 persistent
-    workgroups, and the one-pass result against the two-kernel form."""
-    import subprocess
-    import sys
-    root = os.path.join(os.path.dirname(__file__), "..")
-    env = dict(os.environ, VMVM_FUSED_BWD="1")
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py"), "attnb"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    out = p.stdout + p.stderr
-    assert p.returncode == 0 and ", 0 FAILED" in out and "one-pass kernel vs the two-kernel form" in out, out[-3000:]

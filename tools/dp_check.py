@@ -42,8 +42,9 @@ def concat_check(agent, model, mb, world, rank, dev):
     eng.forward_backward(b, negatives=neg, train=False, backward=True, on_other_grads_ready=agent.comm.reduce_other)
     agent.comm.reduce_swin_and_wait()
     torch.cuda.synchronize()
-    oa, oe = agent.comm.own
-    red = (S.grad[oa:oe] / world).clone()
+    own = agent.comm.own                                      # list of (lo, hi): the whole arena, or this rank's ZeRO-1 parts
+    cat_own = lambda t: torch.cat([t[lo:hi] for lo, hi in own])
+    red = (cat_own(S.grad) / world).clone()
     # single-process side (computed redundantly on every rank): the concatenated batch, block-diagonal negatives
     cat = {}
     for k, v in b.items():
@@ -57,7 +58,7 @@ def concat_check(agent, model, mb, world, rank, dev):
     eng.on_swin_tail_ready = None
     eng.forward_backward(cat, negatives=neg_cat, train=False, backward=True)
     torch.cuda.synchronize()
-    one = S.grad[oa:oe].clone()
+    one = cat_own(S.grad).clone()
     S.grad.zero_()
     err = float((red - one).abs().max() / (one.abs().max() + 1e-12))
     cos = float((red.double() @ one.double()) / (red.double().norm() * one.double().norm() + 1e-30))
@@ -102,10 +103,11 @@ def main():
     eng.forward_backward(b, negatives=neg, train=True, dp_all=dp, on_other_grads_ready=agent.comm.reduce_other)
     agent.comm.reduce_swin_and_wait()
     torch.cuda.synchronize()
-    oa, oe = agent.comm.own                                   # ZeRO-1 (VMVM_ZERO1=1): a rank holds the reduced gradient of its shard only
-    red = S.grad[oa:oe] / world
-    mean_ref = mean_ref[oa:oe]
-    gather = [g_[oa:oe] for g_ in gather]
+    own = agent.comm.own                                      # ZeRO-1 (VMVM_ZERO1=1): a rank holds the reduced gradient of its parts only
+    cat_own = lambda t: torch.cat([t[lo:hi] for lo, hi in own])
+    red = cat_own(S.grad) / world
+    mean_ref = cat_own(mean_ref)
+    gather = [cat_own(g_) for g_ in gather]
     err = float((red - mean_ref).abs().max() / (mean_ref.abs().max() + 1e-12))
     wire = agent.comm.wire
     # f32 payload: the mean to rounding; bf16 payload: two roundings of 2^-9 relative each (cast + reduction), element by element

@@ -653,10 +653,7 @@ def check_attn_bert():
     ref.backward(dout.float())
     g0 = K.attention_bwd(dout, qkv, out1, lse1, nseq, Lq, heads, 64, 1, 0.125, **kw)
     g1 = K.attention_bwd(dout, qkv, out1, lse1, nseq, Lq, heads, 64, 1, 0.125, drop_mask=dm, **kw)
-    if os.environ.get("VMVM_FUSED_BWD"):          # the one-pass backward (taken with drop_mask) sums in another order than the two-kernel form (taken without)
-        rep("bert attn drop_mask bwd: one-pass kernel vs the two-kernel form", g1, g0, tol=1e-2)
-    else:
-        RESULTS.append(("bert attn drop_mask bwd bit-identical", float((g0 != g1).sum()), 0.0, bool((g0 != g1).any())))
+    RESULTS.append(("bert attn drop_mask bwd bit-identical", float((g0 != g1).sum()), 0.0, bool((g0 != g1).any())))
     rep("bert attn drop_mask bwd dq vs torch", g1[:, :Hd], qf.grad[:, :Hd])
     rep("bert attn drop_mask bwd dk vs torch", g1[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
     rep("bert attn drop_mask bwd dv vs torch", g1[:, 2 * Hd:], qf.grad[:, 2 * Hd:])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA lint of attention.hip and attention_win3.hip (compiles them to gfx950 assembly with hipcc --save-temps and inspects the text): properties the
+"""ISA lint of attention.hip, attention_win3.hip and attention_win4.hip (compiles them to gfx950 assembly with hipcc --save-temps and inspects the text): properties the
 compiler does not guarantee and that were each lost once without any test noticing until a flaky run --
 
 1. the hot loops of the batch-persistent window-attention kernels hold no `s_waitcnt vmcnt(0)` (= the wave drains the next
@@ -7,7 +7,9 @@ compiler does not guarantee and that were each lost once without any test notici
 2. every inline-asm `v_max3_f32` reads registers whose producing MFMA was issued >= MIN_DIST instructions earlier (hipcc does not
    insert MFMA-result wait states in front of inline asm);
 3. no `v_mfma_f32_16x16x16_bf16` result is the SrcC of the next-issued MFMA of the other shape (hipcc 7.2 emits no wait states for
-   that pair and the hardware does not forward between them: tools/probe/bias_mfma_probe.hip).
+   that pair and the hardware does not forward between them: tools/probe/bias_mfma_probe.hip);
+4. (round 5) the key-block walks of the win4 kernels hold no scratch traffic: a spill inside a walk is a scratch reload + s_waitcnt
+   vmcnt(0) per key block (the masked dK / dV build, opt-in and known to spill, is exempt).
 
 usage: python tools/isa_lint.py [path/to/attention.s]      (exit code 0 = clean)"""
 import os
@@ -26,7 +28,7 @@ def assembly():
     d = tempfile.mkdtemp()
     csrc = os.path.join(ROOT, "pytorch_empirical_mvm_amd", "csrc")
     out = []
-    for name in ("attention", "attention_win3"):          # both attention translation units (the win_layout = 1 kernels use the same idioms)
+    for name in ("attention", "attention_win3", "attention_win4"):          # the attention translation units (the win_layout = 1 kernels use the same idioms)
         subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-I", os.path.join(csrc, "hooks"),
                         "-c", os.path.join(csrc, name + ".hip"), "-o", os.path.join(d, name + ".o"), "-save-temps"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         out.append(open(os.path.join(d, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read())
@@ -43,6 +45,8 @@ def kernels(s):
 def main():
     bad = []
     for name, ins in kernels(assembly()):
+        if "kernel" not in name:                          # (data symbols, e.g. the W3_PA table)
+            continue
         short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:64]
         mf = [k for k, l in enumerate(ins) if l.startswith("v_mfma")]
         ex = [k for k, l in enumerate(ins) if l.startswith("v_exp_f32")]
@@ -52,6 +56,14 @@ def main():
             n_wf = sum(1 for k, l in enumerate(loop) if l.startswith("v_cmp_eq_u64") and any(x.startswith("s_and_saveexec") for x in loop[k:k + 5]))
             if n_vm or n_wf:
                 bad.append(f"{short}: {n_vm} vmcnt(0) drains and {n_wf} waterfall loops inside the hot loop")
+        if "win4_kernel" in name and ex and "attn_bwd_dkv_win4_kernelILb1" not in name:
+            exs = set(ex)
+            for k, l in enumerate(ins):
+                if l.startswith("scratch_"):
+                    before = any((k - d) in exs for d in range(1, 120))
+                    after = any((k + d) in exs for d in range(1, 120))
+                    if before and after:
+                        bad.append(f"{short}: {l.split()[0]} inside a key-block walk (instruction {k})")
         last = {}
         prev_mfma = None
         for k, l in enumerate(ins):
@@ -64,7 +76,7 @@ def main():
                 prev_mfma = (m.group(1), (int(m.group(2)), int(m.group(3))))
                 for r in range(int(m.group(2)), int(m.group(3)) + 1):
                     last[r] = k
-            if l.startswith("v_max3_f32"):
+            if l.startswith("v_max3_f32") and "win4_kernel" not in name:      # (the win4 kernels have no inline-asm maxima: theirs come from the compiler, which pads them)
                 for r in [int(x) for x in re.findall(r"v(\d+)", l)][1:]:
                     if r in last and k - last[r] < MIN_DIST:
                         bad.append(f"{short}: inline-asm v_max3_f32 reads v{r} {k - last[r]} instructions after the MFMA that writes it")

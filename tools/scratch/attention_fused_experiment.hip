@@ -1,3 +1,7 @@
+// NOT COMPILED (round 5: moved out of libvmvm.so).  The one-pass backward of the fusion encoder's attention built in
+// round 4: parity-green, 0-10 % slower than the two-kernel form it was meant to replace (profiles/r04_fused_attention_backward.txt,
+// DESIGN 8 round 4).  Kept as the record of the experiment; to revive it, move it back to csrc/, add it to build.SOURCES and restore
+// the vmvm_fused dispatch in attention.hip (git show caf873b:pytorch_empirical_mvm_amd/csrc/attention.hip | grep -n vmvm_fused).
 // attention_fused.hip -- the fusion encoder's attention backward (mode 1: 432-token sequences, head_dim 64, key mask, attention dropout
 // with the forward's stored decisions) in ONE pass: scores, probabilities and dS are computed once per score tile and feed dV, dK AND dQ.
 // The two-kernel form of attention.hip computes S and dP twice (14 MFMAs + two softmax chains + two mask evaluations per score tile);
