@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x 3 (C2/C3)
+EXECUTED_FLOP_PER_CLIP = 2.060e12 - 0.068e12 - 0.09 * 3 * 281.3e9      # minus the VTM pass' dead query rows and ~9 % of the Swin blocks (DropPath draws of 0): 1.916e12
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
@@ -181,7 +182,6 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--img", type=int, default=224, help="frame size; --size large --img 384 --frames 16 is BASELINE config 5's geometry (run at bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fp8", action="store_true", help="config 5's fp8 path: fusion qkv / FFN-in forward GEMMs on e4m3 operands (not the headline: C2 is bf16)")
     ap.add_argument("--host-masking", action="store_true", help="mask the batches on the host before the timed region (the round-1 default until device-side masking existed)")
     ap.add_argument("--mvm-target", default="pixel", help="pixel (C2/C3, the headline config), vq (C4: frozen dVAE tokenizer, random weights), 2d_feature (args_pretrain.json's own "
                     "default: frozen HF Swin-B teacher) or 3d_feature (frozen VideoSwin-B teacher)")
@@ -214,7 +214,7 @@ def main():
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     args = CFG.get_args(vis_backbone_size=a.size, size_frame=a.frames, max_size_frame=max(a.frames, 6), size_img=a.img, size_txt=32,
-                        mvm_target=[a.mvm_target], max_iter=10000, seed=88 + rank, fp8_forward=a.fp8)
+                        mvm_target=[a.mvm_target], max_iter=10000, seed=88 + rank)
     model = VIOLET_Pretrain(args, None, device=device)
     agent = Agent_Pretrain(args, model)
     agent.prepare_dist_model()
@@ -280,24 +280,28 @@ def main():
         label = {"pixel": "C2", "vq": "C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)"}.get(
             a.mvm_target, f"C2 shapes with the {a.mvm_target} target (frozen Swin-B teacher on the same kernels, random weights)")
     elif a.size == "large" and a.img == 384 and a.frames == 16:
-        label = ("C5 geometry, fp8 (e4m3) forward GEMMs in the fusion encoder's qkv / FFN-in, everything else bf16" if a.fp8 else
-                 "C5 geometry at bf16 (--fp8 switches the fusion qkv / FFN-in forward GEMMs to e4m3)") + "; streaming attention kernels"
+        label = "C5 geometry at bf16 (the opt-in e4m3 forward of rounds 1-4 never moved this number and was removed in round 5, DESIGN 7); streaming attention kernels"
     else:
         label = "non-headline shape"
     out = {
         "metric": "pretrain clips/sec (Swin-B, 8x224^2, 32 txt tok)" if headline else f"pretrain clips/sec (Swin-{a.size}, {a.frames}x{a.img}^2, 32 txt tok)", "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "host_issue_ms_per_step": round(dt_host / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16+fp8" if a.fp8 else "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{label}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window{window}, {a.frames}x{a.img}^2 frames, 32 text tokens, "
                                f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip, "
                                f"{'device-side rm/bm masking inside the timed step' if mask_in_step else 'masking before the timed region'}",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+        # two fractions of the dense bf16 MFMA peak: of the reference's ALGORITHMIC step FLOPs (2.060 TFLOP per clip -- the
+        # metric's definition) and of the FLOPs this build EXECUTES (EXECUTED_FLOP_PER_CLIP: the dead query rows of the VTM pass' last fusion
+        # layer, 0.068 TFLOP per clip, and on average ~9 % of the Video-Swin block FLOPs -- clip-branches whose DropPath draw is 0 -- are
+        # never computed; same losses and gradients)
         "step_mfma_frac": round(value * TRAIN_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
-        # algorithmic FLOPs of the reference's step (2.060 TFLOP per clip).  Executed: 3.3 % fewer -- in the last fusion layer only the
-        # text [CLS] query row of the VTM sequences is computed (the only row the VTM head reads; same losses and gradients)
-        "step_flop_note": "step_mfma_frac counts the reference's algorithmic 2.060 TFLOP/clip; not executed: 0.068 TFLOP/clip of dead query rows in the VTM pass' last fusion layer and, "
-                          "on average, ~9 % of the Video-Swin block FLOPs (clip-branches whose DropPath draw is 0) -- results are those of the full computation; "
-                          "VMVM_QROW=0 VMVM_DROPPATH_DCE=0 executes everything as the reference formulates it (same build, one box: 114.6-115.0 ms against 110.2-110.9)",
+        "step_mfma_frac_executed": round(value * EXECUTED_FLOP_PER_CLIP / (world * PEAK_BF16), 4) if (a.mvm_target == "pixel" and headline) else None,
+        "step_flop_note": "step_mfma_frac counts the reference's algorithmic 2.060 TFLOP/clip, step_mfma_frac_executed the 1.916 TFLOP/clip this build executes: not executed are "
+                          "0.068 TFLOP/clip of dead query rows in the VTM pass' last fusion layer and, on average, ~9 % of the Video-Swin block FLOPs (clip-branches whose DropPath "
+                          "draw is 0) -- results are those of the full computation; VMVM_QROW=0 VMVM_DROPPATH_DCE=0 executes everything as the reference formulates it "
+                          "(round-5 build, one box, interleaved pairs: 106.41-106.43 ms against 102.72-102.77)",
+        "switches": model.engine.sw.describe(),               # every VMVM_* step-path switch that differs from its default (empty: the measured-winner configuration)
         "roofline": {"bound": "mfma", "achieved": round(kflop / kt / 1e12, 1) if kt else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(kflop / kt / PEAK_BF16, 4) if kt else None, "traffic": pmc_traffic_bytes(),
                      "kernel": f"fusion FFN fc1 GEMM + bias + GELU + saved 8-bit GELU' code (M={B * (1 + O) * Lq}, N=3072, K=768; 2*M*N*K flop per launch), "

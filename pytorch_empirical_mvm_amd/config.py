@@ -75,7 +75,6 @@ def model_cfg(args):
     cfg["teacher_arch"] = dict(args["teacher_arch_override"]) if args.get("teacher_arch_override") else dict(ARCH["base"])
     cfg["pretrain_tasks"] = tuple(args.get("pretrain_tasks", ("vtm", "mlm", "mvm")))      # "smtm" adds the seq2seq MLM pass
     cfg["task"] = args.get("task", "pretrain")
-    cfg["fp8_forward"] = bool(args.get("fp8_forward", False))     # config 5: fp8 forward GEMMs (fusion qkv / FFN-in)
     cfg["size_vocab"] = args.get("size_vocab", 0)        # open-ended QA answer vocabulary (main_qaoe.py:47)
     return cfg
 

@@ -64,25 +64,8 @@ __device__ __forceinline__ void w4_wait_v(s16x4& a0, s16x4& a1, s16x4& c0, s16x4
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1) : "i"(N));
 }
 
-// windowed table copy with 256-byte rows (attn_win3_dev.h builds 192-byte rows: the two table rows a b128 read touches -- lq = 0 / 1 --
-// then sit 48 banks apart and the windows (lq 1, s) and (lq 0, s - 4) collide 2-way: 30 % of the LDS cycles of the first win4 forward
-// were bank-conflict cycles, profiles/r05_pmc_window_attention_win4.txt; with 64-bank rows the three distinct (row, window) runs of every
-// 16-lane group fall on disjoint banks).  Row layout as w3_build_table: 12 windows of 4 consecutive entries, row 169 = -inf.
-constexpr int W4_ROWB = 256;
-constexpr int W4_TAB_BYTES = w3::NROW * W4_ROWB;      // 43 520
-template <int DIR>
-__device__ __forceinline__ void w4_build_table(unsigned char* tl, const float* stage, int tid, int nthreads) {
-  for (int i = tid; i < w3::NROW * 12; i += nthreads) {
-    const int rho = i / 12, s = i - rho * 12;
-    f32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = DIR ? s + j : 14 - s - j;
-      v[j] = rho < 169 ? stage[e * 169 + rho] : NEG_INF;
-    }
-    *reinterpret_cast<f32x4*>(tl + rho * W4_ROWB + s * 16) = v;
-  }
-}
+constexpr int W4_ROWB = w3::ROWB;                  // 256-byte table rows (attn_win3.h: bank-conflict-free b128 reads)
+constexpr int W4_TAB_BYTES = w3::TAB_BYTES;
 // How the next sequence's register fragments are fetched (measured, tools/scratch/w4_timeline.py): they are requested by PLAIN loads in
 // the epilogue, in front of the output stores, and an empty asm statement behind the stores makes the compiler wait for them there --
 // inside one basic block it counts the stores and emits s_waitcnt vmcnt(#stores), so the stores stay in flight (their acknowledgement
@@ -118,7 +101,7 @@ __global__ __launch_bounds__(832) void attn_fwd_win4_kernel(const vmvm_attn_fwd_
     float* stage = reinterpret_cast<float*>(smem + 2 * KV);
     for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
     __syncthreads();
-    w4_build_table<0>(TL, stage, tid, NWV * 64);
+    w3_build_table<0>(TL, stage, tid, NWV * 64);
     __syncthreads();
   }
   // this wave's query tiles (wave 12: tile 24 only)
@@ -457,7 +440,7 @@ __global__ __launch_bounds__(832) void attn_bwd_dkv_win4_kernel(const vmvm_attn_
     float* stage = reinterpret_cast<float*>(smem + BUF);
     for (int i = tid; i < 15 * 169; i += NWV * 64) stage[i] = p.bias_table[(size_t)i * heads + h];
     __syncthreads();
-    w4_build_table<1>(TL, stage, tid, NWV * 64);
+    w3_build_table<1>(TL, stage, tid, NWV * 64);
     __syncthreads();
   }
   const bool odd = !MASK && wave == NWV - 1;              // (the masked build runs wave 12 as a two-tile job with the all-padding tile 25: 18 walk variants spill where 9 do not)

@@ -14,9 +14,11 @@ namespace w3 {
 
 constexpr int NT = 25;                       // 16-token tiles per window
 constexpr int L = 392;
-constexpr int ROWB = 192;                    // bytes of one row of the windowed table: 12 windows of 4 consecutive f32 entries
+constexpr int ROWB = 256;                    // bytes of one row of the windowed table: 12 windows of 4 consecutive f32 entries (192 bytes) padded to 64 banks --
+                                             // at 192 the two rows a b128 read touches sit 48 banks apart and (row + 1, window s) collides with (row, s - 4): 18-34 % of
+                                             // the LDS cycles of the round-4 backward kernels were bank conflicts (profiles/r04_pmc_window_attention_*.txt, r05_pmc_*)
 constexpr int NROW = 170;                    // 169 rows rho + the padding row (-inf)
-constexpr int TAB_BYTES = NROW * ROWB;       // 32 640
+constexpr int TAB_BYTES = NROW * ROWB;       // 43 520
 constexpr int PH[50] = {0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,            // A
                         0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3,                        // B (pairs along h)
                         4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6,                        // C

@@ -20,7 +20,7 @@ __device__ __forceinline__ void w3_build_table(unsigned char* tl, const float* s
       const int e = DIR ? s + j : 14 - s - j;
       v[j] = rho < 169 ? stage[e * 169 + rho] : NEG_INF;
     }
-    *reinterpret_cast<f32x4*>(tl + i * 16) = v;
+    *reinterpret_cast<f32x4*>(tl + rho * w3::ROWB + s * 16) = v;
   }
 }
 // A = 13 h + w of slot position `pos` (run-time index, set-up code only): a namespace-scope table (a function-local constexpr array

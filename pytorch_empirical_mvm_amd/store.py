@@ -114,28 +114,10 @@ class ParamStore:
             o += self.index[n][1]
         return buf[o0:o].view(shape)
 
-    W8_SCALE = 512.0        # static per-tensor scale of the fp8 weight copies (|w| up to 0.875 before e4m3 saturates at 448)
-
     def refresh_shadow(self):
         self.sync_pending()
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
         self.refresh_transposed()
-        if getattr(self, "shadow8", None) is not None:
-            K.cast_fp8(self.shadow[:self.total8], self.W8_SCALE, out=self.shadow8[:self.total8])
-
-    def enable_fp8(self):
-        """allocate the e4m3 copy of the arena (BASELINE config 5's fp8 forward GEMMs); refreshed with the bf16 copy"""
-        self.sync_pending()
-        if getattr(self, "shadow8", None) is None and self.device.type == "cuda":
-            self.total8 = -(-self.total // 8) * 8
-            self.shadow8 = torch.zeros(self.total8 + self.TAIL, device=self.device, dtype=torch.uint8)
-            K.cast_fp8(self.shadow[:self.total8], self.W8_SCALE, out=self.shadow8[:self.total8])
-
-    def b8(self, n, shape=None):
-        return self._view(self.shadow8, n, shape)
-
-    def fused8(self, names, shape):
-        return self.fused(self.shadow8, names, shape)
 
     # ---- W^T copies (bf16) of every Linear weight: dgrad dX = dY W then runs as a k-major x k-major GEMM
     def build_transpose_table(self):

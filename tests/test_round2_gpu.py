@@ -2,8 +2,7 @@
 
 * full-size C2 (Swin-B, 8 x 224^2, 432-token fusion sequences) PER-TENSOR gradients against the oracle's autograd -- the 18-deep
   stage 3, 16 / 32 heads, split-K weight gradients at K = 50 176 tokens and the fused bias-gradient column sums end to end;
-* full-width config 5 (Swin-L-384, window (8,12,12), 16 x 384^2) step with and without the fp8 forward GEMMs;
-* several optimizer steps with fp8 forward: the e4m3 weight copy follows the optimizer (ADVICE r01, high);
+* full-width config 5 (Swin-L-384, window (8,12,12), 16 x 384^2) step;
 * the native dVAE tokenizer against the ORACLE's encoder (not against the package's own torch path);
 * RCCL itself: backend nccl at world size 1 with the reducer active (VMVM_FORCE_DIST) == the run without a reducer;
 * evaluate() / step(is_train=False) incl. the smtm accuracy; save_model -> load_ckpt with the max_size_frame 6 -> 8 resize rule;
@@ -100,35 +99,31 @@ def test_full_size_c2_gradients_vs_oracle():
 
 
 @pytest.mark.timeout(1200)
-def test_full_width_c5_step_bf16_and_fp8():
+def test_full_width_c5_step():
     """BASELINE config 5 at full width (Swin-L, 16 x 384^2 frames, window (8,12,12): 1152-token windows, 2352-token fusion
-    sequences on the streaming attention kernels), B = 2: one training step each with bf16 and with the fp8 (e4m3) forward GEMMs;
-    finite, and the two agree on every loss within 5 %."""
+    sequences on the streaming attention kernels), B = 2: one training step; finite losses, a positive finite gradient norm.  (Rounds 1-4
+    ran this twice, with and without the opt-in e4m3 forward GEMMs; that path was removed in round 5 -- DESIGN 7 -- and the full-width
+    forward is now pinned to the oracle in tests/test_round5_gpu.py.)"""
     from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
     import bench
-    res = {}
-    for fp8 in (False, True):
-        model, args = _engine(dict(vis_backbone_size="large", size_frame=16, max_size_frame=16, size_img=384, max_iter=100, fp8_forward=fp8, seed=88))
-        agent = Agent_Pretrain(args, model)
-        agent.sched_step = 10
-        img, txt, mask = bench.synth_batch(args, 2, "cuda", 123)
-        import random
-        random.seed(5); np.random.seed(5); torch.manual_seed(5)
-        mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
-        model.eval()                     # dropout / DropPath off so that the two runs see the same network
-        eng = model.engine
-        b = dict(img=mb["unmask_img"].float().contiguous(), cov=mb["cov"].contiguous(), txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"])
-        losses, _ = eng.forward_backward(b, negatives=np.array([[1], [0]]), train=False, backward=True)
-        agent.backward_step()
-        torch.cuda.synchronize()
-        res[fp8] = {k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}
-        assert all(np.isfinite(v) for v in res[fp8].values()), res
-        assert np.isfinite(agent.grad_norm()) and agent.grad_norm() > 0
-        del model, agent, eng
-        torch.cuda.empty_cache()
-    for k in ("mtm", "mvm"):
-        assert abs(res[True][k] - res[False][k]) <= 5e-2 * abs(res[False][k]), res
-    assert abs(res[True]["vtm"] - res[False]["vtm"]) <= 5e-2 * abs(res[False]["vtm"]) + 5e-2, res
+    model, args = _engine(dict(vis_backbone_size="large", size_frame=16, max_size_frame=16, size_img=384, max_iter=100, seed=88))
+    agent = Agent_Pretrain(args, model)
+    agent.sched_step = 10
+    img, txt, mask = bench.synth_batch(args, 2, "cuda", 123)
+    import random
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
+    model.eval()
+    eng = model.engine
+    b = dict(img=mb["unmask_img"].float().contiguous(), cov=mb["cov"].contiguous(), txt=mb["txt"], mask=mb["mask"], ans_mtm=mb["ans_mtm"])
+    losses, _ = eng.forward_backward(b, negatives=np.array([[1], [0]]), train=False, backward=True)
+    agent.backward_step()
+    torch.cuda.synchronize()
+    res = {k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}
+    assert all(np.isfinite(v) for v in res.values()), res
+    assert np.isfinite(agent.grad_norm()) and agent.grad_norm() > 0
+    del model, agent, eng
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.timeout(900)
@@ -175,39 +170,6 @@ def test_gelu_code8_step_equals_bf16_preactivation_step():
             bad.append((n, round(cos, 5), round(ratio, 4)))
     assert checked > 300 and not bad, (checked, bad[:12])
 
-
-def test_fp8_weight_copy_follows_the_optimizer():
-    """with fp8_forward the e4m3 weight copy must be re-cast after every AdamW step; the loss trajectory of
-    three steps tracks the bf16 run."""
-    from oracle import violet_ref as R
-    from pytorch_empirical_mvm_amd import kernels as K
-    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
-    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
-    traj = {}
-    for fp8 in (False, True):
-        model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, arch_override=arch, bert_layers=2, max_iter=20,
-                                   lr=1e-3, size_img=96, temp=1.0, fp8_forward=fp8))
-        cfg = R.make_cfg("tiny", T=4, img=96, arch=arch, bert_layers=2, temp=1.0)
-        model.load_state_dict(R.make_state_dict(cfg))
-        img, txt, mask = R.make_batch(cfg, 2)
-        mb = R.default_masking(cfg, img, txt, mask, seed=1)
-        cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
-        agent = Agent_Pretrain(args, model)
-        agent.sched_step = 5
-        b = dict(img=img.cuda(), cov=cov.cuda().contiguous(), txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
-        S = model.engine.store
-        out = []
-        for _ in range(3):
-            losses, _ = model.engine.forward_backward(b, negatives=R.vtm_negatives_default(2), train=False, backward=True)
-            agent.backward_step()
-            out.append(float(losses["mtm"].item()) + float(losses["mvm"].item()))
-            if fp8:
-                want = K.cast_fp8(S.shadow[:S.total8], S.W8_SCALE)
-                assert torch.equal(want, S.shadow8[:S.total8]), "e4m3 weight copy is stale after the optimizer step"
-        traj[fp8] = out
-    assert traj[False][2] < traj[False][0]                      # lr 1e-3: the loss moves
-    for a, b_ in zip(traj[False], traj[True]):
-        assert abs(a - b_) <= 3e-2 * abs(a), traj
 
 
 @pytest.mark.timeout(600)

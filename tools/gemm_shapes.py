@@ -74,6 +74,52 @@ agent.step(mb, is_train=True, sync=False)
 torch.cuda.synchronize()
 tot = sum(v[1] for v in stats.values())
 print(f"GEMM total {tot:.1f} ms over {sum(v[0] for v in stats.values())} calls (B={B})")
-print(f"{'M':>8} {'N':>6} {'K':>8} lay {'n':>4} {'ms':>8} {'avg_us':>8} {'TF':>7}  epilogue")
-for (M, N, Kd, fl, epi), (n, ms) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-    print(f"{M:8d} {N:6d} {Kd:8d} {fl}  {n:4d} {ms:8.2f} {ms / n * 1e3:8.1f} {2.0 * M * N * Kd * n / ms / 1e9:7.1f}  {epi}")
+# the vendor library on the same shapes (plain bf16 GEMM, no epilogue: torch.matmul -> hipBLASLt), as the practical ceiling of each
+# shape: the same operand layouts, 5 timed launches after 2 warm-up launches, alone on the device
+_ref = {}
+
+
+def blaslt_tf(M, N, Kd, fl):
+    key = (M, N, Kd, fl)
+    if key not in _ref:
+        try:
+            if fl == "TT":
+                a, b = torch.randn(M, Kd, device=dev, dtype=torch.bfloat16), torch.randn(N, Kd, device=dev, dtype=torch.bfloat16)
+                f = lambda: torch.matmul(a, b.t())
+            elif fl == "NN":
+                a, b = torch.randn(Kd, M, device=dev, dtype=torch.bfloat16), torch.randn(Kd, N, device=dev, dtype=torch.bfloat16)
+                f = lambda: torch.matmul(a.t(), b)
+            elif fl == "TN":
+                a, b = torch.randn(M, Kd, device=dev, dtype=torch.bfloat16), torch.randn(Kd, N, device=dev, dtype=torch.bfloat16)
+                f = lambda: torch.matmul(a, b)
+            else:
+                a, b = torch.randn(Kd, M, device=dev, dtype=torch.bfloat16), torch.randn(N, Kd, device=dev, dtype=torch.bfloat16)
+                f = lambda: torch.matmul(a.t(), b.t())
+            for _ in range(2):
+                f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            _ref[key] = 2.0 * M * N * Kd * 5 / e0.elapsed_time(e1) / 1e9
+            del a, b
+        except Exception:
+            _ref[key] = float("nan")
+    return _ref[key]
+
+
+K.gemm = orig
+print(f"{'M':>8} {'N':>6} {'K':>8} lay {'n':>4} {'ms':>8} {'avg_us':>8} {'TF':>7} {'blasLt':>7} {'ours/lt':>7}  epilogue   (blasLt = torch.matmul, plain bf16 GEMM of the shape, no epilogue)")
+rows = sorted(stats.items(), key=lambda kv: -kv[1][1])
+behind = []
+for (M, N, Kd, fl, epi), (n, ms) in rows:
+    tf = 2.0 * M * N * Kd * n / ms / 1e9
+    lt = blaslt_tf(M, N, Kd, fl) if ms / tot > 0.002 else float("nan")       # (shapes below 0.2 % of the GEMM time: not timed)
+    print(f"{M:8d} {N:6d} {Kd:8d} {fl}  {n:4d} {ms:8.2f} {ms / n * 1e3:8.1f} {tf:7.1f} {lt:7.1f} {tf / lt if lt == lt else float('nan'):7.2f}  {epi}")
+    if lt == lt and epi in ("", "res", "bias") and tf < 0.9 * lt:
+        behind.append((M, N, Kd, fl, epi, round(tf), round(lt)))
+print(f"plain / bias / residual-class shapes more than 10 % behind the vendor GEMM: {len(behind)}")
+for b_ in behind:
+    print("   ", b_)
