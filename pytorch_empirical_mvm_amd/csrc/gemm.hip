@@ -1413,11 +1413,20 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // (explicit: the split below offsets A / C / resid by ROWS of 2-byte elements -- k-major operands, 16-bit output, no row map /
     //  column sums / accumulation.  pp_shape implies all of this today; the split must not depend on that staying true.)
     const bool split_ok = dd.a_kmajor && dd.b_kmajor && !dd.out_fp32 && !dd.row_map && !dd.colsum && !dd.accumulate && !dd.in_fp8 && !dd.conv_taps;
-    if (pays && split_ok && dd.variant == 0 && dd.K >= 2048 && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
+    // (round 5: also at 1024 <= K < 2048 and where the ping-pong kernel alone does not "pay" -- 47040 x 512 x 1536 is 368 tiles -- when the
+    // remainder fits ONE round of quarter tiles: whole ping-pong rounds + one 128x128 round beat 2.9 rounds of the 128x128 kernel)
+    const long rem_q_all = tiles > cus_ ? (long)((dd.M - (int)(((tiles / cus_) * cus_) / ((dd.N + 255) / 256)) * 256 + 127) / 128) * ((dd.N + 127) / 128) : (1L << 40);
+    const bool split_fits = dd.K >= 1024 && dd.N >= 512 && rem_q_all <= 2 * cus_;
+    if ((pays || split_fits) && split_ok && dd.variant == 0 && (dd.K >= 2048 || split_fits) && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
       const int nbn_ = (dd.N + 255) / 256, nbm_ = (dd.M + 255) / 256;
       const int tm_split = (int)(((tiles / cus_) * cus_) / nbn_);
       const long rem_tiles = (long)(nbm_ - tm_split) * nbn_;
-      if (tm_split > 0 && tm_split < nbm_ && rem_tiles <= cus_ / 4) {
+      // Round 5: the remainder may be up to ONE round of the 128x128 kernel's 2 x CUs slots (quarter-size tiles): 47040 x 512 x 2048 is
+      // 368 tiles = 1.44 rounds, i.e. two ping-pong rounds (126 us, 784 TF against hipBLASLt's 1204); one whole round (32768 rows) + the
+      // other 14272 rows as 448 quarter tiles in one 128x128 round is 48 + 36 us by the tile times of the two kernels.  (Round 3 allowed
+      // a quarter of a round only: its counter-example, 50176 x 512, leaves 544 quarter tiles -- a second 128x128 round.)
+      const long rem_q = (long)((dd.M - tm_split * 256 + 127) / 128) * ((dd.N + 127) / 128);
+      if (tm_split > 0 && tm_split < nbm_ && (rem_tiles <= cus_ / 4 || rem_q <= 2 * cus_)) {
         const int m_split = tm_split * 256;
         vmvm_gemm_desc d1 = dd;
         d1.M = m_split;

@@ -15,6 +15,7 @@ import torch
 
 from . import config as CFG
 from .engine import ParamStore, VioletEngine
+from .switches import Switches
 
 
 class _NoTape(list):
@@ -40,6 +41,7 @@ class SwinTeacher:
         eng.seed, eng.rng_offset, eng._idx_cache, eng.tape = int(seed), 0, {}, []
         eng.teacher = eng.feature_teacher = eng.on_swin_tail_ready = None
         eng.dpr = [0.0] * sum(cfg["depths"])
+        eng.sw = Switches.from_env()
         self.eng = eng
         self.feat_size = self.arch["embed_dim"] * 8
 
