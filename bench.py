@@ -25,7 +25,7 @@ TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x
 EXECUTED_FLOP_PER_CLIP = 2.060e12 - 0.068e12 - 0.09 * 3 * 281.3e9      # minus the VTM pass' dead query rows and ~9 % of the Swin blocks (DropPath draws of 0): 1.916e12
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
 
 
 def pmc_traffic_bytes():
