@@ -317,16 +317,10 @@ class Agent_Pretrain:
                 for gi in (1, 3):
                     a, e = S.segments[gi]
                     S.grad[a:e].zero_()
-                # (round 5) the W^T copies of the SWIN weights too: only the backward's input-gradient GEMMs read them, a whole forward later --
-                # on the main stream their transposes (0.9 ms per step) sat in front of the next forward.  The side stream started behind the
-                # Swin update (wait_stream above), and every reader is behind encode()'s sync_pending() on `other_ready`.
-                if eng.sw.swin_wt_side:
-                    S.refresh_transposed("swin")
                 eng.other_ready = torch.cuda.Event()
                 eng.other_ready.record()
                 S.pending = eng.other_ready              # (ParamStore.sync_pending: every reader of the non-Swin arena waits for this)
-            if not eng.sw.swin_wt_side:
-                S.refresh_transposed("swin")
+            S.refresh_transposed("swin")                 # (measured in round 5: on the side stream instead -- the backward is their only reader -- the step is the same, 106.74 vs 106.83 ms)
             for gi in (0, 2):
                 a, e = S.segments[gi]
                 S.grad[a:e].zero_()

@@ -24,7 +24,6 @@ class Switches:
     gelu_code8: bool = True        # VMVM_GELU_CODE8: GELU' saved as an 8-bit code
     wgrad_stream: bool = True      # VMVM_WGRAD_STREAM: weight gradients on a second HIP stream
     opt_overlap: bool = True       # VMVM_OPT_OVERLAP: optimizer tail of the non-Swin groups beside the next forward
-    swin_wt_side: bool = True      # VMVM_SWIN_WT_SIDE: the Swin weights' W^T copies (read by the backward only) refreshed on the side stream too
     zero1: bool = False            # VMVM_ZERO1: ZeRO-1 shape of the data-parallel step
     grad_wire: str = "bf16"        # VMVM_GRAD_WIRE: gradient payload on the wire (bf16 | f32)
     comm_cus: int = 16             # VMVM_COMM_CUS: CUs left to the collective while it is in flight
@@ -43,7 +42,6 @@ class Switches:
         s.gelu_code8 = _flag(env, "VMVM_GELU_CODE8", True)
         s.wgrad_stream = _flag(env, "VMVM_WGRAD_STREAM", True)
         s.opt_overlap = _flag(env, "VMVM_OPT_OVERLAP", True)
-        s.swin_wt_side = _flag(env, "VMVM_SWIN_WT_SIDE", True)
         s.zero1 = env.get("VMVM_ZERO1", "0") == "1"
         w = env.get("VMVM_GRAD_WIRE", "bf16").lower()
         if w not in ("bf16", "f32"):
