@@ -2635,6 +2635,8 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       // Measured and not kept (round 4, profiles/r04_ab_fusion_attention_variants.txt): two key tiles per wave in dK/dV (KTP = 2), two query
       // tiles per wave in dQ (QT = 2) -- half the LDS bytes per score tile, same time: these kernels are not LDS-bound --, and 9 waves
       // (3 full passes over the 27 owner tiles instead of 3 + a 3-wave pass): slower, the 8-wave form already loads the SIMDs 7/7/7/6.
+      // (round 5: a key-blocked, persistent dQ kernel -- tools/scratch/attention_fus4_experiment.hip -- is 17 % faster alone and changes
+      //  nothing in the step: DESIGN 8 round 5)
       LAUNCH_BWD_DQ(64, 1, 8, 27);
       LAUNCH_BWD(attn_bwd_dkv_kernel, 64, 1, 8, 2, 27);
     } else {

@@ -657,6 +657,36 @@ def check_attn_bert():
     rep("bert attn drop_mask bwd dq vs torch", g1[:, :Hd], qf.grad[:, :Hd])
     rep("bert attn drop_mask bwd dk vs torch", g1[:, Hd:2 * Hd], qf.grad[:, Hd:2 * Hd])
     rep("bert attn drop_mask bwd dv vs torch", g1[:, 2 * Hd:], qf.grad[:, 2 * Hd:])
+    # masked keys anywhere in the sequence (not only the padded text tail), 26 sequences x 12 heads = 312 (sequence, head) units,
+    # with and without dropout + record
+    nseq2 = 26
+    qkv2 = rnd(nseq2 * Lq, 3 * Hd)
+    km2 = torch.ones(nseq2, Lq, dtype=torch.uint8, device=dev)
+    km2[0, 37] = 0; km2[1, 200:216] = 0; km2[2, 0:3] = 0; km2[3, 120:330] = 0; km2[4, 431] = 0
+    for s_ in range(5, nseq2):
+        km2[s_, torch.randperm(Lq, device=dev)[: 3 * s_]] = 0
+    for pdrop in (0.0, 0.1):
+        kw2 = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=km2, dropout_p=pdrop, seed=5, offset=3)
+        dm2 = K.attention_drop_mask(nseq2, Lq, heads, 64, 1, 0.1, dev) if pdrop else None
+        o2, l2 = K.attention_fwd(qkv2, nseq2, Lq, heads, 64, 1, 0.125, drop_mask=dm2, **kw2)
+        if pdrop:
+            b2 = ((dm2.view(nseq2 * heads, 27, 27, 4, 2, 1).to(torch.int64) >> torch.arange(32, device=dev)) & 1).reshape(nseq2 * heads, 27, 27, 4, 4, 16)
+            mask2 = (1.0 - b2.permute(0, 1, 5, 2, 4, 3).reshape(nseq2, heads, Lq, Lq).float()) * (65536.0 / (65536.0 - 6554.0))
+        else:
+            mask2 = 1.0
+        qf2 = qkv2.float().requires_grad_(True)
+        x2 = qf2.view(nseq2, Lq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        sc2 = (x2[0] * 0.125) @ x2[1].transpose(-1, -2) + torch.where(km2.bool(), 0.0, float("-inf"))[:, None, None, :]
+        ref2 = ((torch.softmax(sc2, -1) * mask2) @ x2[2]).transpose(1, 2).reshape(nseq2 * Lq, Hd)
+        do2 = rnd(nseq2 * Lq, Hd)
+        ref2.backward(do2.float())
+        g2 = K.attention_bwd(do2, qkv2, o2, l2, nseq2, Lq, heads, 64, 1, 0.125, drop_mask=dm2, **kw2)
+        tag2 = f"bert attn scattered key mask, 312 units, p={pdrop}"
+        rep(tag2 + " fwd", o2, ref2)
+        rep(tag2 + " bwd dq", g2[:, :Hd], qf2.grad[:, :Hd])
+        rep(tag2 + " bwd dk", g2[:, Hd:2 * Hd], qf2.grad[:, Hd:2 * Hd])
+        rep(tag2 + " bwd dv", g2[:, 2 * Hd:], qf2.grad[:, 2 * Hd:])
+        del qf2, x2, sc2, ref2, mask2
     # a problem without a stored-decision build refuses the buffer
     try:
         K.attention_fwd(qkv[: 2 * 100], 2, 100, heads, 64, 1, 0.125, drop_mask=dm, q_off=0, k_off=Hd, v_off=2 * Hd, dropout_p=0.1, seed=1, offset=0)
