@@ -179,6 +179,13 @@ typedef struct {
    * (every source row gathered by at most one output row: vmvm_invert_map keeps one of several and the others' dY would be lost);
    * anything else is refused / undefined. */
   const int32_t* inv; int32_t rows_in_total;
+  /* optional (identity walk only: src == NULL), NULL = off: dX row m is written to row dx_map[m % dx_map_len] + (m / dx_map_len) *
+   * dx_map_len instead of row m -- a per-batch PERMUTATION (every entry in [0, dx_map_len), each once; M a multiple of dx_map_len).
+   * Video-Swin block backward: the norm2 backward writes d(x1) straight in the block's WINDOW order (dx_map = the inverse window map),
+   * which is where the projection's backward GEMMs and the norm1 backward (add_by_out) want it -- no gather pass, no natural-order copy. */
+  const int32_t* dx_map; int32_t dx_map_len;
+  /* with src (nseg == 1): dX_add is indexed by the OUTPUT row m (like dY) instead of the source row */
+  int32_t add_by_out;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);
 /* out[0..n_out) = -1, then out[src[i]] = i for every src[i] >= 0 (i < n_src): the inverse of a gather map (vmvm_ln_bwd_desc.inv) */

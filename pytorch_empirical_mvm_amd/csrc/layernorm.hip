@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const v
           unpack_bf8(xraw[i], xv);
         }
         addv[i] = make_uint4(0, 0, 0, 0);
-        if (ADD && srow[i] >= 0) addv[i] = *reinterpret_cast<const uint4*>(ADD + (size_t)srow[i] * p.ldadd + within[i]);
+        if (ADD && srow[i] >= 0) addv[i] = *reinterpret_cast<const uint4*>(ADD + (p.add_by_out ? (size_t)m * p.ldadd + col : (size_t)srow[i] * p.ldadd + within[i]));
         dyraw[i] = *reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col);
         unpack_bf8(dyraw[i], dyv);
         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const v
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += a[e];
         }
-        *reinterpret_cast<uint4*>(dX + (size_t)srow[i] * p.lddx + within[i]) = pack_bf8(o);
+        long drow = srow[i];
+        if (p.dx_map) { const long bb = m / p.dx_map_len; drow = (long)p.dx_map[m - bb * p.dx_map_len] + bb * p.dx_map_len; }     // (identity walk: srow = m)
+        *reinterpret_cast<uint4*>(dX + (size_t)drow * p.lddx + within[i]) = pack_bf8(o);
         if (dX2) {
           if (has_drop) {
             uint32_t bits[8];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
       }
       float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
       if (srow >= 0) load_x8<XF32>(p.X, (size_t)srow * p.ldx + within, xv);
-      if (ADD && srow >= 0) addv = *reinterpret_cast<const uint4*>(ADD + (size_t)srow * p.ldadd + within);
+      if (ADD && srow >= 0) addv = *reinterpret_cast<const uint4*>(ADD + (p.add_by_out ? (size_t)mm * p.ldadd + col : (size_t)srow * p.ldadd + within));
       unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)mm * p.lddy + col), dyv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -391,7 +393,9 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += a[e];
       }
-      *reinterpret_cast<uint4*>(dX + (size_t)srow * p.lddx + within) = pack_bf8(o);
+      long drow = srow;
+      if (p.dx_map) { const long bb = mm / p.dx_map_len; drow = (long)p.dx_map[mm - bb * p.dx_map_len] + bb * p.dx_map_len; }     // (identity walk: srow = mm)
+      *reinterpret_cast<uint4*>(dX + (size_t)drow * p.lddx + within) = pack_bf8(o);
       if (dX2) {
         if (has_drop) {
           uint32_t bits[8];
@@ -494,6 +498,8 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->dX2 && d->src) return VMVM_ENOSUPPORT;
   if (d->C > 6 * 512) return VMVM_ENOSUPPORT;
   if (d->inv && (!d->src || d->nseg != 1 || d->C > 256 || d->rows_in_total <= 0 || d->dX2 || d->pad_mode != 0)) return VMVM_ENOSUPPORT;     // source-major order: the packed kernels, one segment, pad slots constant zero (the walk never visits rows without a source, and with pad_mode != 0 those rows contribute dY to dgamma / dbeta)
+  if (d->dx_map && (d->src || d->inv || d->dx_map_len <= 0 || (d->M % d->dx_map_len))) return VMVM_EINVAL;      // scattered dX: the identity walk, whole batches
+  if (d->add_by_out && (!d->src || d->nseg != 1 || !d->dX_add)) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
   // Workgroups that fit per CU at the variant's VGPR count.  Allocation granule 8: the packed C <= 128 build takes 100 -> 104

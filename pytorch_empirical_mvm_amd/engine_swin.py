@@ -141,8 +141,28 @@ class SwinMixin:
                 K.copy_batches(x1, x2, drop_m, nd_m, L)
         out = V(x2)
 
+        # d(x1) straight in WINDOW order (blocks that run every clip, un-padded windows): the norm2 backward scatters its rows through the
+        # inverse window map (vmvm_ln_bwd_desc.dx_map), the projection's backward GEMMs read them in order and the norm1 backward takes
+        # them as its residual gradient by output row (add_by_out) -- no gather pass (2 x the activation bytes) and no natural-order d(x1)
+        win_dx1 = self.sw.dx1_window and not compact and not compact2 and Lp == L
+
         def bwd():
             dx2 = out.g
+            if win_dx1:
+                du = self._linear_bwd(dx2, h, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", row_scale=dpm, rows_per_scale=L, cs_scale=ds2.scale if (ds2 is not None and ds2.n_kept == B) else None,
+                                      dx_kw=dict(act=3, aux=u, row_scale=dpm, rows_per_scale=L, code8=c8))
+                dy2 = self._linear_bwd(du, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
+                inv_map = self._cached(("wminv", dims, ws, ss, w3), _inv_host)
+                dx1w, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2, dx_map=inv_map)
+                dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp,
+                                       cs_scale=ds.scale if (ds is not None and ds.n_kept == B) else None)
+                dqkv = K.attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, 0, scale,
+                                       dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
+                dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
+                dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
+                                        pad_mode=0, dX_add=dx1w, add_by_out=True, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L)
+                _acc(xv, dx)
+                return
             if compact2 and Bm == 0:
                 dx1 = dx2
             else:

@@ -151,7 +151,8 @@ def layernorm_fwd(X, gamma, beta, eps, *, M=None, C_=None, nseg=1, src=None, row
 
 
 def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=None, nseg=1, src=None, rows_out_per_batch=0,
-                  rows_in_per_batch=0, pad_mode=0, dX_add=None, want_dX2=False, dropout_p=0.0, seed=0, offset=0, inv=None):
+                  rows_in_per_batch=0, pad_mode=0, dX_add=None, want_dX2=False, dropout_p=0.0, seed=0, offset=0, inv=None, dx_map=None,
+                  add_by_out=False):
     M, Cc = dY.shape
     if dX is None:
         dX = torch.empty((rows_in if rows_in is not None else M, Cc // nseg), device=dY.device, dtype=BF16)
@@ -170,6 +171,8 @@ def layernorm_bwd(dY, X, gamma, mean, rstd, dgamma, dbeta, *, dX=None, rows_in=N
     d.workspace, d.workspace_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
     d.reserve_cus = reserve_cus()
     d.inv, d.rows_in_total = L.ptr(inv), (dX.shape[0] if inv is not None else 0)       # source-major walk (see include/vmvm.h)
+    d.dx_map, d.dx_map_len = L.ptr(dx_map), (dx_map.numel() if dx_map is not None else 0)       # identity walk: dX rows permuted per batch
+    d.add_by_out = int(add_by_out)
     L.check(L.load().vmvm_layernorm_bwd(C.byref(d), L.stream()), "layernorm_bwd")
     return dX, dX2
 

@@ -48,7 +48,8 @@ class LnBwdDesc(C.Structure):
                 ("pad_mode", c_int),
                 ("dX_add", c_void_p), ("ldadd", c_int),
                 ("dX2", c_void_p), ("lddx2", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("x_fp32", c_int),
-                ("workspace", c_void_p), ("workspace_bytes", c_u64), ("reserve_cus", c_int), ("inv", c_void_p), ("rows_in_total", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_u64), ("reserve_cus", c_int), ("inv", c_void_p), ("rows_in_total", c_int),
+                ("dx_map", c_void_p), ("dx_map_len", c_int), ("add_by_out", c_int)]
 
 
 class AttnFwdDesc(C.Structure):

@@ -18,6 +18,7 @@ def _flag(env, name, default):
 class Switches:
     win_layout: bool = True        # VMVM_WIN_LAYOUT: region-major token order inside (8,7,7) windows + the win3 / win4 attention kernels
     ln_src_major: bool = True      # VMVM_LN_SRC_MAJOR: LayerNorm backward of the window-gathered norm1 (C <= 256) walks the source rows
+    dx1_window: bool = True        # VMVM_DX1_WINDOW: norm2's backward writes d(x1) in the block's window order (no gather pass; blocks that run every clip)
     droppath_dce: str = "1"        # VMVM_DROPPATH_DCE: "1" both branches on the kept clips only, "attn" attention branch only, "0" every clip (scaled)
     qrow: bool = True              # VMVM_QROW: last fusion layer of the VTM sequences on the one query row the VTM head reads
     drop_mask: bool = True         # VMVM_DROP_MASK: fusion attention forward records its dropout decisions for the backward
@@ -36,6 +37,7 @@ class Switches:
         s = cls()
         s.win_layout = _flag(env, "VMVM_WIN_LAYOUT", True)
         s.ln_src_major = _flag(env, "VMVM_LN_SRC_MAJOR", True)
+        s.dx1_window = _flag(env, "VMVM_DX1_WINDOW", True)
         s.droppath_dce = env.get("VMVM_DROPPATH_DCE", "1")
         s.qrow = _flag(env, "VMVM_QROW", True)
         s.drop_mask = _flag(env, "VMVM_DROP_MASK", True)

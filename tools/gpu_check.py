@@ -433,6 +433,36 @@ def check_ln_gather():
                     src=src_abs, rows_out_per_batch=2 * Lp, rows_in_per_batch=B * Lq, pad_mode=0, dX_add=add, inv=inv_abs)
     rep("ln window-gather bwd, source-major, absolute map: kept clip", dxa[:Lq], dx[:Lq], tol=0)
     rep("ln window-gather bwd, source-major, absolute map: other clip untouched", dxa[Lq:], torch.full_like(dxa[Lq:], 7.0), tol=0)
+    # round 5: scattered dX of the identity walk (dx_map = a per-batch permutation) and the residual gradient by OUTPUT row (add_by_out):
+    # bit-identical to "ordinary backward, then permute the rows" / "gather the residual gradient first" -- un-padded window maps, the
+    # packed (C = 64, 128, 256) and the row-per-wave (C = 512) kernels
+    for (Cq, dims_q) in ((64, (8, 14, 14)), (128, (8, 14, 7)), (256, (8, 7, 14)), (512, (8, 14, 14))):
+        Dq, Hq, Wq = dims_q
+        wsq, ssq = SI.get_window_size(dims_q, (8, 7, 7), (0, 3, 3))
+        mq, _ = SI.window_map(Dq, Hq, Wq, wsq, ssq)
+        Lw = Dq * Hq * Wq
+        assert mq.size == Lw and (mq >= 0).all()
+        srcq = torch.from_numpy(mq).to(dev)
+        invq = K.invert_map(srcq, Lw)
+        xq = rnd(B * Lw, Cq)
+        gq = torch.randn(Cq, device=dev) * 0.1 + 1
+        bq = torch.randn(Cq, device=dev) * 0.1
+        # identity LayerNorm (norm2 of a block): dX through dx_map
+        yq, mq_, rq_ = K.layernorm_fwd(xq, gq, bq, 1e-5)
+        dyq, addq = rnd(B * Lw, Cq), rnd(B * Lw, Cq)
+        d0, d1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
+        dxn, _ = K.layernorm_bwd(dyq, xq, gq, mq_, rq_, d0, d1, dX_add=addq)
+        e0, e1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
+        dxw, _ = K.layernorm_bwd(dyq, xq, gq, mq_, rq_, e0, e1, dX_add=addq, dx_map=invq)
+        rep(f"ln bwd dx_map C={Cq}: rows = gather of the ordinary dX", dxw, K.gather_rows(dxn, srcq, B * Lw, Lw, Lw), tol=0)
+        rep(f"ln bwd dx_map C={Cq}: dgamma", e0, d0, tol=1e-6)
+        # gathered LayerNorm (norm1): residual gradient by output row
+        yg, mg_, rg_ = K.layernorm_fwd(xq, gq, bq, 1e-5, M=B * Lw, C_=Cq, nseg=1, src=srcq, rows_out_per_batch=Lw, rows_in_per_batch=Lw, pad_mode=0)
+        f0, f1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
+        dxa_, _ = K.layernorm_bwd(dyq, xq, gq, mg_, rg_, f0, f1, rows_in=B * Lw, nseg=1, src=srcq, rows_out_per_batch=Lw, rows_in_per_batch=Lw, pad_mode=0, dX_add=dxn)
+        h0, h1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
+        dxb_, _ = K.layernorm_bwd(dyq, xq, gq, mg_, rg_, h0, h1, rows_in=B * Lw, nseg=1, src=srcq, rows_out_per_batch=Lw, rows_in_per_batch=Lw, pad_mode=0, dX_add=dxw, add_by_out=True)
+        rep(f"ln bwd add_by_out C={Cq}: identical to the source-row form", dxb_, dxa_, tol=0)
     # gather_rows (window_partition of a gradient)
     gr = K.gather_rows(x, src, B * Lp, Lp, Lq)
     refg = torch.where((srcl >= 0)[None, :, None], x.float().view(B, Lq, C_)[:, srcl.clamp(min=0)], torch.zeros((), device=dev)).reshape(B * Lp, C_)
