@@ -11,6 +11,10 @@
   / attention dropout off.  Asserted: per-clip `out_mtm` / `out_mvm` / `out_vtm` equal within bf16 noise (cosine >= 0.9995 per output,
   max |diff| <= 5e-2 of the output scale: the two batch sizes take different GEMM tilings / split-K plans, so 36 layers of bf16 rounding
   differ -- measured 0.99989 / 2.1e-2 on out_mvm), losses within 1e-3 relative, gradient arena cosine >= 0.9995 and norm within 1 %.
+* `test_window_order_dx1_path_equals_gather_path`: the Video-Swin block backward with `norm2`'s backward writing d(x1) in window order
+  (`vmvm_ln_bwd_desc.dx_map` / `add_by_out`, `Switches.dx1_window`) against the form with the `gather_rows` pass: same kernels' arithmetic,
+  rows only routed differently -- the gradient arenas agree to f32 summation order (cosine >= 0.999999, every optimizer group).  Eval mode
+  (every block takes the path) and train mode with DropPath draws that leave some blocks whole and compact others.
 * `test_full_width_c5_forward_losses_vs_oracle`: BASELINE config 5 at FULL width (Swin-L, 16 x 384^2, 1152-token windows, 2352-token
   fusion sequences), B = 1, forward only, against the CPU oracle (earlier rounds pinned that geometry at reduced width only): losses
   within 2e-2 relative (vtm: 8e-2 absolute at temp 0.05), out_mvm / out_mtm cosine >= 0.999.
@@ -114,6 +118,52 @@ def test_full_width_c2_batch32_equals_eight_batches_of_four():
             if e > a:
                 cg = _cos(g32[a:e], gsum[a:e])
                 assert cg >= 0.999, (train, gi, cg)
+
+
+@pytest.mark.timeout(900)
+def test_window_order_dx1_path_equals_gather_path():
+    from oracle import violet_ref as R                    # (batch / weight generators only)
+    B = 4
+    cfg = R.make_cfg("base", T=8, temp=1.0)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8, temp=1.0))
+    model.load_state_dict(R.make_state_dict(cfg))
+    eng, S = model.engine, model.engine.store
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=3)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+    batch = dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+    neg = eng.sample_negatives(B, np.random.RandomState(7))
+    n_blk = sum(cfg["depths"])
+    rng = np.random.RandomState(11)
+    scales = np.ones((n_blk, 2, B), np.float32)
+    for blk in range(2, n_blk, 3):                         # every third block: one branch loses a clip (compacted: the gather path either way)
+        scales[blk, blk & 1, rng.randint(B)] = 0.0
+        scales[blk, blk & 1][scales[blk, blk & 1] != 0] = 1.25
+
+    def run(train, on):
+        eng.sw.dx1_window = on
+        S.grad.zero_()
+        kw = dict(train=True, dp_all=[(torch.from_numpy(scales[i, 0]).cuda(), torch.from_numpy(scales[i, 1]).cuda()) for i in range(n_blk)],
+                  dropout=False) if train else dict(train=False)
+        losses, _ = eng.forward_backward(batch, negatives=neg, backward=True, **kw)
+        torch.cuda.synchronize()
+        return {k: float(losses[k].item()) for k in ("mtm", "mvm", "vtm")}, S.grad[:S.n_trainable].clone()
+
+    try:
+        for train in (False, True):
+            l0, g0 = run(train, False)
+            l1, g1 = run(train, True)
+            assert l0 == l1, (train, l0, l1)                # the forward is untouched
+            assert torch.isfinite(g1).all()
+            for gi in range(4):
+                a, e = S.segments[gi]
+                if e > a:
+                    c = _cos(g0[a:e], g1[a:e])
+                    assert c >= 0.999999, (train, gi, c)
+            d = float((g0 - g1).abs().max() / (g0.abs().max() + 1e-30))
+            assert d <= 1e-3, (train, d)
+    finally:
+        eng.sw.dx1_window = True
 
 
 @pytest.mark.timeout(2400)
