@@ -153,7 +153,8 @@ def test_window_order_dx1_path_equals_gather_path():
         for train in (False, True):
             l0, g0 = run(train, False)
             l1, g1 = run(train, True)
-            assert l0 == l1, (train, l0, l1)                # the forward is untouched
+            for k in l0:                                    # the forward is untouched (loss sums use atomics: last-bit differences run to run)
+                assert abs(l0[k] - l1[k]) <= 1e-6 * abs(l0[k]) + 1e-7, (train, k, l0[k], l1[k])
             assert torch.isfinite(g1).all()
             for gi in range(4):
                 a, e = S.segments[gi]
