@@ -455,7 +455,7 @@ def check_ln_gather():
         e0, e1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
         dxw, _ = K.layernorm_bwd(dyq, xq, gq, mq_, rq_, e0, e1, dX_add=addq, dx_map=invq)
         rep(f"ln bwd dx_map C={Cq}: rows = gather of the ordinary dX", dxw, K.gather_rows(dxn, srcq, B * Lw, Lw, Lw), tol=0)
-        rep(f"ln bwd dx_map C={Cq}: dgamma", e0, d0, tol=1e-6)
+        rep(f"ln bwd dx_map C={Cq}: dgamma", e0, d0, tol=1e-5)            # (partial sums meet through atomics: order-dependent last bits)
         # gathered LayerNorm (norm1): residual gradient by output row
         yg, mg_, rg_ = K.layernorm_fwd(xq, gq, bq, 1e-5, M=B * Lw, C_=Cq, nseg=1, src=srcq, rows_out_per_batch=Lw, rows_in_per_batch=Lw, pad_mode=0)
         f0, f1 = torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
