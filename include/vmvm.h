@@ -104,6 +104,9 @@ typedef struct {
    * its kept clips only has ONE DropPath scale for all its rows -- video_swin.py:46-54: 1 / keep_prob -- so its bias gradient, the
    * scale-weighted column sum of dY, stays on the weight-gradient GEMM instead of a vmvm_colsum_bf16 pass with per-clip weights.) */
   float colsum_scale;
+  /* row_scale is indexed by (m + scale_row0) / rows_per_scale: a launch over the rows [scale_row0, scale_row0 + M) of a larger problem
+   * (the library's own split of a GEMM into whole ping-pong rounds + a remainder launch uses it; 0 for a whole problem) */
+  int32_t scale_row0;
 } vmvm_gemm_desc;
 int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream);
 /* bytes of `workspace` the split-K slabs of this descriptor take (0: the problem does not split; <0: VMVM_E*).  The library never

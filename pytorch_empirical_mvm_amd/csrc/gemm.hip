@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
       if (mapped < 0) continue;
       dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
     }
-    const float rs = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    const float rs = p.row_scale ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 1.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + g * 4;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const vmvm_gemm_desc p
       valid = mapped >= 0;
       dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
     }
-    const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    const float rs = (valid && p.row_scale) ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 1.0f;
 #pragma clang loop unroll(full)
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + g * 4;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const vmvm_gemm_desc p)
       valid = mapped >= 0;
       dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
     }
-    const float rs = (valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+    const float rs = (valid && p.row_scale) ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 1.0f;
 #pragma clang loop unroll(full)
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + g * 4;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
         dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
       }
       rvalid[i] = valid; rdst[i] = dst;
-      rrs[i] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      rrs[i] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 1.0f;
     }
     uint4 auxv[4][2], resv[4][2];
 #pragma clang loop unroll(full)
@@ -1417,7 +1417,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     // remainder fits ONE round of quarter tiles: whole ping-pong rounds + one 128x128 round beat 2.9 rounds of the 128x128 kernel)
     const long rem_q_all = tiles > cus_ ? (long)((dd.M - (int)(((tiles / cus_) * cus_) / ((dd.N + 255) / 256)) * 256 + 127) / 128) * ((dd.N + 127) / 128) : (1L << 40);
     const bool split_fits = dd.K >= 1024 && dd.N >= 512 && rem_q_all <= 2 * cus_;
-    if ((pays || split_fits) && split_ok && dd.variant == 0 && (dd.K >= 2048 || split_fits) && !dd.row_scale && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {
+    if ((pays || split_fits) && split_ok && dd.variant == 0 && (dd.K >= 2048 || split_fits) && !dd.aux && !dd.C2 && tiles > cus_ && !(dd.N & 7)) {      // (round 5: row_scale moves with the rows through scale_row0)
       const int nbn_ = (dd.N + 255) / 256, nbm_ = (dd.M + 255) / 256;
       const int tm_split = (int)(((tiles / cus_) * cus_) / nbn_);
       const long rem_tiles = (long)(nbm_ - tm_split) * nbn_;
@@ -1438,6 +1438,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
           d2.C = reinterpret_cast<char*>(dd.C) + (size_t)m_split * dd.ldc * 2;
           if (dd.resid) d2.resid = reinterpret_cast<const char*>(dd.resid) + (size_t)m_split * dd.ldr * 2;
           d2.offset = dd.offset + (uint64_t)m_split * (uint64_t)dd.N / 8;
+          d2.scale_row0 = dd.scale_row0 + m_split;
           d2.variant = 6;
           return vmvm_gemm_bf16(&d2, stream);
         }

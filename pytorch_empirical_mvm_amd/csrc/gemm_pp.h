@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
         float bs = 1.0f;
         if ((F & EF_BIAS) && (F & EF_RS) && p.row_scale && p.scale_bias_only) {
           const int m = m0 + wr * 128 + mb * 32 + l31;
-          bs = m < M ? p.row_scale[m / p.rows_per_scale] : 0.f;
+          bs = m < M ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 0.f;
         }
 #pragma clang loop unroll(full)
         for (int q = 0; q < 4; ++q)
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
         dst = (long)mapped + (long)(m / p.map_len) * p.map_stride;
       }
       rvalid[mb] = valid; rdst[mb] = dst;
-      rrs[mb] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[m / p.rows_per_scale] : 1.0f;
+      rrs[mb] = ((F & EF_RS) && valid && p.row_scale) ? p.row_scale[(m + p.scale_row0) / p.rows_per_scale] : 1.0f;
     }
     const float bz0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // (the bias is already in the accumulators)
     // 16-bit outputs leave through a per-wave 4 KiB LDS tile: the MFMA layout gives a lane ONE row (a store instruction would

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
                 ("variant", c_int), ("splitk", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
                 ("in_fp16", c_int), ("conv_taps", c_int), ("conv_h", c_int), ("conv_w", c_int), ("colsum", c_void_p),
-                ("in_fp8", c_int), ("alpha", c_float), ("a_relu", c_int), ("aux_code8", c_int), ("reserve_cus", c_int), ("colsum_scale", c_float)]
+                ("in_fp8", c_int), ("alpha", c_float), ("a_relu", c_int), ("aux_code8", c_int), ("reserve_cus", c_int), ("colsum_scale", c_float), ("scale_row0", c_int)]
 
 
 class LnFwdDesc(C.Structure):

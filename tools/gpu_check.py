@@ -353,6 +353,21 @@ def check_gemm_round_split():
     keep = ((one[idx].float() - r[idx].float()).abs() > 1e-6).float()
     rep("gemm round split rows around the split vs fp32", two[idx], ref * keep / 0.9 + r[idx].float())
     rep("gemm round split plain", K.gemm(A, B), K.gemm(A, B, variant=7).float())
+    # round 5: per-clip row scales move with the rows (vmvm_gemm_desc.scale_row0): the Swin stage-3 fc2 shape, 30 clips of 1 568 rows
+    # (the split point, 32 768 rows, falls inside clip 20), DropPath 'producer' form (the scale multiplies the bias only) and the plain form
+    Bc, Lc = 30, 1568
+    M2, N2, K2 = Bc * Lc, 512, 2048
+    A2, B2 = rnd(M2, K2), rnd(N2, K2, scale=0.05)
+    bias2, r2 = torch.randn(N2, device=dev), rnd(M2, N2)
+    rs2 = torch.rand(Bc, device=dev) + 0.5
+    for sbo in (True, False):
+        kw2 = dict(bias=bias2, resid=r2, row_scale=rs2, rows_per_scale=Lc, scale_bias_only=sbo)
+        got = K.gemm(A2, B2, **kw2)
+        acc = A2.float() @ B2.float().t()
+        rsr = rs2.repeat_interleave(Lc)[:, None]
+        ref2 = (acc + bias2 * rsr if sbo else (acc + bias2) * rsr) + r2.float()
+        rep(f"gemm round split with per-clip row scales (scale_bias_only={sbo}) vs fp32", got, ref2)
+        rep(f"gemm round split with per-clip row scales (scale_bias_only={sbo}) vs the 128x128 kernel", got, K.gemm(A2, B2, variant=6, **kw2).float(), tol=1e-2)          # (two kernels: one bf16 ulp of the largest outputs)
 
 
 # ------------------------------------------------------------------ layernorm
