@@ -1,3 +1,7 @@
+// NOT COMPILED INTO libvmvm (round 5 experiment, kept for the record: profiles/r05_fusion_dq_keyblocked_experiment.txt).  The kernel below is
+// parity-green and 17 % faster than attn_bwd_dq_kernel alone, and changes nothing in the step (its scalar record loads are HBM misses
+// there).  To run it: copy to pytorch_empirical_mvm_amd/csrc/attention_fus4.hip, add it to build.py SOURCES and restore the
+// vmvm_f4::launch_dq dispatch in attention.hip (git show 718f769^:pytorch_empirical_mvm_amd/csrc/attention.hip | grep -n vmvm_f4).
 // attention_fus4.hip -- fusion-encoder self-attention backward (BertSelfAttention of the cross-modal encoder, VIOLET_Base.go_cross
 // model.py:183-189: L = 432 tokens, head_dim 64, additive key mask, attention-probability dropout) in the KEY-BLOCKED form of
 // attention_win4.hip: small per-wave state, three waves per SIMD, two query tiles per wave against one key tile at a
