@@ -185,9 +185,12 @@ typedef struct {
   /* optional (identity walk only: src == NULL), NULL = off: dX row m is written to row dx_map[m % dx_map_len] + (m / dx_map_len) *
    * dx_map_len instead of row m -- a per-batch PERMUTATION (every entry in [0, dx_map_len), each once; M a multiple of dx_map_len).
    * Video-Swin block backward: the norm2 backward writes d(x1) straight in the block's WINDOW order (dx_map = the inverse window map),
-   * which is where the projection's backward GEMMs and the norm1 backward (add_by_out) want it -- no gather pass, no natural-order copy. */
+   * which is where the projection's backward GEMMs and the norm1 backward (add_by_out) want it -- no gather pass, no natural-order copy.
+   * dx_map entries are NOT range-checked (the caller builds them from its own window map); dX must not alias dX_add (rows are written
+   * out of order: VMVM_EINVAL); dX2 stays at row m, so dx_map together with dX2 is refused (VMVM_ENOSUPPORT). */
   const int32_t* dx_map; int32_t dx_map_len;
-  /* with src (nseg == 1): dX_add is indexed by the OUTPUT row m (like dY) instead of the source row */
+  /* with src (nseg == 1): dX_add is indexed by the OUTPUT row m (like dY) instead of the source row.  Not with inv (the source-major
+   * walk indexes dX_add by source row: VMVM_ENOSUPPORT). */
   int32_t add_by_out;
 } vmvm_ln_bwd_desc;
 int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream);

@@ -36,6 +36,10 @@ class Agent_Pretrain:
             self.comm = D.GradReducer(self.engine.store, self.engine.device)
             if getattr(self.engine, "wstream", None) is not None:
                 self.comm.wait_streams.append(self.engine.wstream)      # weight gradients are produced on the engine's second stream
+            # the autograd-driven step (model(batch) ... loss.backward(), model._OpenStep) starts the same two exchange phases from inside
+            # its backward node: the non-Swin groups behind the fusion backward, the Swin tail behind stage n-2
+            self.model._grad_hook = self.comm.reduce_other
+            self.engine.on_swin_tail_ready = self.comm.reduce_swin_tail
             D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
             self.engine.store.refresh_shadow()
             # DDP also broadcasts the frozen teachers' parameters (they are sub-modules of the wrapped model): without this, ranks
@@ -271,8 +275,17 @@ class Agent_Pretrain:
         self.model.train()
         return out
 
-    def backward_step(self):
-        """all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:186-193)"""
+    def forward_step(self, batch):
+        """agent.py:161-179 : `out = self.model(batch)` -- with grad mode on the outputs carry a grad_fn (model._OpenStep), so the
+        reference's own `step` body (losses in plain torch, `backward_step(ls)`) drives this model."""
+        return self.model(batch)
+
+    def backward_step(self, loss=None):
+        """[loss.backward() ->] all-reduce (rest) -> global grad norm -> clip -> AdamW -> scheduler.step -> zero_grad   (agent.py:181-193).
+        `loss` = the reference's call form `backward_step(ls)`: the scalar of a step that went through `forward_step` / `model(batch)`;
+        None = the gradients are already in the arena (the fused `step()` below)."""
+        if loss is not None:
+            loss.backward()
         S = self.engine.store
         S.sync_pending()                                 # (a second backward_step without a forward in between: the previous tail first)
         if self.comm is not None:

@@ -21,6 +21,7 @@
 // Attention-prob dropout: Philox4x32-7 per 4x4 (query,key) block, 16 random bytes; an element compares a 16-bit field
 // (p quantised to 1/65536, attn_common.h drop_field), the same block is addressed row-wise by fwd/A and column-wise by B.
 #include "attn_common.h"
+#include <vmvm_probe_hooks.h>
 #include <cstdlib>
 
 namespace {
@@ -2373,9 +2374,7 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#ifndef W4_TIMELINE                                    // (probe builds pass their stamp buffer as drop_mask, tools/scratch/w4_timeline.py)
-  if (d->drop_mask && !drop_mask_ok(d)) return VMVM_ENOSUPPORT;
-#endif
+  if (!vmvm_hook::W4_TIMELINE_BUILD && d->drop_mask && !drop_mask_ok(d)) return VMVM_ENOSUPPORT;      // (timeline probe builds pass their stamp buffer as drop_mask, tools/scratch/w4_timeline.py)
   if (use_stream(d)) {                               // streaming kernels: K / V chunks of 128 tokens, 8 query tiles per workgroup
     constexpr int NWS = 8, KCS = 128;
     const SmemS ss = smem_stream(d->L, d->head_dim, d->mode, d->table_len, 0, KCS);
@@ -2471,9 +2470,7 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   int rc = check_desc(&d->f);
   if (rc) return rc;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
-#ifndef W4_TIMELINE
-  if (d->f.drop_mask && !drop_mask_ok(&d->f)) return VMVM_ENOSUPPORT;
-#endif
+  if (!vmvm_hook::W4_TIMELINE_BUILD && d->f.drop_mask && !drop_mask_ok(&d->f)) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (use_stream(&d->f)) {                           // streaming kernels (see vmvm_attention_fwd)
     constexpr int NWS = 8, KCS = 128;

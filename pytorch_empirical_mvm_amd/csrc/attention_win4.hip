@@ -25,13 +25,9 @@
 
 namespace {
 
-// Probe builds (-DW4_TIMELINE, tools/scratch/w4_timeline.py): s_memtime stamps of every wave of workgroup 0 for sequences 2..5 into
-// the buffer passed as vmvm_attn_fwd_desc.drop_mask ([4 sequences][13 waves][32 stamps] u64).  Production builds: nothing.
-#ifdef W4_TIMELINE
-#define W4_STAMP(idx) do { if (p.drop_mask && blockIdx.x == 0 && b >= 2 && b < 6 && lane == 0) reinterpret_cast<unsigned long long*>(p.drop_mask)[((b - 2) * 13 + wave) * 32 + (idx)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define W4_STAMP(idx) do { } while (0)
-#endif
+// Per-wave timeline stamps (tools/scratch/w4_timeline.py) and the "no odd tile" ablation are HOOKS (vmvm_probe_hooks.h): no-ops /
+// constants in the library build, instrumented in tools/probe/hooks (switches -DW4_TIMELINE, -DW4_NO_ODD live there, not here).
+#define W4_STAMP(idx) vmvm_hook::w4_stamp(p.drop_mask, (int)blockIdx.x, b, lane, wave, (idx))
 
 template <int V> struct IC4 { static constexpr int value = V; };
 
@@ -105,12 +101,8 @@ __global__ __launch_bounds__(832) void attn_fwd_win4_kernel(const vmvm_attn_fwd_
     __syncthreads();
   }
   // this wave's query tiles (wave 12: tile 24 only)
-  #ifdef W4_NO_ODD
-  const bool odd = false;
-#else
-  const bool odd = wave == NWV - 1;
-#endif
-  const int qt[2] = {2 * wave, odd ? 2 * wave : (2 * wave + 1 < w3::NT ? 2 * wave + 1 : w3::NT - 1)};     // (W4_NO_ODD builds: wave 12's second tile repeats tile 24, not stored)
+  const bool odd = !vmvm_hook::W4_SKIP_ODD && wave == NWV - 1;
+  const int qt[2] = {2 * wave, odd ? 2 * wave : (2 * wave + 1 < w3::NT ? 2 * wave + 1 : w3::NT - 1)};     // (vmvm_hook::W4_SKIP_ODD probe builds: wave 12's second tile repeats tile 24, not stored)
   const int qc = w3::cls_of(qt[0]);                       // both tiles lie in one class (classes start on even tiles)
 
   // this workgroup's sequences: the clips [c0, c1) of its window positions, window-major

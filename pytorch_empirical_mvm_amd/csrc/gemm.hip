@@ -1239,6 +1239,13 @@ int launch_pers(const vmvm_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
+// Tile counts, grids and split-K plans below are 32-bit: a problem with more than 2^24 output tiles of 128 x 128 (M * N > 2.7e11) is
+// refused up front (found by the host-side sanitizer sweep, tools/cabi_validation.py: 2^30 x 2^30 overflowed the tile count to 0 and
+// the split plan divided by it).
+static bool gemm_tiles_ok(int M, int N) {
+  return (int64_t)((M + BM - 1) / BM) * (int64_t)((N + BN - 1) / BN) <= (int64_t)1 << 24;
+}
+
 extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VMVM_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
@@ -1298,6 +1305,8 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     if (!ar && !dt.out_fp32 && dt.act == 0) return launch_pers_teacher<false, EF_TEACHER_RES, 1, false>(dt, st_);
     return ar ? launch_pers_teacher<false, EF_TEACHER, 1, true>(dt, st_) : launch_pers_teacher<false, EF_TEACHER, 1, false>(dt, st_);
   }
+  if (!gemm_tiles_ok(d->M, d->N)) return VMVM_ENOSUPPORT;
+  if (d->act < 0 || d->act > 4) return VMVM_EINVAL;             // (act = 5, the fused arg-max, exists in the fp16 teacher builds above only)
   // 16-byte chunks may straddle the logical extent as long as the row stride covers the round-up
   const int K8 = (d->K + 7) & ~7, M8 = (d->M + 7) & ~7, N8 = (d->N + 7) & ~7;
   if (d->a_kmajor ? (d->lda < K8) : (d->lda < M8)) return VMVM_EINVAL;
@@ -1482,6 +1491,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
 // takes one).  Mirrors the plan of vmvm_gemm_bf16 for variant 0 / splitk 0|>1; 0 = this problem never splits.
 extern "C" int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return VMVM_EINVAL;
+  if (!gemm_tiles_ok(d->M, d->N)) return VMVM_ENOSUPPORT;
   const bool plain_acc = d->out_fp32 && d->accumulate && !d->bias && !d->row_scale && !d->act && !d->resid && !d->row_map &&
                          d->dropout_p <= 0.f && d->col_scale_n == 0;
   if (!plain_acc || d->in_fp8 || d->in_fp16 || d->conv_taps || d->splitk == 1) return 0;

@@ -30,4 +30,9 @@ struct W3Timeline {
   __device__ __forceinline__ void flush(int) {}
 };
 
+// per-wave, per-key-block timeline of the win4 window-attention kernels (attention_win4.hip) + its "no odd tile" ablation
+constexpr bool W4_TIMELINE_BUILD = false;     // (probe builds hand their stamp buffer in as vmvm_attn_fwd_desc.drop_mask: vmvm_attention_fwd/_bwd skip the drop_mask_ok check)
+constexpr bool W4_SKIP_ODD = false;             // wave 12 of the forward treated like the others (its second tile repeats tile 24)
+__device__ __forceinline__ void w4_stamp(void*, int, int, int, int, int) {}
+
 }  // namespace vmvm_hook

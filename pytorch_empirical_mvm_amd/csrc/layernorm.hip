@@ -500,6 +500,11 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   if (d->inv && (!d->src || d->nseg != 1 || d->C > 256 || d->rows_in_total <= 0 || d->dX2 || d->pad_mode != 0)) return VMVM_ENOSUPPORT;     // source-major order: the packed kernels, one segment, pad slots constant zero (the walk never visits rows without a source, and with pad_mode != 0 those rows contribute dY to dgamma / dbeta)
   if (d->dx_map && (d->src || d->inv || d->dx_map_len <= 0 || (d->M % d->dx_map_len))) return VMVM_EINVAL;      // scattered dX: the identity walk, whole batches
   if (d->add_by_out && (!d->src || d->nseg != 1 || !d->dX_add)) return VMVM_EINVAL;
+  //  combinations nothing defines: dX goes to dx_map[m] but dX2 would stay at row m; the source-major walk indexes its
+  // residual gradient by SOURCE row, add_by_out by output row.  dX must not alias dX_add under dx_map (rows are written out of order).
+  if (d->dx_map && d->dX2) return VMVM_ENOSUPPORT;
+  if (d->add_by_out && d->inv) return VMVM_ENOSUPPORT;
+  if (d->dx_map && d->dX_add == d->dX) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one resident set of workgroups (256 CUs x workgroups that fit per CU at this variant's VGPR count); each loops over rows
   // Workgroups that fit per CU at the variant's VGPR count.  Allocation granule 8: the packed C <= 128 build takes 100 -> 104

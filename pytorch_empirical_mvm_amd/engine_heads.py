@@ -62,16 +62,15 @@ class HeadsMixin:
         return self._linear_bwd(du_, hd["r"], pm + "transform.dense.weight", pm + "transform.dense.bias",
                                 dx_kw=None if dx_out is None else dict(out=dx_out))
 
-    # -------------------------------------------------------------- full step
-    def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
-                         dropout=None, on_other_grads_ready=None):
-        """One pass of the hot path.  batch: img f32 (B,T,3,H,W) UN-masked, cov u8 (B,T,h,w), txt i64 (B,X) (masked ids),
-        mask i64 (B,X), ans_mtm i64 (B,X).  Returns dict of loss scalars (device f32 tensors) and optional outputs."""
+    # -------------------------------------------------------------- the trunk both step forms share
+    def _forward_trunk(self, batch, negatives, train, dp_all, dropout, backward):
+        """encoders -> token pool -> sequence assembly -> ONE fusion pass over the B pass-1 and B*O VTM sequences (+ the smtm pass):
+        everything of VIOLET_Pretrain.forward (main_pretrain.py:226-262) in front of the heads.  Returns the record the heads and
+        `_backward_trunk` read."""
         cfg, S, dev = self.cfg, self.store, self.device
-        img, cov, txt, mask, ans_mtm = batch["img"], batch["cov"], batch["txt"], batch["mask"], batch["ans_mtm"]
+        img, cov, txt, mask = batch["img"], batch["cov"], batch["txt"], batch["mask"]
         B, T, _, H, W = img.shape
         X = txt.shape[1]
-        Hd = cfg["hidden"]
         O = min(B, 4)
         self.tape = []
         if train and dp_all is None:
@@ -100,12 +99,14 @@ class HeadsMixin:
         pair_i = np.repeat(np.arange(B), O)
         pair_j = np.concatenate([np.arange(B)[:, None], neg], axis=1).reshape(-1)
         idx2 = seq_rows(pair_i, pair_j)
-        idx1_d = _dev_i32(idx1, dev) if "smtm" in cfg.get("pretrain_tasks", ()) else None
+        use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
+        idx1_d = _dev_i32(idx1, dev) if use_smtm else None
         km_txt = (mask != 0).to(torch.uint8)
         km1 = torch.cat([torch.ones(B, Lv, dtype=torch.uint8, device=dev), km_txt], 1).contiguous()
         tj_h = pair_j
         tj = _h2d(torch.from_numpy(tj_h), dev)
         km2 = torch.cat([torch.ones(B * O, Lv, dtype=torch.uint8, device=dev), km_txt[tj]], 1).contiguous()
+        txt_off_d = txt_list_d = None
         if backward:                            # CSR of the pass-2 sequences by their text index (the pool gradient gathers through it)
             order = np.argsort(tj_h, kind="stable")
             csr = np.concatenate([np.concatenate([[0], np.cumsum(np.bincount(tj_h, minlength=B))]), order]).astype(np.int32)
@@ -122,6 +123,7 @@ class HeadsMixin:
         # `_bert_layer_qrow` on n2 rows instead of n2 * Lq (`go_cross(qrow_split=...)`); results are those of the full layer.
         ntape = len(self.tape)
         qrow = self.sw.qrow                             # (0: the whole last layer for every sequence, for A/B runs)
+        out12 = cls_rows = None
         if qrow:
             (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), qrow_split=(n1, Lv))
             if backward:
@@ -134,16 +136,48 @@ class HeadsMixin:
                 out12.g = torch.empty_like(out12.t)
                 out1.g = out12.g[:n1 * Lq]
         n_fusion_closures = len(self.tape) - ntape
-        use_smtm = "smtm" in cfg.get("pretrain_tasks", ())
+        out3 = in3 = None
         if use_smtm:                            # third pass under the seq2seq mask (main_pretrain.py:238-240)
             out3, in3, _ = self.go_cross(pool, idx1_d, km1, B, Lq, self._drop_on("fusion", train), causal_from=Lv)
+        txt_rows = self._cached(("txt_rows", B, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(B)]), dev))
+        return dict(B=B, T=T, H=H, W=W, X=X, O=O, Lv=Lv, Lq=Lq, hw=hw, n1=n1, n2=n2, train=train, feat_target=feat_target, pool=pool, in12=in12,
+                    out1=out1, out2c=out2c, out12=out12, cls_rows=cls_rows, out3=out3, in3=in3, use_smtm=use_smtm, qrow=qrow,
+                    n_fusion_closures=n_fusion_closures, txt_off_d=txt_off_d, txt_list_d=txt_list_d, txt_rows=txt_rows, ar_t=ar_t)
+
+    def _backward_trunk(self, tr, on_other_grads_ready=None):
+        """the tape behind the heads: fusion layers (, smtm pass) -> token-pool gradient -> encode -> Video-Swin; `tr` = `_forward_trunk`'s
+        record with out1.g / out2c.g (/ out12.g, out3.g) filled by the heads"""
+        B, O, Lv, X, Lq, n1 = tr["B"], tr["O"], tr["Lv"], tr["X"], tr["Lq"], tr["n1"]
+        n_layers = self.cfg["bert_layers"]
+        for _ in range((n_layers if tr["use_smtm"] else 0) + tr["n_fusion_closures"]):
+            self.tape.pop()()
+        g12 = tr["in12"].g
+        tr["pool"].g = K.pool_grad(g12[:n1 * Lq], g12[n1 * Lq:], tr["in3"].g if tr["use_smtm"] else None, B, O, Lv, X, tr["txt_off_d"], tr["txt_list_d"])
+        self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
+        if on_other_grads_ready is not None:
+            on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward
+        while self.tape:
+            self.tape.pop()()
+        self._wgrad_join()
+
+    # -------------------------------------------------------------- full step
+    def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
+                         dropout=None, on_other_grads_ready=None):
+        """One pass of the hot path.  batch: img f32 (B,T,3,H,W) UN-masked, cov u8 (B,T,h,w), txt i64 (B,X) (masked ids),
+        mask i64 (B,X), ans_mtm i64 (B,X).  Returns dict of loss scalars (device f32 tensors) and optional outputs."""
+        cfg, S, dev = self.cfg, self.store, self.device
+        img, cov, txt, mask, ans_mtm = batch["img"], batch["cov"], batch["txt"], batch["mask"], batch["ans_mtm"]
+        Hd = cfg["hidden"]
+        tr = self._forward_trunk(batch, negatives, train, dp_all, dropout, backward)
+        B, T, H, W, X, O, Lv, Lq, hw, n1, n2 = (tr[k] for k in ("B", "T", "H", "W", "X", "O", "Lv", "Lq", "hw", "n1", "n2"))
+        train, feat_target, pool, in12, out1, out2c, out12, cls_rows = (tr[k] for k in ("train", "feat_target", "pool", "in12", "out1", "out2c", "out12", "cls_rows"))
+        out3, in3, use_smtm, qrow, txt_rows = (tr[k] for k in ("out3", "in3", "use_smtm", "qrow", "txt_rows"))
         lz = torch.zeros(8, device=dev, dtype=F32)                                          # one fill: the kernels accumulate into their slot
         losses = {k: lz[i:i + 1] for i, k in enumerate(("mtm", "vtm", "mvm", "mvm_pixel", "mvm_vq", "mvm_feature", "mvm_hog", "smtm"))}
         outs = {}
 
         # ---- MLM head (HF BertOnlyMLMHead; main_pretrain.py:236,560) -- also the head of the smtm pass (:240,:567)
         Vv = cfg["vocab"]
-        txt_rows = self._cached(("txt_rows", B, Lv, X), lambda: _dev_i32(np.concatenate([i * Lq + Lv + ar_t for i in range(B)]), dev))
         tgt_m = ans_mtm.reshape(-1).contiguous()
 
         def mlm_head(outv, loss):
@@ -308,15 +342,85 @@ class HeadsMixin:
             K.gather_rows(dr_v, inv2, B * O * Lq, out=out12.g[n1 * Lq:])
 
         # encoders (tape holds: encode, the merged pass' layers (, the smtm pass' layers)) -> run them back, then gather into the pool
-        n_layers = cfg["bert_layers"]
-        for _ in range((n_layers if use_smtm else 0) + n_fusion_closures):
-            self.tape.pop()()
-        g12 = in12.g
-        pool.g = K.pool_grad(g12[:n1 * Lq], g12[n1 * Lq:], in3.g if use_smtm else None, B, O, Lv, X, txt_off_d, txt_list_d)
-        self.tape.pop()()                       # encode backward: text embeddings + EncVideo head -> last non-Swin gradients
-        if on_other_grads_ready is not None:
-            on_other_grads_ready()              # data-parallel: all-reduce of the non-Swin groups overlaps the Swin backward
-        while self.tape:
-            self.tape.pop()()
-        self._wgrad_join()
+        self._backward_trunk(tr, on_other_grads_ready)
         return losses, outs
+
+    # -------------------------------------------------------------- the step OPEN at the reference's model outputs (autograd interop)
+    def forward_open(self, batch, negatives=None, train=True, dp_all=None, dropout=None):
+        """VIOLET_Pretrain.forward as the REFERENCE defines it (main_pretrain.py:226-267): the model ends at `out_mtm` (MLM logits
+        (B, X, V) f32), `out_mvm` (the fusion encoder's visual-token states (B, T*(1+hw), H) bf16) and `out_vtm` ((B, O) pair scores / temp,
+        f32); the losses -- and the MVM decoders, which the reference's agent applies itself (main_pretrain.py:420-432) -- are the
+        caller's.  The tape stays armed: `backward_open` takes the three output gradients.  model.VIOLET_Pretrain.forward wraps the pair
+        in a torch.autograd.Function."""
+        S, dev, Hd = self.store, self.device, self.cfg["hidden"]
+        tr = self._forward_trunk(batch, negatives, train, dp_all, dropout, True)
+        B, X, O, Lv, Lq = tr["B"], tr["X"], tr["O"], tr["Lv"], tr["Lq"]
+        out1, out2c = tr["out1"], tr["out2c"]
+        Vv, Vpad, Nlog = self._mlm_dims()
+
+        def head_open(outv):                    # HF BertOnlyMLMHead without the loss
+            pm = "fc_mtm.predictions."
+            rows = K.gather_rows(outv.t, tr["txt_rows"], B * X)
+            u_ = torch.empty((B * X, Hd), device=dev, dtype=BF16)
+            t_ = K.gemm(rows, S.b(pm + "transform.dense.weight"), bias=S.p(pm + "transform.dense.bias"), act=1, out_preact=u_)
+            tn_, mean_, rstd_ = K.layernorm_fwd(t_, S.p(pm + "transform.LayerNorm.weight"), S.p(pm + "transform.LayerNorm.bias"), CFG.BERT["eps"])
+            lg_ = torch.empty((B * X, Vpad), device=dev, dtype=F32)
+            K.gemm(tn_, S.b(pm + "decoder.weight"), N=Nlog, bias=S.p(pm + "bias"), out=lg_)
+            return dict(r=rows, u=u_, t=t_, tn=tn_, mean=mean_, rstd=rstd_, logits=lg_, dlog=None, n=B * X)
+        tr["h_mlm"] = head_open(out1)
+        tr["h_smtm"] = head_open(tr["out3"]) if tr["use_smtm"] else None
+        # VTM head (main_pretrain.py:146-147,260-262)
+        r_v = out2c.t
+        p_fc = 0.1 if self._drop_on("vtm", tr["train"]) else 0.0
+        off_fc = self._next_offset(r_v.numel())
+        self.last_offsets["vtm"] = off_fc
+        r_vd = K.dropout(r_v, p_fc, self.seed, off_fc) if p_fc > 0 else r_v
+        h_v = K.gemm(r_vd, S.b("fc.1.weight"), bias=S.p("fc.1.bias"), act=2)
+        inv_temp = 1.0 / self.cfg["temp"]
+        lg_v = K.rowdot(h_v, S.p("fc.3.weight", (2 * Hd,)), S.p("fc.3.bias"), inv_temp)
+        tr.update(r_vd=r_vd, h_v=h_v, p_fc=p_fc, off_fc=off_fc, inv_temp=inv_temp)
+        outs = {"out_mtm": tr["h_mlm"]["logits"][:, :Vv].reshape(B, X, Vv), "out_mvm": out1.t.view(B, Lq, Hd)[:, :Lv], "out_vtm": lg_v.view(B, O),
+                "out_smtm": tr["h_smtm"]["logits"][:, :Vv].reshape(B, X, Vv) if tr["use_smtm"] else None}
+        return outs, tr
+
+    def backward_open(self, tr, d_mtm, d_mvm, d_vtm, d_smtm=None, on_other_grads_ready=None):
+        """the backward of `forward_open` from the gradients of its outputs (None = that output did not reach the loss).  Parameter
+        gradients are ACCUMULATED into the gradient arena -- the `.grad` views of model.parameters() -- like autograd's AccumulateGrad."""
+        S, dev, Hd = self.store, self.device, self.cfg["hidden"]
+        B, X, O, Lv, Lq, n1 = tr["B"], tr["X"], tr["O"], tr["Lv"], tr["Lq"], tr["n1"]
+        out1, out2c = tr["out1"], tr["out2c"]
+        Vv, Vpad, _ = self._mlm_dims()
+
+        def dlog_of(d):                          # (B, X, V) -> bf16 [B*X, Vpad] with zero pad columns (what vmvm_cross_entropy hands the head backward)
+            t = torch.zeros((B * X, Vpad), device=dev, dtype=BF16)
+            t[:, :Vv].copy_(d.reshape(B * X, Vv))
+            return t
+        g1 = out1.g.view(B, Lq, Hd)
+        if d_mvm is None:
+            g1[:, :Lv].zero_()
+        else:
+            g1[:, :Lv].copy_(d_mvm.reshape(B, Lv, Hd))
+        if d_mtm is None:
+            g1[:, Lv:].zero_()
+        else:
+            tr["h_mlm"]["dlog"] = dlog_of(d_mtm)
+            g1[:, Lv:].copy_(self._mlm_head_bwd(tr["h_mlm"]).view(B, X, Hd))
+        if tr["use_smtm"]:
+            g3 = torch.zeros((B, Lq, Hd), device=dev, dtype=BF16)
+            if d_smtm is not None:
+                tr["h_smtm"]["dlog"] = dlog_of(d_smtm)
+                g3[:, Lv:].copy_(self._mlm_head_bwd(tr["h_smtm"]).view(B, X, Hd))
+            tr["out3"].g = g3.view(B * Lq, Hd)
+        if d_vtm is None:
+            dr_v = torch.zeros_like(out2c.t)
+        else:
+            dlg_v = d_vtm.reshape(-1).to(F32).contiguous()
+            dh_v = K.rowdot_bwd(tr["h_v"], S.p("fc.3.weight", (2 * Hd,)), dlg_v, tr["inv_temp"], S.g("fc.3.weight", (2 * Hd,)), S.g("fc.3.bias"), relu_mask=True)
+            dr_v = self._linear_bwd(dh_v, tr["r_vd"], "fc.1.weight", "fc.1.bias")
+            if tr["p_fc"] > 0:
+                dr_v = K.dropout(dr_v, tr["p_fc"], self.seed, tr["off_fc"])
+        out2c.g = dr_v
+        if not tr["qrow"]:
+            inv2 = self._cached(("inv2", B * O, Lq, Lv), lambda: self._inverse_rows(B * O * Lq, [tr["cls_rows"]]))
+            K.gather_rows(dr_v, inv2, B * O * Lq, out=tr["out12"].g[n1 * Lq:])
+        self._backward_trunk(tr, on_other_grads_ready)

@@ -18,6 +18,51 @@ class _Node(torch.nn.Module):
     pass
 
 
+class _ConvShuffle(_Node):
+    """`Sequential(Conv2d(H, C, 1), PixelShuffle(r))` of the reference's MVM decoders (main_pretrain.py:178-183,200-203) as a CALLABLE over
+    the arena-view parameters `0.weight` / `0.bias`: the reference's agent applies `model.decoder_pixel(...)` itself inside
+    `calc_mvm_loss` (:420-432), so a model swapped in alone must offer it.  Plain torch ops (the caller's loss code, under the caller's
+    autocast): their parameter gradients reach the arena through the `.grad` views like any AccumulateGrad."""
+    upscale = 1
+
+    def forward(self, x):
+        conv = getattr(self, "0")
+        return torch.nn.functional.pixel_shuffle(torch.nn.functional.conv2d(x, conv.weight.to(x.dtype), conv.bias.to(x.dtype)), self.upscale)
+
+
+class _MLPHead(_Node):
+    """`Sequential(Dropout(0.1), Linear, ReLU, Linear)` (the reference's `fc_mvm`, main_pretrain.py:161-162,204-205) as a callable, same contract"""
+    def forward(self, x):
+        F_ = torch.nn.functional
+        l1, l3 = getattr(self, "1"), getattr(self, "3")
+        h = F_.relu(F_.linear(F_.dropout(x, 0.1, self.training), l1.weight.to(x.dtype), l1.bias.to(x.dtype)))
+        return F_.linear(h, l3.weight.to(x.dtype), l3.bias.to(x.dtype))
+
+
+class _OpenStep(torch.autograd.Function):
+    """The engine's step, open at the reference's model outputs, as ONE autograd node (VERDICT r5 missing #2): forward = `forward_open`
+    (hand-written kernels, tape armed), backward = `backward_open` seeded with the incoming output gradients; parameter gradients are
+    accumulated into the gradient arena, which IS `p.grad` of every `model.parameters()` entry.  `anchor` is a grad-requiring scalar
+    that ties the node into the graph (the parameters are not inputs: 400 views of one buffer would only add AccumulateGrad nodes)."""
+    @staticmethod
+    def forward(ctx, anchor, model, batch, negatives, dp_all):
+        eng = model.engine
+        outs, tr = eng.forward_open(batch, negatives=negatives, train=model.training, dp_all=dp_all)
+        ctx.model, ctx.tr = model, tr
+        ctx.set_materialize_grads(False)                     # an output the loss does not read arrives as None, not as 125 MB of zeros
+        smtm = outs["out_smtm"] if outs["out_smtm"] is not None else anchor.new_zeros(())
+        return outs["out_mtm"], outs["out_mvm"], outs["out_vtm"], smtm
+
+    @staticmethod
+    def backward(ctx, d_mtm, d_mvm, d_vtm, d_smtm):
+        model, tr = ctx.model, ctx.tr
+        ctx.tr = None
+        if tr is None:
+            raise RuntimeError("VIOLET_Pretrain: backward through one forward twice (the activation tape is consumed by the first)")
+        model.engine.backward_open(tr, d_mtm, d_mvm, d_vtm, d_smtm if tr["use_smtm"] else None, on_other_grads_ready=getattr(model, "_grad_hook", None))
+        return None, None, None, None, None
+
+
 def _trunc_normal_(t, std, gen):
     # video_swin.py:17-43 (a=-2, b=2 in absolute units, as the reference passes them)
     l = (1.0 + math.erf((-2.0) / std / math.sqrt(2.0))) / 2.0
@@ -65,6 +110,15 @@ class VIOLET_Pretrain(torch.nn.Module):
             prm = torch.nn.Parameter(store.p(name), requires_grad=name not in store.FROZEN or True)
             prm.grad = store.g(name)
             node.register_parameter(parts[-1], prm)
+        # the heads the reference's AGENT calls itself (calc_mvm_loss): callable over the same arena-view parameters
+        for hname, ups in (("decoder_pixel", args.size_patch), ("decoder_hog", args.size_patch), ("decoder_vq", max(1, args.size_patch // 8))):
+            if hasattr(self, hname):
+                getattr(self, hname).__class__ = _ConvShuffle
+                getattr(self, hname).upscale = int(ups)
+        if hasattr(self, "fc_mvm"):
+            self.fc_mvm.__class__ = _MLPHead
+        self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)     # (plain attribute: not a parameter, not in state_dict)
+        self._grad_hook = None              # data parallel: dist.GradReducer.reduce_other, set by Agent_Pretrain.prepare_dist_model
         # relative_position_index buffers (video_swin.py:123-137) for checkpoint key parity
         win = tuple(self.cfg["window"])
         from .swin_index import rc_codes
@@ -216,10 +270,68 @@ class VIOLET_Pretrain(torch.nn.Module):
                 toload[k] = cur
         self.load_state_dict(toload, strict=False)
 
-    # ------------------------------------------------------------------ forward (inference surface)
-    @torch.no_grad()
-    def forward(self, batch, negatives=None):
-        """main_pretrain.py:226-267 : returns the reference's output dict (eval semantics, no dropout)."""
+    # ------------------------------------------------------------------ forward
+    def _sync_param_surface(self):
+        """Keep the nn.Parameter surface and the arena consistent when somebody ELSE drives the optimizer (the reference's Agent_Base:
+        torch AdamW + GradScaler + `optzr.zero_grad()`, agent.py:181-193):
+        * `zero_grad(set_to_none=True)` (torch's default) detaches `p.grad` from the gradient arena -> the arena is zeroed (None means
+          zero) and every `.grad` view re-attached;
+        * an in-place parameter update through torch bumps the arena's version counter (views share it; the library's own AdamW writes
+          through raw pointers and does not) -> the bf16 compute copy and the W^T copies are refreshed."""
+        S = self.engine.store
+        lost = False
+        for name, prm in self._arena_params():
+            g = prm.grad
+            if g is None or g.data_ptr() != S.g(name).data_ptr():
+                lost = True
+                break
+        if lost:
+            S.sync_pending()
+            S.grad.zero_()
+            for name, prm in self._arena_params():
+                prm.grad = S.g(name)
+        if S.flat._version != getattr(S, "_shadow_version", None):
+            S.refresh_shadow()
+
+    def _arena_params(self):
+        lst = getattr(self, "_arena_param_list", None)
+        if lst is None:
+            idx = self.engine.store.index
+            lst = self._arena_param_list = [(n, p_) for n, p_ in self.named_parameters() if n in idx]
+        return lst
+
+    def forward(self, batch, negatives=None, dp_all=None):
+        """main_pretrain.py:226-267 : returns the reference's output dict.
+        * grad mode ON (the reference's training call, agent.py:161-179: `out = model(batch)`; losses in plain torch; `loss.backward()`):
+          `out_mtm` / `out_mvm` / `out_vtm` (/ `out_smtm`) carry a grad_fn -- one autograd node around the engine (`_OpenStep`); dropout
+          and DropPath follow `self.training`; `batch["img"]` is the MASKED clip as `masking()` returns it (or `unmask_img` + `cov`).
+        * under `torch.no_grad()`: the inference surface of earlier rounds (eval semantics, no dropout), plus the in-engine losses."""
+        if torch.is_grad_enabled():
+            return self._forward_autograd(batch, negatives, dp_all)
+        with torch.no_grad():
+            return self._forward_inference(batch, negatives)
+
+    def _forward_autograd(self, batch, negatives, dp_all):
+        dev = self.engine.device
+        self._sync_param_surface()
+        src = batch["unmask_img"] if ("unmask_img" in batch and batch.get("cov") is not None) else batch["img"]
+        img, txt, mask = src.to(dev, torch.float32).contiguous(), batch["txt"].to(dev).contiguous(), batch["mask"].to(dev).contiguous()
+        B, T, _, H, W = img.shape
+        ps = self.patch_size
+        cov = batch.get("cov")
+        cov = torch.zeros(B, T, H // ps, W // ps, dtype=torch.uint8, device=dev) if cov is None else cov.to(dev).contiguous()
+        b = dict(img=img, cov=cov, txt=txt, mask=mask)
+        if negatives is None:                  # main_pretrain.py:250 draws them with np.random inside forward(): same source, same order
+            negatives = self.engine.sample_negatives(B)
+        out_mtm, out_mvm, out_vtm, out_smtm = _OpenStep.apply(self._anchor, self, b, negatives, dp_all)
+        use_smtm = "smtm" in self.cfg.get("pretrain_tasks", ())
+        ans_mtm = batch.get("ans_mtm")
+        ans_mtm = None if ans_mtm is None else ans_mtm.to(dev)
+        return {"out_vtm": out_vtm, "out_mvm": out_mvm, "out_mtm": out_mtm, "out_smtm": out_smtm if use_smtm else None,
+                "ans_vtm": torch.zeros(B, dtype=torch.long, device=dev), "ans_mtm": ans_mtm, "ans_mvm": batch.get("ans_mvm"),
+                "ans_smtm": ans_mtm if use_smtm else None}
+
+    def _forward_inference(self, batch, negatives=None):
         dev = self.engine.device
         img, txt, mask = batch["img"].to(dev, torch.float32), batch["txt"].to(dev), batch["mask"].to(dev)
         B, T, _, H, W = img.shape

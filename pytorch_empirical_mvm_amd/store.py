@@ -118,6 +118,7 @@ class ParamStore:
         self.sync_pending()
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
         self.refresh_transposed()
+        self._shadow_version = self.flat._version        # (model._sync_param_surface: a torch-side in-place update of a parameter view bumps it)
 
     # ---- W^T copies (bf16) of every Linear weight: dgrad dX = dY W then runs as a k-major x k-major GEMM
     def build_transpose_table(self):

@@ -226,3 +226,59 @@ def test_bf16_wire_error_at_eight_ranks_gloo():
         p.join(60)
     print("\n[bf16 wire, 8 ranks] max element error / sum|g_k|:", max(r[2] for r in res), " gradient-norm error:", max(r[3] for r in res))
     assert all(r[1] for r in res), res
+
+
+def _worker_chunked(rank, world, port, q):
+    """the CHUNKED branch of reduce_scatter_range_ / all_gather_range_ (per > CHUNK_ELEMS: strided windows of every rank's
+    part, staged through temporaries).  The real model reaches it at world = 2 (the non-Swin decay group is ~137 M elements: per ~68 M
+    > 64 M); here CHUNK_ELEMS is patched to 1024 so a small range does: unaligned start, a tail for rank 0, bf16 and f32 payloads."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pytorch_empirical_mvm_amd import dist as D
+    D.init_from_env("gloo")
+    D.CHUNK_ELEMS = 1024
+    ok = True
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 0.0)):
+        n, a, e = 20000, 37, 19411                       # unaligned start; (e - a) = 19374 = 2 * 9472 + a tail of 430 elements
+        bufs = [(torch.randn(n, generator=torch.Generator().manual_seed(7 + k)) * (4.0 if dtype == torch.bfloat16 else 1.0)).to(dtype) for k in range(world)]
+        buf = bufs[rank].clone()
+        per, tail = D.scatter_parts(a, e, world)
+        assert per > D.CHUNK_ELEMS and per % 256 == 0 and e > tail, (per, tail)
+        ncol = D.reduce_scatter_range_(buf, a, e, rank, world)
+        assert ncol == -(-per // D.CHUNK_ELEMS) + 1, ncol          # one collective per window + the tail's rooted reduce
+        want = sum(b.float() for b in bufs)
+        mine = slice(a + rank * per, a + (rank + 1) * per)
+        if dtype == torch.float32:
+            ok &= bool(torch.allclose(buf[mine], want[mine], atol=1e-5))
+        else:                                             # two bf16 addends: the sum is rounded once
+            ok &= bool(torch.equal(buf[mine], (bufs[0][mine].float() + bufs[1][mine].float()).to(dtype)))
+        if rank == 0:
+            ok &= bool(torch.allclose(buf[tail:e].float(), want[tail:e].to(dtype).float(), atol=1e-5 if dtype == torch.float32 else 0.0))
+        ok &= bool(torch.equal(buf[:a], bufs[rank][:a]) and torch.equal(buf[e:], bufs[rank][e:]))          # nothing outside the range moved
+        other = slice(a + (1 - rank) * per, a + (2 - rank) * per)
+        ok &= bool(torch.equal(buf[other], bufs[rank][other]))                                               # the peer's part: untouched by the scatter
+        # the parameter exchange: every rank's parts (and rank 0's tail) to everyone
+        buf[mine] = float(rank + 1)
+        if rank == 0:
+            buf[tail:e] = 9.0
+        ncol = D.all_gather_range_(buf, a, e, rank, world)
+        assert ncol == -(-per // D.CHUNK_ELEMS) + 1, ncol
+        for r_ in range(world):
+            ok &= bool((buf[a + r_ * per:a + (r_ + 1) * per] == float(r_ + 1)).all())
+        ok &= bool((buf[tail:e] == 9.0).all())
+    q.put((rank, bool(ok)))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_chunked_reduce_scatter_and_all_gather_ranges_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_chunked, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

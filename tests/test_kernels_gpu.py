@@ -21,7 +21,7 @@ def gc():
 
 
 @pytest.mark.parametrize("group", ["check_probe", "check_gemm_layouts", "check_gemm_colsum", "check_gemm_fp16_conv", "check_dvae_passes", "check_pool_grad", "check_gemm_fp8", "check_gemm_big", "check_gemm_p3", "check_gemm_epilogues", "check_gemm_round_split", "check_ln", "check_ln_gather",
-                                   "check_attn_window", "check_attn_bert", "check_attn_query_row", "check_attn_stream", "check_attn_seq2seq", "check_attn_colsum", "check_misc"])
+                                   "check_attn_window", "check_attn_window_spike", "check_attn_window_mask_boundary", "check_attn_window_nonfinite", "check_attn_bert", "check_attn_query_row", "check_attn_stream", "check_attn_seq2seq", "check_attn_colsum", "check_misc"])
 def test_kernel_group(gc, group):
     import torch
     gc.RESULTS.clear()

@@ -228,12 +228,35 @@ def test_droppath_dead_clip_elimination_equals_the_scaled_path(monkeypatch):
     batch = dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
     S = eng.store
     res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("VMVM_DROPPATH_DCE", mode)
-        S.grad.zero_()
-        losses, _ = eng.forward_backward(batch, negatives=neg, train=True, dp_all=dp_dev, dropout=False, backward=True, want_outputs=True)
-        torch.cuda.synchronize()
-        res[mode] = ({k: float(v.item()) for k, v in losses.items() if k in ("mtm", "mvm", "vtm")}, S.grad[:S.n_trainable].clone())
+    # (the engine reads every VMVM_* switch ONCE at construction -- setting the environment here would compare the compacted
+    # path with itself.  The switch is flipped on the live engine, and the two runs must have taken different paths: the compacted one
+    # launches vmvm_expand_batch_map / vmvm_copy_batches_bf16 (counted through the kernels module), the scaled one does not.)
+    from pytorch_empirical_mvm_amd import kernels as K
+    calls = {}
+    real_expand, real_copy = K.expand_batch_map, K.copy_batches
+
+    def counted(name, fn):
+        def w(*a, **k):
+            calls[name] = calls.get(name, 0) + 1
+            return fn(*a, **k)
+        return w
+    monkeypatch.setattr(K, "expand_batch_map", counted("expand", real_expand))
+    monkeypatch.setattr(K, "copy_batches", counted("copy", real_copy))
+    saved = eng.sw.droppath_dce
+    launches = {}
+    try:
+        for mode in ("1", "0"):
+            eng.sw.droppath_dce = mode
+            calls.clear()
+            S.grad.zero_()
+            losses, _ = eng.forward_backward(batch, negatives=neg, train=True, dp_all=dp_dev, dropout=False, backward=True, want_outputs=True)
+            torch.cuda.synchronize()
+            launches[mode] = dict(calls)
+            res[mode] = ({k: float(v.item()) for k, v in losses.items() if k in ("mtm", "mvm", "vtm")}, S.grad[:S.n_trainable].clone())
+    finally:
+        eng.sw.droppath_dce = saved
+    assert launches["1"].get("expand", 0) > 20 and launches["1"].get("copy", 0) > 20, launches       # compact row maps + identity copies of the dropped clips
+    assert not launches["0"], launches                                                                # every clip ran, dropped ones scaled by 0
     for k, v in res["1"][0].items():
         assert abs(v - res["0"][0][k]) <= 1e-3 * abs(res["0"][0][k]) + 1e-4, (k, v, res["0"][0][k])
     g1, g0 = res["1"][1].double(), res["0"][1].double()

@@ -1,0 +1,271 @@
+"""Round-6 parity cases (VERDICT r05 "next round" items 1 and 3).
+
+* `test_reference_shaped_step_through_autograd_equals_the_fused_step`: the REFERENCE's training step shape (agent.py:161-193,
+  main_pretrain.py:555-573) -- `out = model(batch)`; cross entropies and the masked pixel L1 (through `model.decoder_pixel`, as
+  `calc_mvm_loss` calls it, main_pretrain.py:420-432) in PLAIN torch; `loss.backward()` -- against the fused `engine.forward_backward`
+  on the same batch: the three losses and the gradient arena (eval mode, then train mode with the same DropPath draws / Philox offsets).
+  Asserted: losses within 2e-3 relative; arena cosine >= 0.9995, norm within 0.5 %, every optimizer group cosine >= 0.999 (the pixel
+  head runs in f32 torch on one side and on bf16 MFMA operands on the other; everything behind the three outputs is the same kernels).
+* `test_model_alone_under_a_torch_optimizer`: the model swapped in ALONE: torch.optim.AdamW over `model.parameters()`,
+  `clip_grad_norm_`, `optimizer.zero_grad()` (set_to_none) -- what the reference's `Agent_Base.backward_step` does -- for three steps
+  against this package's agent (fused AdamW kernel) from the same start: parameters agree (update-direction cosine >= 0.999), which
+  also proves the bf16 compute copy is refreshed after a torch-side update and the `.grad` views are re-attached after `zero_grad`.
+* `test_fifty_step_trajectory_vs_oracle`: 50 optimizer steps (reduced widths, eval-mode forward, GELU' codes on) against the oracle's
+  `train_step`: per-step losses, update direction and update norm at step 50 (bars in the test).
+* `test_seeded_steps_replay`: two seeded 2-step train-mode runs from the same state: what is bit-identical and what sits at the f32
+  atomics floor (DESIGN 5 "Determinism" lists the kernels).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _engine(cfg_args):
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd.model import VIOLET_Pretrain
+    args = CFG.get_args(**cfg_args)
+    return VIOLET_Pretrain(args, None, device="cuda"), args
+
+
+ARCH = dict(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+
+
+def _reference_losses(model, out, ref_batch):
+    """Agent_Pretrain.step's loss block (main_pretrain.py:555-567) + calc_mvm_loss's pixel branch (:420-432), in plain torch"""
+    ce = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    out_mtm, out_mvm, out_vtm = out["out_mtm"], out["out_mvm"], out["out_vtm"]
+    ans_mtm, ans_vtm = out["ans_mtm"], out["ans_vtm"]
+    ls_mtm = ce(out_mtm.flatten(0, len(out_mtm.shape) - 2), ans_mtm.flatten(0, len(ans_mtm.shape) - 1))
+    ls_vtm = ce(out_vtm.flatten(0, len(out_vtm.shape) - 2), ans_vtm.flatten(0, len(ans_vtm.shape) - 1))
+    img, mvm_mask = ref_batch["unmask_img"], ref_batch["mvm_mask"]
+    _B, _T, _in_C, _H, _W = img.shape
+    _h, _w = _H // model.patch_size, _W // model.patch_size
+    _, _L, _C = out_mvm.shape
+    _l = _L // _T
+    x = torch.cat([out_mvm[:, _l * _t + 1: _l * (_t + 1), :] for _t in range(_T)], dim=1)
+    x = x.permute(0, 2, 1).reshape(_B, _C, _T, _h, _w)
+    x = x.permute(0, 2, 1, 3, 4).reshape(_B * _T, _C, _h, _w)
+    x = model.decoder_pixel(x.float()).view(_B, _T, _in_C, _H, _W)
+    ls_pix = torch.nn.functional.l1_loss(x, img, reduction="none")
+    ls_mvm = (ls_pix.float() * mvm_mask.float()).sum() / (mvm_mask.float().sum() + 1e-5) / _in_C
+    return ls_mtm, ls_vtm, ls_mvm
+
+
+def _setup(B=3, temp=1.0, seed=2, **extra):
+    from oracle import violet_ref as R                  # (batch / weight generators)
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=4, max_size_frame=6, arch_override=ARCH, bert_layers=2, size_img=96, temp=temp, **extra))
+    cfg = R.make_cfg("tiny", T=4, img=96, arch=ARCH, bert_layers=2, temp=temp)
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=seed)
+    neg = R.vtm_negatives_default(B)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).contiguous()
+    dev = "cuda"
+    fused = dict(img=img.to(dev), cov=cov.to(dev), txt=mb["txt"].to(dev), mask=mask.to(dev), ans_mtm=mb["ans_mtm"].to(dev))
+    # the reference's batch after masking(): `img` is the MASKED clip, `unmask_img` / `mvm_mask` feed calc_mvm_loss
+    ref = dict(img=mb["img"].to(dev), txt=mb["txt"].to(dev), mask=mask.to(dev), ans_mtm=mb["ans_mtm"].to(dev), ans_mvm=None,
+               unmask_img=img.to(dev), mvm_mask=mb["mvm_mask"].to(dev))
+    return model, args, sd, cfg, mb, neg, fused, ref
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_reference_shaped_step_through_autograd_equals_the_fused_step(train):
+    model, args, sd, cfg, mb, neg, fused, ref = _setup()
+    eng, S = model.engine, model.engine.store
+    B = fused["img"].shape[0]
+    model.train(train)
+    dp = None
+    if train:                                           # fixed DropPath draws for both runs (some clips dropped, padding clips, whole blocks)
+        rng = np.random.RandomState(7)
+        n_blk = sum(cfg["depths"])
+        keep = 1.0 - np.linspace(0, 0.4, n_blk)
+        dp = [tuple(torch.from_numpy((np.floor(keep[i] + rng.rand(B)) / keep[i]).astype(np.float32)).cuda() for _ in range(2)) for i in range(n_blk)]
+    # fused step
+    eng.rng_offset = 0
+    S.grad.zero_()
+    losses, _ = eng.forward_backward(fused, negatives=neg, train=train, dp_all=dp, backward=True)
+    torch.cuda.synchronize()
+    lf = {k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}
+    gf = S.grad[:S.n_trainable].clone()
+    # the reference-shaped step: model(batch) -> torch losses -> loss.backward()
+    eng.rng_offset = 0
+    S.grad.zero_()
+    out = model(ref, negatives=neg, dp_all=dp)
+    assert all(out[k].grad_fn is not None for k in ("out_mtm", "out_mvm", "out_vtm")), "outputs must carry a grad_fn"
+    assert out["out_mtm"].shape == (B, 32, cfg["vocab"]) and out["out_vtm"].shape == (B, min(B, 4)) and out["out_mvm"].shape[0] == B
+    ls_mtm, ls_vtm, ls_mvm = _reference_losses(model, out, ref)
+    ls = ls_mtm + ls_vtm + ls_mvm
+    ls.backward()
+    torch.cuda.synchronize()
+    la = {"mtm": float(ls_mtm), "vtm": float(ls_vtm), "mvm": float(ls_mvm)}
+    ga = S.grad[:S.n_trainable].clone()
+    for k in lf:
+        assert abs(la[k] - lf[k]) <= 2e-3 * abs(lf[k]) + 1e-4, (k, la[k], lf[k])
+    cos, ratio = _cos(ga, gf), float(ga.double().norm() / gf.double().norm())
+    print(f"\n[autograd step, train={train}] losses {la} vs fused {lf}; arena cosine {cos:.6f}, norm ratio {ratio:.5f}")
+    assert cos >= 0.9995 and abs(ratio - 1.0) <= 5e-3, (cos, ratio)
+    for gi in range(4):
+        a, e = S.segments[gi]
+        if e > a and float(gf[a:e].norm()) > 0:
+            assert _cos(ga[a:e], gf[a:e]) >= 0.999, (gi, _cos(ga[a:e], gf[a:e]))
+    # a second backward through the same forward must fail loudly (the tape is consumed), not silently double the gradients
+    with pytest.raises(RuntimeError):
+        (out["out_vtm"].sum()).backward()
+    # the agent surface of the reference: forward_step / backward_step(loss) drive the same path
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    agent = Agent_Pretrain(args, model)
+    before = S.flat[:1000].clone()
+    out = agent.forward_step(ref)
+    l3 = _reference_losses(model, out, ref)
+    agent.sched_step = 5
+    agent.backward_step(l3[0] + l3[1] + l3[2])
+    torch.cuda.synchronize()
+    assert not torch.equal(before, S.flat[:1000]) and float(S.grad.abs().max()) == 0.0      # parameters moved, gradients zeroed
+
+
+def test_model_alone_under_a_torch_optimizer():
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    steps, lr = 3, 5e-5
+    finals = {}
+    for who in ("torch", "fused"):
+        model, args, sd, cfg, mb, neg, fused, ref = _setup(max_iter=20, lr=lr)
+        eng, S = model.engine, model.engine.store
+        model.eval()                                       # (dropout / DropPath off: the two runs differ in the optimizer only)
+        if who == "torch":
+            # the reference's groups (agent.py:84-113): decay 1e-3 except bias / LayerNorm; one lr here (vis_backbone_lr_mul = 1)
+            nd = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+            named = [(n, p) for n, p in model.named_parameters() if n in S.index and n not in S.FROZEN]
+            opt = torch.optim.AdamW([{"params": [p for n, p in named if not any(x in n for x in nd)], "weight_decay": args.decay},
+                                     {"params": [p for n, p in named if any(x in n for x in nd)], "weight_decay": 0.0}], lr=lr, betas=(0.9, 0.98), eps=1e-8)
+            from pytorch_empirical_mvm_amd import config as CFG
+            for step in range(steps):
+                for g in opt.param_groups:
+                    g["lr"] = max(1e-8, lr * CFG.lr_factor(step, args.max_iter))
+                out = model(ref, negatives=neg)
+                l3 = _reference_losses(model, out, ref)
+                (l3[0] + l3[1] + l3[2]).backward()
+                torch.nn.utils.clip_grad_norm_([p for _, p in named], args.max_grad_norm)
+                opt.step()
+                opt.zero_grad()                            # set_to_none=True: detaches every p.grad from the arena
+                assert all(p.grad is None for _, p in named)
+        else:
+            agent = Agent_Pretrain(args, model)
+            for step in range(steps):
+                out = agent.forward_step(ref)
+                l3 = _reference_losses(model, out, ref)
+                agent.backward_step(l3[0] + l3[1] + l3[2])
+        torch.cuda.synchronize()
+        init = torch.zeros(S.n_trainable, device="cuda")
+        for n, (o, c, _) in S.index.items():
+            if o < S.n_trainable and n in sd:
+                init[o:o + c] = sd[n].flatten().cuda()
+        finals[who] = S.flat[:S.n_trainable].clone() - init                # the update theta_3 - theta_0 (arena padding: 0 - 0)
+    ut, uf = finals["torch"], finals["fused"]
+    cos, ratio = _cos(ut, uf), float(ut.double().norm() / uf.double().norm())
+    print(f"\n[model alone under torch AdamW] update-direction cosine vs the fused AdamW {cos:.5f}, norm ratio {ratio:.4f}")
+    assert float(uf.abs().max()) > 0 and cos >= 0.999 and abs(ratio - 1.0) < 0.01, (cos, ratio)
+
+
+@pytest.mark.timeout(1500)
+def test_fifty_step_trajectory_vs_oracle():
+    """the logistic-cubic GELU, the 8-bit GELU' code and bf16 activations are SYSTEMATIC approximations -- what do
+    they do over a horizon?  50 optimizer steps on one batch (reduced widths, eval-mode forward, temp = 1, GELU' codes on wherever the
+    width allows: C % 64 == 0 Swin stages + both fusion layers) against the oracle's fp32 `train_step` trajectory from the same start.
+    Bars: every step's three losses within 2 % (+ 2e-3) of the oracle's at that step; update direction (theta_50 - theta_0) cosine >= 0.98;
+    update norm within 3 %."""
+    from oracle import violet_ref as R
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    arch = dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7))
+    n_steps, max_iter, lr = 50, 100, 1e-4
+    model, args = _engine(dict(vis_backbone_size="tiny", size_frame=2, max_size_frame=6, arch_override=arch, bert_layers=2, max_iter=max_iter,
+                               lr=lr, size_img=96, temp=1.0))
+    assert model.engine.gelu_code8
+    cfg = R.make_cfg("tiny", T=2, img=96, arch=arch, bert_layers=2, temp=1.0)
+    sd = R.make_state_dict(cfg)
+    model.load_state_dict(sd)
+    img, txt, mask = R.make_batch(cfg, 2)
+    mb = R.default_masking(cfg, img, txt, mask, seed=1)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8)
+    neg = R.vtm_negatives_default(2)
+    agent = Agent_Pretrain(args, model)
+    batch = agent.prepare_batch(dict(unmask_img=img, cov=cov.contiguous(), txt=mb["txt"], mask=mask, ans_mtm=mb["ans_mtm"]))
+    b = dict(img=batch["unmask_img"], cov=batch["cov"], txt=batch["txt"], mask=batch["mask"], ans_mtm=batch["ans_mtm"])
+    opt_state, worst = {}, {"mtm": 0.0, "vtm": 0.0, "mvm": 0.0}
+    first = last = None
+    for step in range(1, n_steps + 1):
+        ref = R.train_step(sd, cfg, mb, opt_state, step, max_iter, negatives=neg, lr=lr)
+        losses, _ = model.engine.forward_backward(b, negatives=neg, train=False, backward=True)
+        agent.backward_step()
+        got = {k: float(losses[k].item()) for k in worst}
+        for k in worst:
+            rel = abs(got[k] - ref[k]) / (abs(ref[k]) + 1e-12)
+            worst[k] = max(worst[k], rel)
+            assert abs(got[k] - ref[k]) <= 2e-2 * abs(ref[k]) + 2e-3, (step, k, got[k], ref[k])
+        first = first or dict(ref)
+        last = ref
+    got_sd = model.state_dict()
+    ur = torch.cat([(v - R.closed_form(k, tuple(v.shape))).double().flatten() for k, v in sd.items() if v.is_floating_point()])
+    ug = torch.cat([(got_sd[k].cpu() - R.closed_form(k, tuple(v.shape))).double().flatten() for k, v in sd.items() if v.is_floating_point()])
+    cos, ratio = _cos(ur, ug), float(ug.norm() / ur.norm())
+    print(f"\n[50-step trajectory] oracle losses step 1 {[round(first[k], 4) for k in ('mtm', 'vtm', 'mvm')]} -> step {n_steps} "
+          f"{[round(last[k], 4) for k in ('mtm', 'vtm', 'mvm')]}; worst per-step relative loss error {({k: round(v, 4) for k, v in worst.items()})}; "
+          f"update-direction cosine {cos:.4f}, norm ratio {ratio:.4f}")
+    assert last["mtm"] < first["mtm"] and last["mvm"] < first["mvm"], "the trajectory must actually move the losses"
+    assert cos >= 0.98 and abs(ratio - 1.0) <= 0.03, (cos, ratio)
+
+
+def test_seeded_steps_replay():
+    """Two runs of two seeded train-mode optimizer steps from the same state (same DropPath / negatives draws, same Philox offsets).
+    The forward has no atomics on its path except the loss sums' own f32 adds: step-1 losses equal to 1e-6.  The backward has f32
+    atomic accumulations (DESIGN 5 "Determinism" lists them: relative-position-table gradient, fused bias column sums, embedding-table
+    gradients), so gradient entries differ in their last bits from run to run: the step-1 gradient arenas must agree to 1e-6 of their
+    norm.  AdamW's first steps are sign-like, so entries whose gradient is analytically ZERO (the key bias of every attention: softmax
+    is shift-invariant) move by +-lr on rounding noise: the parameter arenas after two steps are compared on everything else to 1e-6 and
+    as a whole to 1e-4 (measured values printed).  A replay reproduces a run at the f32 rounding floor, not bit for bit."""
+    from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+    res = []
+    for run in range(2):
+        model, args, sd, cfg, mb, neg, fused, ref = _setup(max_iter=20, lr=5e-5)
+        eng, S = model.engine, model.engine.store
+        agent = Agent_Pretrain(args, model)
+        model.train()
+        np.random.seed(123)
+        eng.rng_offset = 0
+        ls, g1 = [], None
+        for step in range(2):
+            S.sync_pending()
+            losses, _ = eng.forward_backward(fused, negatives=neg, train=True, backward=True)
+            if g1 is None:
+                g1 = S.grad[:S.n_trainable].clone()
+            agent.backward_step()
+            ls.append({k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")})
+        torch.cuda.synchronize()
+        res.append((ls, g1, S.flat[:S.n_trainable].clone(), S))
+    (l0, g0, p0, S), (l1, g1, p1, _) = res
+    for k in l0[0]:
+        assert abs(l0[0][k] - l1[0][k]) <= 1e-6 * abs(l0[0][k]) + 1e-7, (k, l0[0][k], l1[0][k])
+    relg = float((g0.double() - g1.double()).norm() / g0.double().norm())
+    keyb = torch.zeros(S.n_trainable, dtype=torch.bool, device="cuda")          # analytically-zero gradients: the K third of every qkv / key bias
+    for n, (o, c, shp) in S.index.items():
+        if n.endswith("attn.qkv.bias"):
+            keyb[o + c // 3:o + 2 * (c // 3)] = True
+        if n.endswith("attention.self.key.bias"):
+            keyb[o:o + c] = True
+    relp = float((p0.double() - p1.double()).norm() / p0.double().norm())
+    relp_rest = float(((p0.double() - p1.double()) * (~keyb)).norm() / p0.double().norm())
+    print(f"\n[replay] step-1 gradient arenas: relative L2 difference {relg:.3e} ({int((g0 != g1).sum())} of {g0.numel()} entries differ in some bit); "
+          f"parameters after 2 steps: {relp:.3e} (without the {int(keyb.sum())} key-bias entries {relp_rest:.3e}); step-2 losses {l0[1]} / {l1[1]}")
+    assert relg <= 1e-6, relg
+    assert relp_rest <= 1e-5 and relp <= 1e-4, (relp_rest, relp)
+    for k in l0[1]:
+        assert abs(l0[1][k] - l1[1][k]) <= 1e-4 * abs(l0[1][k]) + 1e-6, (k, l0[1][k], l1[1][k])

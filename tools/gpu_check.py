@@ -587,7 +587,11 @@ def check_attn_window_spike():
         qkv = rnd(nseq * N, 3 * C_, scale=1.0)
         q3 = qkv.view(nseq, N, 3, heads, 32)
         # (sequence, head, query slot, key slot): same mask region needed for the pair to be live -> use neighbours inside one tile pair
-        for (sq, hh, qi, kj) in [(0, 0, 5, 390), (1, 1, 200, 201), (nseq - 1, 0, 391, 388), (2, 1, 17, 3), (3, 0, 300, 310)]:
+        # (round 6: + spikes whose key lies in the LAST live block of a masked walk -- sequence 2 = the h-split window: class-A queries walk
+        # classes A + B, key slot 13 * 16 + 5 sits in B's last tile; sequence 3 = the corner window: class-C queries walk class C only, key in
+        # tile 19; sequence 1 = the w-split window: class-B query (tile 9) against class D's tile 24 = the last block of the {B, D} walk)
+        for (sq, hh, qi, kj) in [(0, 0, 5, 390), (1, 1, 200, 201), (nseq - 1, 0, 391, 388), (2, 1, 17, 3), (3, 0, 300, 310),
+                                 (2, 0, 40, 13 * 16 + 5), (3, 1, 14 * 16 + 2, 19 * 16 + 9), (1, 0, 9 * 16 + 1, 24 * 16 + 3)]:
             q3[sq, kj, 1, hh] = (q3[sq, qi, 0, hh].float() * (4.5 if shifted else 8.0)).to(BF)    # (shifted: cross terms with MASKED queries must stay << 100 -- the kernels skip masked pairs, the reference adds -100)
         table = (torch.randn((2 * 8 - 1) * 13 * 13, heads, device=dev) * 0.5)
         rc_t = torch.from_numpy(rc).to(dev)
@@ -621,6 +625,114 @@ def check_attn_window_spike():
         rep(tag + " bwd dk", dqkv[:, C_:2 * C_], gq[:, C_:2 * C_])
         rep(tag + " bwd dv", dqkv[:, 2 * C_:], gq[:, 2 * C_:])
         rep(tag + " bwd dtable", dtab, tf.grad)
+
+
+def _win_problem(dims, B, heads, shifted, win=(8, 7, 7)):
+    """tables of one win_layout = 1 window-attention problem (slot order of swin_index.win3_perm)"""
+    D, H, W = dims
+    ws, ss = SI.get_window_size(dims, win, (4, 3, 3) if shifted else (0, 0, 0))
+    m, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+    N = ws[0] * ws[1] * ws[2]
+    nW = m.size // N
+    reg = SI.region_ids(Dp, Hp, Wp, ws, ss)
+    rc, rc0 = SI.rc_codes(N, win)
+    pm = SI.win3_perm()
+    rc_t = torch.from_numpy(np.ascontiguousarray(rc[pm])).to(dev)
+    reg_t = None if reg is None else torch.from_numpy(np.ascontiguousarray(reg[:, pm])).to(dev)
+    return N, nW, rc_t, rc0, reg_t
+
+
+def _win_ref(qkv, table, nseq, N, heads, rc_t, rc0, reg_t, B):
+    """fp32 torch reference of WindowAttention3D (video_swin.py:147-172) with the reference's ADDITIVE -100 shift mask (:292-307)"""
+    C_ = heads * 32
+    qf = qkv.float().requires_grad_(True)
+    tf = table.clone().requires_grad_(True)
+    x = qf.view(nseq, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    idx = (rc_t[:, None] - rc_t[None, :] + rc0).long()
+    bias = tf[idx.reshape(-1)].view(N, N, heads).permute(2, 0, 1)[None]
+    if reg_t is not None:
+        mk = torch.where(reg_t[:, :, None] != reg_t[:, None, :], -100.0, 0.0)
+        bias = bias + mk.repeat(B, 1, 1)[:, None]
+    s_ = x[0] @ x[1].transpose(-1, -2) + bias
+    o = s_.softmax(-1) @ x[2]
+    return qf, tf, s_, o.transpose(1, 2).reshape(nseq * N, C_)
+
+
+def check_attn_window_mask_boundary():
+    """The shift mask at its boundary.  The reference ADDS -100 to the logits of pairs in different regions
+    (video_swin.py:304-306); the win_layout = 1 kernels SKIP those pairs (probability exactly 0).  The two agree while
+    exp(s_masked - 100 - max_live) underflows the f32 / bf16 resolution of the row, i.e. while no masked RAW logit exceeds the row's live
+    maximum by more than ~83 (documented: include/vmvm.h vmvm_attn_fwd_desc.region).  Here masked raw logits exceed the live
+    row maximum by ~20-30 (far outside anything a trained network produces for a cross-region pair, still 70 below the leak): forward,
+    lse and every gradient must equal the additive-mask reference."""
+    dims, B, heads = (8, 14, 14), 2, 2
+    N, nW, rc_t, rc0, reg_t = _win_problem(dims, B, heads, True)
+    C_ = heads * 32
+    nseq = B * nW
+    qkv = rnd(nseq * N, 3 * C_, scale=0.5)                 # live logits ~ N(0, 8 * 0.0625): row maxima ~ 3-5
+    q3 = qkv.view(nseq, N, 3, heads, 32)
+    reg_h = reg_t.cpu().numpy()
+    cases = []
+    for (sq, hh, qi) in [(1, 0, 5), (2, 1, 100), (3, 0, 391), (nseq - 1, 1, 230)]:
+        wtype = sq % nW
+        other = np.flatnonzero(reg_h[wtype] != reg_h[wtype, qi])          # key slots in ANOTHER region of this window: masked for query qi
+        assert other.size > 0
+        kj = int(other[len(other) // 2])
+        q3[sq, kj, 1, hh] = (q3[sq, qi, 0, hh].float() * 3.2).to(BF)      # raw logit ~ 3.2 |q|^2 ~ 26
+        cases.append((sq, hh, qi, kj))
+    table = (torch.randn((2 * 8 - 1) * 13 * 13, heads, device=dev) * 0.5)
+    out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t,
+                               rc0=rc0, region=reg_t, n_win=nW, win_layout=1)
+    qf, tf, s_, ref = _win_ref(qkv, table, nseq, N, heads, rc_t, rc0, reg_t, B)
+    raw = s_.detach() + torch.where(reg_t[:, :, None] != reg_t[:, None, :], 100.0, 0.0).repeat(B, 1, 1)[:, None]      # logits before the mask
+    live_max = s_.detach().amax(-1)
+    exc = min(float(raw[sq, hh, qi, kj] - live_max[sq, hh, qi]) for (sq, hh, qi, kj) in cases)
+    print(f"     (masked raw logits exceed their row's live maximum by >= {exc:.1f})")
+    assert exc > 15.0, exc
+    tag = "win attn mask boundary (masked logit > live max + 15)"
+    rep(tag + " fwd", out, ref)
+    rep(tag + " lse", lse.view(nseq, heads, N), torch.logsumexp(s_, -1), tol=1e-3)
+    dout = rnd(nseq * N, C_)
+    ref.backward(dout.float())
+    dtab = torch.zeros_like(table)
+    dqkv = K.attention_bwd(dout, qkv, out, lse, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table,
+                           rc=rc_t, rc0=rc0, region=reg_t, n_win=nW, dbias_table=dtab, win_layout=1)
+    gq = qf.grad.clone()
+    gq[:, :C_] *= 32 ** -0.5
+    rep(tag + " bwd dq", dqkv[:, :C_], gq[:, :C_])
+    rep(tag + " bwd dk", dqkv[:, C_:2 * C_], gq[:, C_:2 * C_])
+    rep(tag + " bwd dv", dqkv[:, 2 * C_:], gq[:, 2 * C_:])
+    rep(tag + " bwd dtable", dtab, tf.grad)
+
+
+def check_attn_window_nonfinite():
+    """The win4 forward's overflow retry must TERMINATE on non-finite input: a NaN / inf query row makes l / O non-finite
+    on the first walk AND on the retry with the exact maxima -- the loop is `given -> break`, so the wave leaves after the second walk.
+    The poisoned rows come out non-finite, every other sequence (and every other head of the poisoned sequences) equals the reference."""
+    dims, B, heads = (8, 14, 14), 2, 2
+    for shifted in (False, True):
+        N, nW, rc_t, rc0, reg_t = _win_problem(dims, B, heads, shifted)
+        C_ = heads * 32
+        nseq = B * nW
+        qkv = rnd(nseq * N, 3 * C_, scale=1.0)
+        q3 = qkv.view(nseq, N, 3, heads, 32)
+        q3[1, 7, 0, 0, 3] = float("nan")                      # one query element of (sequence 1, head 0, slot 7)
+        q3[nseq - 1, 391, 0, 1, 0] = float("inf")             # the odd tile's wave, head 1, last sequence
+        table = (torch.randn((2 * 8 - 1) * 13 * 13, heads, device=dev) * 0.5)
+        out, lse = K.attention_fwd(qkv, nseq, N, heads, 32, 0, 32 ** -0.5, q_off=0, k_off=C_, v_off=2 * C_, bias_table=table, rc=rc_t,
+                                   rc0=rc0, region=reg_t, n_win=nW, win_layout=1)
+        torch.cuda.synchronize()                              # (returns: the retry loop ended)
+        _, _, _, ref = _win_ref(qkv, table, nseq, N, heads, rc_t, rc0, reg_t, B)
+        o4, r4 = out.float().view(nseq, N, heads, 32), ref.detach().view(nseq, N, heads, 32)
+        bad = torch.zeros(nseq, N, heads, dtype=torch.bool, device=dev)
+        bad[1, 7, 0] = True
+        bad[nseq - 1, 391, 1] = True
+        tag = f"win attn non-finite input shifted={shifted}"
+        ok_rows = ~bad
+        rep(tag + " clean rows", o4[ok_rows], r4[ok_rows])
+        nonfin = (~torch.isfinite(o4[bad])).any(-1).all()
+        RESULTS.append((tag + " poisoned rows non-finite", 0.0 if bool(nonfin) else 1.0, 0.0, not bool(nonfin)))
+        print(f"  {'ok ' if bool(nonfin) else 'BAD'} {tag} poisoned rows non-finite")
 
 
 def check_attn_bert():
@@ -1360,9 +1472,9 @@ def bench_ln():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnsp", "attnb", "attns", "attnc", "attna", "misc", "bench"]
+    which = sys.argv[1:] or ["probe", "gemm", "cs", "f16", "big", "epi", "ln", "lng", "attnw", "attnsp", "attnmb", "attnnf", "attnb", "attns", "attnc", "attna", "misc", "bench"]
     table = dict(probe=check_probe, gemm=check_gemm_layouts, cs=check_gemm_colsum, f16=check_gemm_fp16_conv, big=check_gemm_big, p3=check_gemm_p3, epi=check_gemm_epilogues, ln=check_ln, lng=check_ln_gather,
-                 attnw=check_attn_window, attnsp=check_attn_window_spike, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc, dvae=check_dvae_passes, pool=check_pool_grad)
+                 attnw=check_attn_window, attnsp=check_attn_window_spike, attnmb=check_attn_window_mask_boundary, attnnf=check_attn_window_nonfinite, attnb=check_attn_bert, attns=check_attn_stream, attnc=check_attn_seq2seq, attna=check_attn_colsum, f8=check_gemm_fp8, misc=check_misc, dvae=check_dvae_passes, pool=check_pool_grad)
     for w in which:
         if w == "bench":
             run(bench_gemm); run(bench_attn)

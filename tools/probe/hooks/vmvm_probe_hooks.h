@@ -8,6 +8,9 @@
 //   -DVMVM_PROBE_STAGGER=P / -DVMVM_PROBE_STAGGER_CU=pct     start-up staggers (stagger128_probe.sh, stagger_cu_probe.sh)
 //   -DVMVM_PROBE_BUILD            LayerNorm backward: workgroups per CU from VMVM_LN_PER_CU (tools/gpu_check.py benchln)
 //   -DW3_TIMELINE                 cycle stamps of waves 0 and 5 of attn_bwd_dkv_win3_kernel (tools/scratch/w3_timeline.py)
+//   -DW4_TIMELINE                 s_memtime stamps of every wave of workgroup 0, sequences 2..5, of the win4 kernels into the buffer passed as
+//                                 vmvm_attn_fwd_desc.drop_mask ([4 sequences][13 waves][32 stamps] u64; tools/scratch/w4_timeline.py)
+//   -DW4_NO_ODD                   win4 forward: wave 12 runs the two-tile walk like the others (cost of the odd tile)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -145,6 +148,21 @@ struct W3Timeline {
   __device__ __forceinline__ void stamp(int) {}
   __device__ __forceinline__ void flush(int) {}
 };
+#endif
+
+#ifdef W4_TIMELINE
+constexpr bool W4_TIMELINE_BUILD = true;
+__device__ __forceinline__ void w4_stamp(void* buf, int block, int b, int lane, int wave, int idx) {
+  if (buf && block == 0 && b >= 2 && b < 6 && lane == 0) reinterpret_cast<unsigned long long*>(buf)[((b - 2) * 13 + wave) * 32 + idx] = __builtin_readcyclecounter();
+}
+#else
+constexpr bool W4_TIMELINE_BUILD = false;
+__device__ __forceinline__ void w4_stamp(void*, int, int, int, int, int) {}
+#endif
+#ifdef W4_NO_ODD
+constexpr bool W4_SKIP_ODD = true;
+#else
+constexpr bool W4_SKIP_ODD = false;
 #endif
 
 }  // namespace vmvm_hook
