@@ -311,14 +311,18 @@ __global__ __launch_bounds__(832) void attn_fwd_win4_kernel(const vmvm_attn_fwd_
     };
     // wave 12 holds query class D only: its walks exist for the live sets of class D (15, 12, 10, 8) -- the switch above is shared
     auto walk_m = [&](const bool given, const bool first) __attribute__((always_inline)) { if (odd) walk_n(IC4<1>{}, given, first); else walk_n(IC4<2>{}, given, first); };
-    auto finite = [&]() __attribute__((always_inline)) {       // l in (0, inf) and every |O| < inf (NaN fails both compares)
+    // l in (0, 2^125) and every |O| < inf (NaN fails both compares).  The bound on l is NOT "finite": the epilogue multiplies by
+    // v_rcp_f32(l), which flushes a denormal result to zero -- for l in (2^126, 2^128) the row came out as ZEROS with a correct lse
+    // (a row whose maximum sits 87.3 .. 88.7 above the first block's: found in round 6 by the widened spike test, a random query
+    // against a spiked key).  Below 2^125 the reciprocal is a normal number with a factor 2 to spare for seq_scale.
+    auto finite = [&]() __attribute__((always_inline)) {
       bool ok = true;
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         float m0 = fmaxf(fmaxf(fabsf(o[x][0][0]), fabsf(o[x][0][1])), fmaxf(fabsf(o[x][0][2]), fabsf(o[x][0][3])));
         float m1 = fmaxf(fmaxf(fabsf(o[x][1][0]), fabsf(o[x][1][1])), fmaxf(fabsf(o[x][1][2]), fabsf(o[x][1][3])));
         const float sm = o[x][0][0] + o[x][0][1] + o[x][0][2] + o[x][0][3] + o[x][1][0] + o[x][1][1] + o[x][1][2] + o[x][1][3];     // NaN anywhere -> NaN
-        ok = ok && (osum[x][0] < 3.0e38f) && (osum[x][0] > 0.f) && (fmaxf(m0, m1) < 3.0e38f) && (sm == sm);
+        ok = ok && (osum[x][0] < 4.0e37f) && (osum[x][0] > 0.f) && (fmaxf(m0, m1) < 3.0e38f) && (sm == sm);
       }
       return ok;
     };
