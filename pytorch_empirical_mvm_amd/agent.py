@@ -10,6 +10,7 @@ import torch
 from . import config as CFG
 from . import dist as D
 from . import kernels as K
+from . import lib as L
 
 
 class Agent_Pretrain:
@@ -324,7 +325,7 @@ class Agent_Pretrain:
             # forward's first kernels.  (Round 4 kept the other order behind VMVM_OPT_ORDER; its A/B was 0.07-0.16 ms: removed in round 5.)
             update((0, 2))
             eng.wstream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(eng.wstream):
+            with L.on_stream(eng.wstream):
                 update((1, 3))
                 S.refresh_transposed("other")
                 for gi in (1, 3):

@@ -30,6 +30,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import lib as L
 from .switches import Switches
 
 CHUNK_ELEMS = 64 * 1024 * 1024      # 256 MiB of f32 (128 MiB of bf16) per collective
@@ -320,7 +321,7 @@ class GradReducer:
             self.stream.wait_stream(torch.cuda.current_stream())
             for ws in self.wait_streams:
                 self.stream.wait_stream(ws)
-            with torch.cuda.stream(self.stream):
+            with L.on_stream(self.stream):
                 for a, e in ranges:
                     self._reduce_range(a, e)
             self.pending = True

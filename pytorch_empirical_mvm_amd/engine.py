@@ -10,13 +10,14 @@ EncVideo.forward (model.py:32-78) -> SwinTransformer3D.forward (video_swin.py:47
 go_cross x2 (model.py:204-214) ; heads + losses (main_pretrain.py:374-432, 555-567)."""
 import math
 import os
-from collections import OrderedDict
+from collections import OrderedDict, deque
 
 import numpy as np
 import torch
 
 from . import config as CFG
 from . import kernels as K
+from . import lib as L
 from . import swin_index as SI
 from .engine_downstream import DownstreamMixin
 from .engine_fusion import FusionMixin
@@ -57,6 +58,8 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         self.wstream = None
         self.other_ready = None             # event: the non-Swin half of the previous optimizer step (agent.backward_step) has finished on wstream
         self._wpending = False              # weight-gradient launches on wstream the main stream has not waited for yet
+        self._wheld = deque()               # (event on wstream behind a weight-gradient launch, its operands): kept alive until the side stream has passed it
+        self._wev_pool = []
         if self.device.type == "cuda":
             self.workspace = torch.empty(192 << 20, device=self.device, dtype=torch.uint8)        # split-K slabs of the wgrad GEMMs
             K.set_workspace(self.workspace)
@@ -85,11 +88,24 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
             fn(None)
             return
         self.wstream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.wstream):
+        with L.on_stream(self.wstream):
             fn(self.workspace_w)
-        for t in operands:
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(self.wstream)
+            if self.sw.wgrad_hold:
+                ev = self._wev_pool.pop() if self._wev_pool else torch.cuda.Event()
+                ev.record()
+        if self.sw.wgrad_hold:
+            # Round 6: the operands are HELD (a Python reference in a FIFO) until the side stream has passed their launch -- one event per
+            # launch, the oldest polled once per launch.  Round 4-5 marked them with `record_stream` instead: every block freed that way
+            # leaves an event in the caching allocator, which polls ALL outstanding ones on EVERY allocation -- torch.empty cost 48 us
+            # per call in the step (8 205 calls, 0.40 s of a 9-step profile: 44 ms of the host's ~65 ms per step, tools/scratch/host_profile.py).
+            held = self._wheld
+            held.append((ev, operands))
+            while held and held[0][0].query():
+                self._wev_pool.append(held.popleft()[0])
+        else:
+            for t in operands:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.wstream)
         self._wpending = True
 
     def _wgrad_join(self):
@@ -97,6 +113,9 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         if self.wstream is not None and self._wpending:
             torch.cuda.current_stream().wait_stream(self.wstream)
             self._wpending = False
+            # everything the main stream enqueues from here on is ordered behind the side stream: the held operands can go
+            while self._wheld:
+                self._wev_pool.append(self._wheld.popleft()[0])
 
     def _linear_bwd(self, dy, x, wname, bname, *, w=None, gw=None, gb=None, M=None, row_scale=None, rows_per_scale=0,
                     need_dx=True, dx_kw=None, wN=None, wT=None, wsync=False, cs_scale=None):

@@ -9,6 +9,7 @@ import torch
 
 from . import config as CFG
 from . import kernels as K
+from . import lib as L
 from . import swin_index as SI
 from .store import BF16, F32, V, DropScale, _acc, _gout, _h2d, _dev_i32
 
@@ -163,6 +164,11 @@ class HeadsMixin:
     # -------------------------------------------------------------- full step
     def forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
                          dropout=None, on_other_grads_ready=None):
+        with L.pin_current():               # (one look-up of torch's current stream per step instead of one per launch, lib.stream)
+            return self._forward_backward(batch, negatives, train, dp_all, want_outputs, backward, dropout, on_other_grads_ready)
+
+    def _forward_backward(self, batch, negatives=None, train=True, dp_all=None, want_outputs=False, backward=True,
+                          dropout=None, on_other_grads_ready=None):
         """One pass of the hot path.  batch: img f32 (B,T,3,H,W) UN-masked, cov u8 (B,T,h,w), txt i64 (B,X) (masked ids),
         mask i64 (B,X), ans_mtm i64 (B,X).  Returns dict of loss scalars (device f32 tensors) and optional outputs."""
         cfg, S, dev = self.cfg, self.store, self.device
@@ -347,6 +353,14 @@ class HeadsMixin:
 
     # -------------------------------------------------------------- the step OPEN at the reference's model outputs (autograd interop)
     def forward_open(self, batch, negatives=None, train=True, dp_all=None, dropout=None):
+        with L.pin_current():
+            return self._forward_open(batch, negatives, train, dp_all, dropout)
+
+    def backward_open(self, tr, d_mtm, d_mvm, d_vtm, d_smtm=None, on_other_grads_ready=None):
+        with L.pin_current():
+            return self._backward_open(tr, d_mtm, d_mvm, d_vtm, d_smtm, on_other_grads_ready)
+
+    def _forward_open(self, batch, negatives=None, train=True, dp_all=None, dropout=None):
         """VIOLET_Pretrain.forward as the REFERENCE defines it (main_pretrain.py:226-267): the model ends at `out_mtm` (MLM logits
         (B, X, V) f32), `out_mvm` (the fusion encoder's visual-token states (B, T*(1+hw), H) bf16) and `out_vtm` ((B, O) pair scores / temp,
         f32); the losses -- and the MVM decoders, which the reference's agent applies itself (main_pretrain.py:420-432) -- are the
@@ -383,7 +397,7 @@ class HeadsMixin:
                 "out_smtm": tr["h_smtm"]["logits"][:, :Vv].reshape(B, X, Vv) if tr["use_smtm"] else None}
         return outs, tr
 
-    def backward_open(self, tr, d_mtm, d_mvm, d_vtm, d_smtm=None, on_other_grads_ready=None):
+    def _backward_open(self, tr, d_mtm, d_mvm, d_vtm, d_smtm=None, on_other_grads_ready=None):
         """the backward of `forward_open` from the gradients of its outputs (None = that output did not reach the loss).  Parameter
         gradients are ACCUMULATED into the gradient arena -- the `.grad` views of model.parameters() -- like autograd's AccumulateGrad."""
         S, dev, Hd = self.store, self.device, self.cfg["hidden"]

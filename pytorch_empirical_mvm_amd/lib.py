@@ -154,8 +154,46 @@ def exported_symbols():
     return sorted(_PROTOS)
 
 
+_PINNED = None        # raw handle of the stream the step is being issued on (None: ask torch)
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t every wrapper in kernels.py launches on.  `torch.cuda.current_stream()` costs ~8 us per call (device-index and
+    lazy-init checks, an environment look-up): at ~1 400 launches per step that was 8-10 ms of host time (tools/scratch/host_profile.py),
+    so the step bodies PIN the handle (`pin_current` / `on_stream`) and this returns it; outside a pinned region torch is asked."""
+    return _PINNED if _PINNED is not None else torch.cuda.current_stream().cuda_stream
+
+
+class _Pin:
+    __slots__ = ("handle", "saved", "ctx")
+
+    def __init__(self, handle, ctx=None):
+        self.handle, self.ctx = handle, ctx
+
+    def __enter__(self):
+        global _PINNED
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        self.saved, _PINNED = _PINNED, self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED
+        _PINNED = self.saved
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def pin_current():
+    """pin torch's current stream for the body (the step functions wrap themselves in this)"""
+    return _Pin(torch.cuda.current_stream().cuda_stream)
+
+
+def on_stream(s):
+    """`with torch.cuda.stream(s)` + the pin: EVERY stream switch inside the package goes through here, so a pinned region never
+    launches on a stream torch does not consider current"""
+    return _Pin(s.cuda_stream, torch.cuda.stream(s))
 
 
 def ptr(t):

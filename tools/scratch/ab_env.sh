@@ -7,6 +7,6 @@ for r in 1 2; do
   for cfg in "$A" "$B"; do
     env $cfg python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg :', d['value'], 'clips/s', d['ms_per_step'], 'ms/step')"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg :', d['value'], 'clips/s', d['ms_per_step'], 'ms/step; host issue', d.get('host_issue_ms_per_step'), 'ms; roofline', d['roofline']['achieved'], 'TF; peak mem', d.get('peak_mem_gib'))"
   done
 done 2>&1 | tee -a gpurun_out/ab_env.txt

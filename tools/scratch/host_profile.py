@@ -9,5 +9,5 @@ bench.main()
 pr.disable()
 s = io.StringIO()
 ps = pstats.Stats(pr, stream=s).sort_stats("tottime")
-ps.print_stats(28)
-print(s.getvalue()[:6000])
+ps.print_stats(70)
+print(s.getvalue()[:14000])
