@@ -40,7 +40,8 @@ class Agent_Pretrain:
             # the autograd-driven step (model(batch) ... loss.backward(), model._OpenStep) starts the same two exchange phases from inside
             # its backward node: the non-Swin groups behind the fusion backward, the Swin tail behind stage n-2
             self.model._grad_hook = self.comm.reduce_other
-            self.engine.on_swin_tail_ready = self.comm.reduce_swin_tail
+            self.model._tail_hook = self.comm.reduce_swin_tail     # (installed on the engine only for the duration of that backward: a bare
+            #                                                         engine.forward_backward() -- tools/dp_check.py's per-rank reference -- must not reduce)
             D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
             self.engine.store.refresh_shadow()
             # DDP also broadcasts the frozen teachers' parameters (they are sub-modules of the wrapped model): without this, ranks

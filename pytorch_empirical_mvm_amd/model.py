@@ -59,7 +59,13 @@ class _OpenStep(torch.autograd.Function):
         ctx.tr = None
         if tr is None:
             raise RuntimeError("VIOLET_Pretrain: backward through one forward twice (the activation tape is consumed by the first)")
-        model.engine.backward_open(tr, d_mtm, d_mvm, d_vtm, d_smtm if tr["use_smtm"] else None, on_other_grads_ready=getattr(model, "_grad_hook", None))
+        eng = model.engine
+        saved = eng.on_swin_tail_ready
+        eng.on_swin_tail_ready = getattr(model, "_tail_hook", None) or saved
+        try:
+            eng.backward_open(tr, d_mtm, d_mvm, d_vtm, d_smtm if tr["use_smtm"] else None, on_other_grads_ready=getattr(model, "_grad_hook", None))
+        finally:
+            eng.on_swin_tail_ready = saved
         return None, None, None, None, None
 
 
@@ -118,7 +124,8 @@ class VIOLET_Pretrain(torch.nn.Module):
         if hasattr(self, "fc_mvm"):
             self.fc_mvm.__class__ = _MLPHead
         self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)     # (plain attribute: not a parameter, not in state_dict)
-        self._grad_hook = None              # data parallel: dist.GradReducer.reduce_other, set by Agent_Pretrain.prepare_dist_model
+        self._grad_hook = None              # data parallel: dist.GradReducer.reduce_other / reduce_swin_tail, set by Agent_Pretrain.prepare_dist_model
+        self._tail_hook = None
         # relative_position_index buffers (video_swin.py:123-137) for checkpoint key parity
         win = tuple(self.cfg["window"])
         from .swin_index import rc_codes
