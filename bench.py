@@ -172,6 +172,11 @@ def cpu_baseline(size, frames, timeout_s=420):
     return res
 
 
+def K_RELEASES():
+    from pytorch_empirical_mvm_amd import kernels as K
+    return K.RESERVE_RELEASES
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,9 +274,20 @@ def main():
     # step is the same work).  EVERY rank runs it: the step holds the gradient collectives.
     O = min(B, 4)
     Lq = a.frames * (1 + (a.img // 32) ** 2) + 32
+    rccl = None
+    if agent.comm is not None:
+        agent.comm.timing = []
+        c0, w0 = agent.comm.collectives, agent.comm.wire_bytes
     with InStepTimers(B * (1 + O) * Lq) as tm:
         one_step(a.steps)
     torch.cuda.synchronize()
+    if agent.comm is not None:
+        # the exchange of ONE step, for the first run on a real node to check itself against: group / backend as torch.distributed sees
+        # them, channels and CUs left to the collectives, bytes this rank put on the wire, and how long the main stream sat waiting
+        # for the side stream at the end of the backward (0 = the exchange hid under the backward completely)
+        rccl = agent.comm.describe()
+        rccl.update(collectives_per_step=agent.comm.collectives - c0, wire_bytes_per_step=agent.comm.wire_bytes - w0, cu_releases_by_event=K_RELEASES())
+        agent.comm.timing = None
     if rank != 0:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.barrier()
@@ -324,6 +340,7 @@ def main():
                                                        f"{tm.adamw_launches[1]} on the second stream, running side by side; bytes of all of them over the union of their intervals on the device timeline)",
                              "achieved": round(30.0 * adamw_n / adamw_s / 1e9, 1) if adamw_s else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                              "frac": round(30.0 * adamw_n / adamw_s / PEAK_HBM, 4) if adamw_s else None, "algorithmic_bytes": int(30 * adamw_n)}},
+        "rccl": rccl,                                 # None at world size 1 (no reducer is built: Agent_Pretrain.prepare_dist_model)
         "losses_last_step": last,
         "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),      # caching-allocator peak of this rank over the whole run
     }

@@ -40,6 +40,7 @@ class Agent_Pretrain:
             # the autograd-driven step (model(batch) ... loss.backward(), model._OpenStep) starts the same two exchange phases from inside
             # its backward node: the non-Swin groups behind the fusion backward, the Swin tail behind stage n-2
             self.model._grad_hook = self.comm.reduce_other
+            self.model._mid_hook = self.comm.reduce_other_early
             self.model._tail_hook = self.comm.reduce_swin_tail     # (installed on the engine only for the duration of that backward: a bare
             #                                                         engine.forward_backward() -- tools/dp_check.py's per-rank reference -- must not reduce)
             D.broadcast_(self.engine.store.flat)           # identical replicas (DDP broadcasts rank-0 parameters at wrap time)
@@ -220,7 +221,11 @@ class Agent_Pretrain:
         if is_train:
             hook = self.comm.reduce_other if self.comm is not None else None
             eng.on_swin_tail_ready = self.comm.reduce_swin_tail if self.comm is not None else None
-            losses, _ = eng.forward_backward(b, negatives=negatives, train=True, dp_all=dp_all, on_other_grads_ready=hook)
+            eng.on_fusion_mid_ready = self.comm.reduce_other_early if self.comm is not None else None
+            try:
+                losses, _ = eng.forward_backward(b, negatives=negatives, train=True, dp_all=dp_all, on_other_grads_ready=hook)
+            finally:
+                eng.on_fusion_mid_ready = None       # (a bare engine.forward_backward() afterwards must not start an exchange)
             self.backward_step()
             self.global_step += 1
         else:

@@ -193,6 +193,21 @@ def all_reduce_chunks_(flat, a, e):
     return n
 
 
+def _minus(rng, holes):
+    """[a, e) without the (disjoint, sorted or not) ranges in `holes` that lie inside it -> list of ranges"""
+    a, e = rng
+    out, pos = [], a
+    for lo, hi in sorted(holes):
+        if hi <= a or lo >= e:
+            continue
+        if lo > pos:
+            out.append((pos, lo))
+        pos = max(pos, hi)
+    if pos < e:
+        out.append((pos, e))
+    return out
+
+
 class GradReducer:
     """Two-phase gradient all-reduce over the ParamStore arena (segments: 0 swin-decay, 1 other-decay, 2 swin-nodecay,
     3 other-nodecay).  Sums only -- the 1/world average is folded into the AdamW kernel's grad_scale."""
@@ -218,11 +233,58 @@ class GradReducer:
         # whole arena into `world` contiguous shards and needed `world` rooted reduces + `world` broadcasts per phase.
         self.world = dist.get_world_size() if self.zero1 else 1
         self.rank = dist.get_rank() if self.zero1 else 0
+        # Round 6: the non-Swin phase starts IN THE MIDDLE of the fusion backward.  When the backward has left fusion layer `mid` (layers run
+        # last -> 0), the gradients of the heads (fc.*, fc_mtm.*, decoder_*, fc_mvm.*: written before the encoder's backward starts) and of
+        # trsfr.layer.mid .. last are final: ~70 M of the 137 M non-Swin elements at C2 (two contiguous runs of the decay group: layers 6-11
+        # and the heads) leave then and overlap layers 5-0, the rest (layers 0-5, embeddings, the no-decay group) after the encode backward.
+        self.early = self._early_ranges()
+        self.early_done = False
         self.ranges = self._reduction_ranges() if self.zero1 else [(0, store.n_trainable)]
         self.own = self.owned_ranges(self.rank) if self.zero1 else [(0, store.n_trainable)]
         self.wait_streams = []                    # further producer streams (the engine's weight-gradient stream) a reduction must wait for
         self.collectives = 0                      # issued so far (tests / profiling)
         self.wire_bytes = 0
+        self.timing = None                        # list: reduce_swin_and_wait appends an event pair around the main stream's wait for the side stream
+
+    def describe(self):
+        """what the first run on a real multi-GPU node needs to verify itself (bench.py prints it as the line's "rccl" object)"""
+        on = dist.is_available() and dist.is_initialized()
+        waits = [a_.elapsed_time(b_) for a_, b_ in (self.timing or [])]
+        return {"backend": dist.get_backend() if on else None, "world": dist.get_world_size() if on else 1, "wire": self.wire, "zero1": bool(self.zero1),
+                "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "reserved_cus": self.reserve_cus, "cu_release": "end" if self.release_at_end else "event",
+                "collectives_issued": self.collectives, "wire_bytes_issued": self.wire_bytes,
+                "phases": {"other_early": [list(r) for r in self.early], "mid_layer": getattr(self, "mid_layer", None), "swin_tail": [list(r) for r in (self.store.swin_tail or [])]},
+                "main_stream_wait_ms": [round(w, 3) for w in waits]}
+
+    MIN_EARLY = 1 << 20                           # elements: shorter runs are not worth a collective of their own
+
+    def _early_ranges(self):
+        """runs of the non-Swin decay group (segment 1) whose gradients are final when the backward leaves fusion layer n // 2: the
+        heads and trsfr.layer.l for l >= n // 2.  Empty for encoders of fewer than 4 layers (test configurations)."""
+        S = self.store
+        layers = sorted({int(n.split(".")[2]) for n in S.index if n.startswith("trsfr.layer.")})
+        if len(layers) < 4:
+            return []
+        self.mid_layer = mid = layers[len(layers) // 2]
+        a, e = S.segments[1]
+
+        def final(n):
+            if n.startswith("trsfr.layer."):
+                return int(n.split(".")[2]) >= mid
+            return not n.startswith(("enc_img.", "enc_txt.", "trsfr."))          # a head
+        runs, cur = [], None
+        for n, (o, c, _) in S.index.items():          # arena order
+            if not (a <= o < e):
+                continue
+            end = o + -(-c // S.PAD) * S.PAD
+            if final(n):
+                cur = [o, end] if cur is None else [cur[0], end]
+            elif cur is not None:
+                runs.append(tuple(cur))
+                cur = None
+        if cur is not None:
+            runs.append((cur[0], e))
+        return [(lo, hi) for lo, hi in runs if hi - lo >= self.MIN_EARLY]
 
     def _reduction_ranges(self):
         """the disjoint ranges the phases reduce, in arena order (they cover [0, n_trainable))"""
@@ -236,6 +298,8 @@ class GradReducer:
             t = tails.get(e) if gi in (0, 2) else None
             if t is not None and a < t < e:
                 out += [(a, t), (t, e)]
+            elif gi == 1 and self.early:
+                out += _minus((a, e), self.early) + list(self.early)
             else:
                 out.append((a, e))
         return sorted(out)
@@ -336,11 +400,25 @@ class GradReducer:
             for a, e in ranges:
                 self._reduce_range(a, e)
 
+    def reduce_other_early(self):
+        """called by the engine when the backward has left fusion layer n // 2 (engine_fusion.go_cross `mid_hook`): the heads and
+        the upper half of the fusion layers leave now and overlap the lower half's backward"""
+        if not is_initialized() or not self.early:
+            return
+        self._side(list(self.early))
+        self.early_done = True
+
     def reduce_other(self):
-        """called by the engine right after the last non-Swin gradient has been written"""
+        """called by the engine right after the last non-Swin gradient has been written: everything of the two non-Swin groups that
+        `reduce_other_early` has not already sent"""
         if not is_initialized():
             return
-        self._side([self.store.segments[gi] for gi in (1, 3)])
+        done = self.early if self.early_done else []
+        self.early_done = False
+        rest = []
+        for gi in (1, 3):
+            rest += _minus(self.store.segments[gi], done)
+        self._side(rest)
 
     def reduce_swin_tail(self):
         """called by the engine when the backward leaves Swin stage n-2: stages >= n-2 (+ final norm) are final; their sum
@@ -361,7 +439,14 @@ class GradReducer:
                 self._reduce_range(a, split)      # nothing left to overlap with: on the main stream
         self.tail_done = False
         if self.cuda and self.pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            if self.timing is not None:           # (bench.py's instrumented step: how long did the main stream sit in this wait?)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                torch.cuda.current_stream().wait_stream(self.stream)
+                e1.record()
+                self.timing.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self.stream)
             self.pending = False
         if self.cuda and self.reserve_cus > 0:
             from . import kernels as K

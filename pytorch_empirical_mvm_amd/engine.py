@@ -44,6 +44,7 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         self.teacher = None                 # frozen dVAE tokenizer (MVM 'vq' target), set by the model
         self.feature_teacher = None         # frozen Swin teacher (MVM '3d_feature' / '2d_feature' targets), set by the model
         self.on_swin_tail_ready = None      # data-parallel hook (dist.GradReducer.reduce_swin_tail)
+        self.on_fusion_mid_ready = None     # data-parallel hook (dist.GradReducer.reduce_other_early): the backward has left fusion layer n // 2
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
         # (BASELINE config 5's "fp8 MFMA path": rounds 1-4 carried an opt-in e4m3 forward for the fusion qkv / FFN-in GEMMs; it never
         # moved that config's number -- 21.8 vs 22.0 clips/s, 58 % of the step is streaming attention -- and was removed in round 5,

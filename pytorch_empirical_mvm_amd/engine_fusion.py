@@ -194,7 +194,7 @@ class FusionMixin:
         self.tape.append(bwd)
         return out
 
-    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0, att_out=None, qrow_split=None):
+    def go_cross(self, pool, idx, keymask, nseq, Lq, train, causal_from=0, att_out=None, qrow_split=None, mid_hook=False):
         """gather the [img;txt] sequences from the token pool and run the 12 fusion layers (model.py:204-214).
         causal_from = Lv: the seq2seq mask of the smtm pass (main_pretrain.py:217-224, model.py:191-199)."""
         Hd = self.cfg["hidden"]
@@ -203,6 +203,10 @@ class FusionMixin:
         cur = xv
         nl = self.cfg["bert_layers"]
         for l in range(nl - 1 if qrow_split is not None else nl):
+            if mid_hook and nl >= 4 and l == nl // 2:
+                # a closure pushed BEFORE layer nl // 2 runs right AFTER that layer's backward: the gradients of layers nl // 2 .. nl - 1
+                # (and of the heads) are final there -- data parallel: their exchange starts now (dist.GradReducer.reduce_other_early)
+                self.tape.append(lambda: self.on_fusion_mid_ready() if self.on_fusion_mid_ready is not None else None)
             cur = self._bert_layer(cur, nseq, Lq, keymask, l, train, causal_from, att_out)
         if qrow_split is None:
             return cur, xv, idx

@@ -126,11 +126,11 @@ class HeadsMixin:
         qrow = self.sw.qrow                             # (0: the whole last layer for every sequence, for A/B runs)
         out12 = cls_rows = None
         if qrow:
-            (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), qrow_split=(n1, Lv))
+            (out1, out2c), in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), qrow_split=(n1, Lv), mid_hook=True)
             if backward:
                 out1.g = torch.empty_like(out1.t)                                  # the heads write it in place
         else:
-            out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train))
+            out12, in12, _ = self.go_cross(pool, idx12_d, km12, n1 + n2, Lq, self._drop_on("fusion", train), mid_hook=True)
             cls_rows = self._cached(("cls_rows", B * O, Lq, Lv), lambda: _dev_i32(np.arange(B * O) * Lq + Lv, dev))
             out1, out2c = V(out12.t[:n1 * Lq]), V(K.gather_rows(out12.t[n1 * Lq:], cls_rows, n2))
             if backward:

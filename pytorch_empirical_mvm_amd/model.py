@@ -60,12 +60,13 @@ class _OpenStep(torch.autograd.Function):
         if tr is None:
             raise RuntimeError("VIOLET_Pretrain: backward through one forward twice (the activation tape is consumed by the first)")
         eng = model.engine
-        saved = eng.on_swin_tail_ready
-        eng.on_swin_tail_ready = getattr(model, "_tail_hook", None) or saved
+        saved = eng.on_swin_tail_ready, eng.on_fusion_mid_ready
+        eng.on_swin_tail_ready = getattr(model, "_tail_hook", None) or saved[0]
+        eng.on_fusion_mid_ready = getattr(model, "_mid_hook", None) or saved[1]
         try:
             eng.backward_open(tr, d_mtm, d_mvm, d_vtm, d_smtm if tr["use_smtm"] else None, on_other_grads_ready=getattr(model, "_grad_hook", None))
         finally:
-            eng.on_swin_tail_ready = saved
+            eng.on_swin_tail_ready, eng.on_fusion_mid_ready = saved
         return None, None, None, None, None
 
 
@@ -126,6 +127,7 @@ class VIOLET_Pretrain(torch.nn.Module):
         self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)     # (plain attribute: not a parameter, not in state_dict)
         self._grad_hook = None              # data parallel: dist.GradReducer.reduce_other / reduce_swin_tail, set by Agent_Pretrain.prepare_dist_model
         self._tail_hook = None
+        self._mid_hook = None
         # relative_position_index buffers (video_swin.py:123-137) for checkpoint key parity
         win = tuple(self.cfg["window"])
         from .swin_index import rc_codes

@@ -282,3 +282,76 @@ def test_chunked_reduce_scatter_and_all_gather_ranges_world2_gloo():
     for p in ps:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _worker_early(rank, world, port, q, zero1):
+    """Round 6: the non-Swin phase starts in the middle of the fusion backward -- `reduce_other_early` sends the
+    heads and the upper half of the fusion layers, `reduce_other` the rest.  4 fusion layers: layers 2-3 + the heads are early.  Every
+    trainable element must be reduced exactly once whichever hooks fire (early + late, or late alone), in both the all-reduce and the
+    ZeRO-1 (reduce-scatter) shapes, and the ZeRO-1 ownership ranges must follow the finer reduction ranges."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VMVM_GRAD_WIRE="f32",
+                      VMVM_ZERO1="1" if zero1 else "0")
+    from pytorch_empirical_mvm_amd import config as CFG
+    from pytorch_empirical_mvm_amd import dist as D
+    from pytorch_empirical_mvm_amd.engine import ParamStore
+    D.init_from_env("gloo")
+    args = CFG.get_args(vis_backbone_size="tiny", arch_override=dict(embed_dim=32, depths=(1, 1, 1, 1), num_heads=(1, 2, 4, 8), window=(8, 7, 7)), bert_layers=4)
+    S = ParamStore(CFG.param_shapes(CFG.model_cfg(args)), torch.device("cpu"))
+    gens = [torch.randn(S.total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    want = sum(gens)
+    red = D.GradReducer(S, "cpu")
+    ok = bool(red.zero1 == zero1)
+    # the early runs: inside the non-Swin decay group, made of the heads and trsfr.layer.2-3 only, and large
+    a1, e1 = S.segments[1]
+    ok &= len(red.early) >= 1 and all(a1 <= lo < hi <= e1 and hi - lo >= red.MIN_EARLY for lo, hi in red.early) and red.mid_layer == 2
+    for n, (o, c, _) in S.index.items():
+        inside = any(lo <= o < hi for lo, hi in red.early)
+        if n.startswith(("trsfr.layer.0.", "trsfr.layer.1.", "enc_txt.", "enc_img.")):
+            ok &= not inside
+        if a1 <= o < e1 and n.startswith(("trsfr.layer.2.", "trsfr.layer.3.", "fc_mtm.predictions.decoder.weight")):
+            ok &= inside
+    if zero1:                                            # ownership: disjoint, covering, never cutting through a phase boundary
+        cover = torch.zeros(S.n_trainable, dtype=torch.int32)
+        for r_ in range(world):
+            for lo, hi in red.owned_ranges(r_):
+                cover[lo:hi] += 1
+        ok &= bool((cover == 1).all())
+    for mode in ("early+late", "late only"):
+        S.grad[:S.total].copy_(gens[rank])
+        n0 = red.collectives
+        if mode == "early+late":
+            red.reduce_other_early()
+            mid = S.grad[:S.total].clone()               # the early runs are summed (on their owners), nothing else has moved
+            for lo, hi in red.early:
+                for olo, ohi in (red.own if zero1 else [(lo, hi)]):
+                    x, y = max(lo, olo), min(hi, ohi)
+                    if y > x:
+                        ok &= bool(torch.allclose(mid[x:y], want[x:y], atol=1e-5))
+            rest = D._minus((0, S.n_trainable), red.early)
+            ok &= all(bool(torch.equal(mid[lo:hi], gens[rank][lo:hi])) for lo, hi in rest)
+        red.reduce_other()
+        red.reduce_swin_tail()
+        red.reduce_swin_and_wait()
+        got = S.grad[:S.n_trainable]
+        for lo, hi in (red.own if zero1 else [(0, S.n_trainable)]):
+            ok &= bool(torch.allclose(got[lo:hi], want[lo:hi], atol=1e-5))
+        ok &= bool(torch.equal(S.grad[S.n_trainable:S.total], gens[rank][S.n_trainable:S.total]))       # the frozen segment is left alone
+        ok &= red.collectives > n0 and not red.early_done
+    q.put((rank, bool(ok)))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("zero1", [False, True], ids=["allreduce", "zero1"])
+@pytest.mark.timeout(300)
+def test_non_swin_phase_starts_mid_fusion_backward_world2_gloo(zero1):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_early, args=(r, world, port, q, zero1)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

@@ -48,6 +48,12 @@ def test_bench_contract_two_ranks():
     assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak" and o["config"]["global_batch"] == 8
     assert o["value"] > 0 and abs(o["value"] - 8 * 2 / (o["ms_per_step"] * 2 / 1e3)) < 1e-2 * o["value"]
     assert "cpu_baseline" not in o and o["roofline"]["frac"] > 0
+    # round 6: the line describes its own exchange (what the first run on a real node checks itself against)
+    r = o["rccl"]
+    assert r["world"] == 2 and r["backend"] and r["wire"] in ("bf16", "f32") and r["collectives_per_step"] >= 3
+    n_train = sum(e - a for a, e in r["phases"]["other_early"])            # (12 fusion layers: the early non-Swin phase exists)
+    assert n_train > 0 and r["phases"]["mid_layer"] == 6 and r["phases"]["swin_tail"]
+    assert r["wire_bytes_per_step"] > 0 and len(r["main_stream_wait_ms"]) == 1 and r["main_stream_wait_ms"][0] >= 0.0
 
 
 @pytest.mark.timeout(900)
