@@ -329,10 +329,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const size_t slab = (size_t)M * N;
   const int per = (S + gridDim.y - 1) / gridDim.y;
   const int s0 = blockIdx.y * per, s1 = (s0 + per < S) ? s0 + per : S;
+  // Round 6: the slabs are read ONCE (non-temporal) and four at a time -- the loop body used to be one dependent load-add per slab, so a
+  // thread had 16 bytes in flight; the sum order stays s0, s0 + 1, ... (same bits as before).
+  typedef float v4f __attribute__((ext_vector_type(4)));
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = s0; s < s1; ++s) {
-    const float4 v = *reinterpret_cast<const float4*>(ws + s * slab + m * N + c);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  const float* src = ws + m * N + c;
+  int s = s0;
+  for (; s + 4 <= s1; s += 4) {
+    v4f v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)(s + u) * slab));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3]; }
+  }
+  for (; s < s1; ++s) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)s * slab));
+    a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3];
   }
   float* o = C + m * ldc + c;
   if (gridDim.y == 1) {

@@ -476,34 +476,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
 
 // ---------------------------------------------------------------- batched bf16 transpose (W [N][K] -> W^T [K][N])
 // One launch transposes every 2-D weight of the arena: table[tile] = {offset, N, K, tile_row*65536 + tile_col}.
-__global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __restrict__ src, u16* __restrict__ dst, const int4* __restrict__ table) {
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const u16* __restrict__ src, u16* __restrict__ dst, const int4* __restrict__ table, const int ntiles) {
   // 64x64 tile through LDS as 32-bit words holding 2x2 sub-blocks: a thread transposes 2x2 in registers, so both the
   // LDS writes and reads are conflict-free 32-bit accesses and global accesses stay 16-byte.
-  __shared__ uint32_t t[64][33];                       // [row][col pair], +1 pad
-  const int4 e = table[blockIdx.x];
-  const long off = e.x; const int N = e.y, K = e.z, tr = e.w >> 16, tc = e.w & 0xffff;
-  const int r0 = tr * 64, c0 = tc * 64;
+  // Round 6: a RESIDENT grid walking the tile table (two LDS tiles: the next tile's loads are issued before this tile's stores).  One
+  // workgroup per 8-KiB tile was 55 000 workgroups for the arena's 450 MB: 0.93 ms = 0.97 TB/s, bound by workgroup dispatch, not by HBM.
+  __shared__ uint32_t t[2][64][33];                    // [buffer][row][col pair], +1 pad
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  auto load = [&](int tile, uint4 (&v)[2]) __attribute__((always_inline)) {
+    const int4 e = table[tile];
+    const long off = e.x; const int N = e.y, K = e.z, r0 = (e.w >> 16) * 64, c0 = (e.w & 0xffff) * 64;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + row < N && c0 + ch * 8 < K) v = *reinterpret_cast<const uint4*>(src + off + (long)(r0 + row) * K + c0 + ch * 8);
-    t[row][ch * 4 + 0] = v.x; t[row][ch * 4 + 1] = v.y; t[row][ch * 4 + 2] = v.z; t[row][ch * 4 + 3] = v.w;
-  }
-  __syncthreads();
-  // output row = source column c (0..63), 8 consecutive source rows per 16-byte store
+    for (int i = 0; i < 2; ++i) {
+      const int row = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (r0 + row < N && c0 + ch * 8 < K) {
+        const v4u x = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + off + (long)(r0 + row) * K + c0 + ch * 8));
+        v[i] = make_uint4(x[0], x[1], x[2], x[3]);
+      }
+    }
+  };
+  uint4 v[2];
+  int tile = blockIdx.x, buf = 0;
+  if (tile < ntiles) load(tile, v);
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int col = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;        // 8 lanes write one 128-byte row segment
-    if (c0 + col < K && r0 + ch * 8 < N) {
-      uint32_t w[8];
+    for (int i = 0; i < 2; ++i) {
+      const int row = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;
+      t[buf][row][ch * 4 + 0] = v[i].x; t[buf][row][ch * 4 + 1] = v[i].y; t[buf][row][ch * 4 + 2] = v[i].z; t[buf][row][ch * 4 + 3] = v[i].w;
+    }
+    __syncthreads();                                   // (one barrier per tile: the other buffer was last read two iterations ago, behind the previous barrier)
+    const int4 e = table[tile];
+    const long off = e.x; const int N = e.y, K = e.z, r0 = (e.w >> 16) * 64, c0 = (e.w & 0xffff) * 64;
+    if (tile + (int)gridDim.x < ntiles) load(tile + gridDim.x, v);
+    // output row = source column c (0..63), 8 consecutive source rows per 16-byte store
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = t[ch * 8 + k][col >> 1];
-      const int sh = (col & 1) * 16;
-      uint32_t o[4];
+    for (int i = 0; i < 2; ++i) {
+      const int col = (threadIdx.x >> 3) + 32 * i, ch = threadIdx.x & 7;        // 8 lanes write one 128-byte row segment
+      if (c0 + col < K && r0 + ch * 8 < N) {
+        uint32_t w[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = ((w[2 * k] >> sh) & 0xffffu) | (((w[2 * k + 1] >> sh) & 0xffffu) << 16);
-      *reinterpret_cast<uint4*>(dst + off + (long)(c0 + col) * N + r0 + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int k = 0; k < 8; ++k) w[k] = t[buf][ch * 8 + k][col >> 1];
+        const int sh = (col & 1) * 16;
+        v4u o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ((w[2 * k] >> sh) & 0xffffu) | (((w[2 * k + 1] >> sh) & 0xffffu) << 16);
+        *reinterpret_cast<v4u*>(dst + off + (long)(c0 + col) * N + r0 + ch * 8) = o;
+      }
     }
   }
 }
@@ -694,6 +713,9 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
   s = block_sum(s, sh);
   if (threadIdx.x == 0) *out += s;
 }
+// U = float4 groups per thread and iteration (all of their loads are issued before the first use), NT = non-temporal loads / stores
+// (every byte is touched once per step: nothing of it is worth a cache line)
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(const vmvm_adamw_desc d) {
   float coef = d.grad_scale;
   if (d.max_grad_norm > 0.f && d.sumsq) {
@@ -704,33 +726,54 @@ __global__ __launch_bounds__(256) void adamw_kernel(const vmvm_adamw_desc d) {
   const float step_size = d.lr / d.bias_corr1;
   const float inv_sqrt_bc2 = rsqrtf(d.bias_corr2);
   u16* pb = reinterpret_cast<u16*>(d.param_bf16);
-  const long stride = (long)gridDim.x * 256 * 4;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < d.n; i += stride) {
-    const int cnt = (int)((d.n - i) < 4 ? (d.n - i) : 4);
-    float p[4], g[4], m[4], v[4];
-    if (cnt == 4) {
-      const float4 p4 = *reinterpret_cast<const float4*>(d.param + i), g4 = *reinterpret_cast<const float4*>(d.grad + i);
-      const float4 m4 = *reinterpret_cast<const float4*>(d.m + i), v4 = *reinterpret_cast<const float4*>(d.v + i);
-      p[0] = p4.x; p[1] = p4.y; p[2] = p4.z; p[3] = p4.w; g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-      m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w; v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
-    } else {
-      for (int e = 0; e < cnt; ++e) { p[e] = d.param[i + e]; g[e] = d.grad[i + e]; m[e] = d.m[i + e]; v[e] = d.v[i + e]; }
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  auto ld4 = [](const float* q) __attribute__((always_inline)) {
+    const v4f x = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(q)) : *reinterpret_cast<const v4f*>(q);
+    return make_float4(x[0], x[1], x[2], x[3]);
+  };
+  auto st4 = [](float* q, float4 x) __attribute__((always_inline)) {
+    const v4f y = {x.x, x.y, x.z, x.w};
+    if (NT) __builtin_nontemporal_store(y, reinterpret_cast<v4f*>(q)); else *reinterpret_cast<v4f*>(q) = y;
+  };
+  auto upd = [&](float& p, float g, float& m, float& v) __attribute__((always_inline)) {
+    const float gg = g * coef;
+    p *= decay;
+    m = d.beta1 * m + (1.f - d.beta1) * gg;
+    v = d.beta2 * v + (1.f - d.beta2) * gg * gg;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + d.eps;
+    p -= step_size * m / denom;
+  };
+  const long chunk = (long)256 * 4;                       // elements one workgroup covers per group: a wave's loads are 1 KiB contiguous
+  const long stride = (long)gridDim.x * chunk * U;
+  for (long base = (long)blockIdx.x * chunk * U + (long)threadIdx.x * 4; base < d.n; base += stride) {
+    float4 p4[U], g4[U], m4[U], v4[U];
+    bool full[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * chunk;
+      full[u] = i + 4 <= d.n;
+      if (full[u]) { p4[u] = ld4(d.param + i); g4[u] = ld4(d.grad + i); m4[u] = ld4(d.m + i); v4[u] = ld4(d.v + i); }
     }
-    for (int e = 0; e < cnt; ++e) {
-      const float gg = g[e] * coef;
-      p[e] *= decay;
-      m[e] = d.beta1 * m[e] + (1.f - d.beta1) * gg;
-      v[e] = d.beta2 * v[e] + (1.f - d.beta2) * gg * gg;
-      const float denom = sqrtf(v[e]) * inv_sqrt_bc2 + d.eps;
-      p[e] -= step_size * m[e] / denom;
-    }
-    if (cnt == 4) {
-      *reinterpret_cast<float4*>(d.param + i) = make_float4(p[0], p[1], p[2], p[3]);
-      *reinterpret_cast<float4*>(d.m + i) = make_float4(m[0], m[1], m[2], m[3]);
-      *reinterpret_cast<float4*>(d.v + i) = make_float4(v[0], v[1], v[2], v[3]);
-      if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3]));
-    } else {
-      for (int e = 0; e < cnt; ++e) { d.param[i + e] = p[e]; d.m[i + e] = m[e]; d.v[i + e] = v[e]; if (pb) pb[i + e] = f2bf(p[e]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * chunk;
+      if (full[u]) {
+        upd(p4[u].x, g4[u].x, m4[u].x, v4[u].x); upd(p4[u].y, g4[u].y, m4[u].y, v4[u].y);
+        upd(p4[u].z, g4[u].z, m4[u].z, v4[u].z); upd(p4[u].w, g4[u].w, m4[u].w, v4[u].w);
+        st4(d.param + i, p4[u]); st4(d.m + i, m4[u]); st4(d.v + i, v4[u]);
+        if (pb) {
+          const v2u b2 = {pack_bf2(p4[u].x, p4[u].y), pack_bf2(p4[u].z, p4[u].w)};
+          if (NT) __builtin_nontemporal_store(b2, reinterpret_cast<v2u*>(pb + i)); else *reinterpret_cast<v2u*>(pb + i) = b2;
+        }
+      } else if (i < d.n) {                                // the arena's last partial group (n % 4 != 0)
+        for (long e = i; e < d.n; ++e) {
+          float p = d.param[e], m = d.m[e], v = d.v[e];
+          upd(p, d.grad[e], m, v);
+          d.param[e] = p; d.m[e] = m; d.v[e] = v;
+          if (pb) pb[e] = f2bf(p);
+        }
+      }
     }
   }
 }
@@ -1022,8 +1065,9 @@ int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float s
 }
 extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream) {
   if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst),
-                     reinterpret_cast<const int4*>(table));
+  const int grid = ntiles < 256 * 8 ? ntiles : 256 * 8;       // 8 workgroups per CU (17 KiB of LDS, 256 threads each)
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(grid), dim3(256), 0, ST, reinterpret_cast<const u16*>(src), reinterpret_cast<u16*>(dst),
+                     reinterpret_cast<const int4*>(table), ntiles);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -1098,9 +1142,14 @@ extern "C" int vmvm_sumsq_f32(const float* g, int64_t n, float* out_accum, void*
 }
 extern "C" int vmvm_adamw(const vmvm_adamw_desc* d, void* stream) {
   if (!d || !d->param || !d->grad || !d->m || !d->v || d->n <= 0) return VMVM_EINVAL;
-  int grid = nblk((d->n + 3) / 4, 256);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, *d);
+  // Round 6: EIGHT float4 groups per thread and iteration (32 loads in flight per thread before the first use) and non-temporal loads /
+  // stores -- every byte is touched once per step.  Measured on two boxes (tools/scratch/bench_adamw.py, 197 M elements, 30 B each):
+  // U = 1 cached 4.65 TB/s (rounds 1-5), U = 1 nt 4.87, U = 2 nt 4.93, U = 4 nt 5.27-5.64, U = 8 nt 5.41-5.49, U = 6 nt 4.73 (an odd
+  // group count leaves the workgroups' chunks mis-aligned to the 8-KiB interleave).
+  constexpr int U = 8;
+  int grid = nblk((d->n + 3) / 4, 256 * U);
+  if (grid > 4096 / U) grid = 4096 / U;
+  hipLaunchKernelGGL((adamw_kernel<U, true>), dim3(grid), dim3(256), 0, ST, *d);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }

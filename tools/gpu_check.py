@@ -1282,6 +1282,16 @@ def check_misc():
     K.transpose_batched(src, dstT, torch.tensor(ents, dtype=torch.int32, device=dev))
     rep("transpose_batched 64x64", dstT[:4096].view(64, 64), src[:4096].view(64, 64).t(), tol=0)
     rep("transpose_batched 200x136", dstT[4096:4096 + 200 * 136].view(136, 200), src[4096:4096 + 200 * 136].view(200, 136).t(), tol=0)
+    # (round 6: the kernel is a resident grid of 2 048 workgroups walking the tile table through two LDS buffers: MORE tiles than workgroups)
+    Nb, Kb = 3000, 3016
+    srcb = rnd(Nb * Kb + 1000 * 72)
+    dstb = torch.zeros_like(srcb)
+    ents = [(0, Nb, Kb, (tr << 16) | tc) for tr in range(-(-Nb // 64)) for tc in range(-(-Kb // 64))]
+    ents += [(Nb * Kb, 1000, 72, (tr << 16) | tc) for tr in range(-(-1000 // 64)) for tc in range(2)]
+    assert len(ents) > 2048 * 1.05
+    K.transpose_batched(srcb, dstb, torch.tensor(ents, dtype=torch.int32, device=dev))
+    rep("transpose_batched 3000x3016 (tiles > resident grid)", dstb[:Nb * Kb].view(Kb, Nb), srcb[:Nb * Kb].view(Nb, Kb).t(), tol=0)
+    rep("transpose_batched 1000x72 behind it", dstb[Nb * Kb:].view(72, 1000), srcb[Nb * Kb:].view(1000, 72).t(), tol=0)
     # optimizer
     n = 100003
     p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 3

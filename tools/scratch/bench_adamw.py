@@ -1,4 +1,6 @@
 """standalone rate of vmvm_adamw / vmvm_sumsq_f32 / the gradient zero-fill on arenas of the step's sizes (Swin-B part 88 M, whole model 197 M f32)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pytorch_empirical_mvm_amd import kernels as K
 dev = torch.device("cuda:0")
