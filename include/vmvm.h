@@ -134,6 +134,11 @@ int vmvm_argmax_pairs(const float* pairs, int32_t ld, int32_t M, int32_t groups,
 /* column sums  out[n] (+)= sum_m scale[m/rows_per_scale] * X[m,n]   (bias gradients)  X bf16 [M][ldx], out f32 */
 int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale,
                      int32_t rows_per_scale, float* out, int32_t accumulate, void* stream);
+/* the same with caller-owned scratch (vmvm_colsum_workspace_size bytes): the row-block partial sums are stored and added in a fixed
+ * order by a second small kernel instead of one f32 atomic per (row block, column) -- run-to-run reproducible (round 6) */
+int vmvm_colsum_bf16_ws(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
+                        int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t vmvm_colsum_workspace_size(int32_t M, int32_t N);
 
 /* ------------------------------------------------------------------------------------------
  * Gather-LayerNorm.  Output row m (width C = nseg*Cseg) = LN( concat_s  X[src[m*nseg+s], 0:Cseg] ).
@@ -243,7 +248,17 @@ typedef struct {
    * score tile is then four 8 x 8 Toeplitz blocks (one 16-byte LDS read per lane and tile from a windowed copy of the head's table
    * column instead of a register-resident bias block per wave), every tile lies in one mask region of every window, and the
    * (query tile, key tile) pairs the shift mask (video_swin.py:292-307) zeroes are skipped.  `region` must be tile-uniform (checked on
-   * the host side by the caller); kernels without a win_layout build ignore the flag (they are order-agnostic). */
+   * the host side by the caller); kernels without a win_layout build ignore the flag (they are order-agnostic).
+   * MASK SEMANTICS.  The reference ADDS -100 to the logit of a cross-region pair (video_swin.py:304-306); these kernels give such a
+   * pair probability exactly 0.  The two are the same function while exp(s_masked - 100 - max_live) is below the resolution of the
+   * row's f32 sum -- i.e. as long as no masked RAW logit exceeds the row's largest live logit by more than ~83 (100 - ln 2^24).  Beyond
+   * that the reference itself leaks attention across the shift mask (an artefact of its finite constant); this library does not
+   * reproduce the leak.  tools/gpu_check.py check_attn_window_mask_boundary pins the equality with masked logits 34 above the live
+   * maximum; a trained network's cross-region logits sit within a few units of its live ones.
+   * SOFTMAX REFERENCE.  The forward walks the keys once against a fixed reference (the row maximum of the first live key block) and
+   * repeats a sequence with the exact row maxima when the row sum comes out above 2^125 or anything is non-finite (a later logit more
+   * than ~86 above the first block's): results are those of the exact softmax at any logit scale; a NaN / inf input poisons its own
+   * rows only and the retry runs once (check_attn_window_spike, check_attn_window_nonfinite). */
   int32_t win_layout;
   /* mode 1, dropout_p > 0, L = 432 (the fusion encoder's exact-tile kernels; no causal_from, att_colsum, streaming), NULL = off: the
    * forward WRITES its keep / drop decisions here and the backward READS them instead of evaluating the Philox stream twice more.
@@ -261,11 +276,17 @@ typedef struct {
   vmvm_attn_fwd_desc f;        /* same problem description (out = forward output O, lse = saved) */
   const void* dout; int32_t ld_dout;   /* bf16 [nseq*L][ld_dout] */
   void* dqkv; int32_t ld_dqkv;         /* bf16, same column layout as qkv */
-  float* dbias_table;                  /* mode 0: f32 [table_len][heads], ACCUMULATED (atomics) */
+  float* dbias_table;                  /* mode 0: f32 [table_len][heads], ACCUMULATED (atomics unless dbias_ws is given, below) */
   float* delta;                        /* workspace f32 [nseq][heads][L] */
+  /* optional scratch for a REPRODUCIBLE table gradient (round 6; win_layout = 1 kernels, i.e. the (8,7,7) windows of C2-C4): every
+   * workgroup of the dQ kernel leaves its partial table here (no global atomics; inside the workgroup the waves add their running sums
+   * one after the other), and a second small kernel sums the partial tables of a head in a fixed order.  Size:
+   * vmvm_attention_bwd_dbias_ws_size().  NULL / too small / another kernel family: f32 atomics, run-to-run differences in the last bits. */
+  void* dbias_ws; int64_t dbias_ws_bytes;
 } vmvm_attn_bwd_desc;
 int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
 int64_t vmvm_attention_bwd_workspace_size(const vmvm_attn_bwd_desc* d); /* bytes of the `delta` scratch */
+int64_t vmvm_attention_bwd_dbias_ws_size(const vmvm_attn_bwd_desc* d);  /* bytes of `dbias_ws` (0: this problem has no reproducible build) */
 
 /* ------------------------------------------------------------------------------------------
  * Small fused kernels

@@ -2343,6 +2343,7 @@ bool applicable(const vmvm_attn_fwd_desc* d);
 int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_dq(const vmvm_attn_bwd_desc* d, hipStream_t st);
 int launch_fwd(const vmvm_attn_fwd_desc* d, hipStream_t st);
+int64_t dbias_ws_size(const vmvm_attn_bwd_desc* d);
 }  // namespace vmvm_w3
 // key-blocked win_layout = 1 kernels (attention_win4.hip, round 5): the same problems as vmvm_w3::applicable
 namespace vmvm_w4 {
@@ -2647,6 +2648,13 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
 extern "C" int64_t vmvm_attention_drop_mask_size(const vmvm_attn_fwd_desc* d) {
   if (!d || !drop_mask_ok(d)) return 0;
   return (int64_t)d->nseq * d->heads * 27 * 27 * 8 * 4;
+}
+
+// scratch of the reproducible table gradient (vmvm_attn_bwd_desc.dbias_ws): one partial table per workgroup of the win_layout = 1 dQ kernel
+extern "C" int64_t vmvm_attention_bwd_dbias_ws_size(const vmvm_attn_bwd_desc* d) {
+  if (!d || d->f.nseq <= 0 || d->f.heads <= 0 || d->f.L <= 0) return VMVM_EINVAL;
+  if (d->f.mode != 0 || !d->f.win_layout || !vmvm_w3::applicable(&d->f) || w3_off(0)) return 0;
+  return vmvm_w3::dbias_ws_size(d);
 }
 
 // `delta` scratch of the backward (f32 [nseq][heads][L])

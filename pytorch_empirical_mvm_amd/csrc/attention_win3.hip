@@ -20,6 +20,7 @@
 
 namespace {
 
+constexpr int W3_DTAB = 2560;                        // floats per workgroup slot of vmvm_attn_bwd_desc.dbias_ws (15 * 169 = 2 535, padded)
 template <int V> struct IC { static constexpr int value = V; };
 
 // ================================================================================================
@@ -614,7 +615,12 @@ __global__ __launch_bounds__(4 * NS * 64) void attn_bwd_dq_win3_kernel(const vmv
     __syncthreads();
     for (int i = tid; i < 15 * 169; i += NWV * 64) dtab[i] = 0.f;
     __syncthreads();
-    if (qv) {
+    // Reproducible form (pb.dbias_ws): the waves scatter ONE AFTER THE OTHER (NWV barriers, once per workgroup: the order of the f32
+    // adds into an LDS entry is then fixed -- inside one ds_add instruction colliding lanes are served in lane order) and the table goes
+    // to this workgroup's slot of the scratch instead of global atomics; w3_dbias_reduce_kernel sums a head's slots in order.
+    const bool det = pb.dbias_ws != nullptr;
+    for (int turn = 0; turn < (det ? NWV : 1); ++turn) {
+    if (qv && (!det || wave == turn)) {
       auto scatter = [&](auto khc) {
         constexpr int KH = decltype(khc)::value;
         constexpr w3::TileList KL = w3::list_part(15, KH, NS);
@@ -634,11 +640,27 @@ __global__ __launch_bounds__(4 * NS * 64) void attn_bwd_dq_win3_kernel(const vmv
       if (kh == 0) scatter(IC<0>{}); else if (NS == 2 || kh == 1) scatter(IC<1>{}); else scatter(IC<NS - 1>{});
     }
     __syncthreads();
-    for (int i = tid; i < 15 * 169; i += NWV * 64) {
-      const float v = dtab[i];
-      if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+    }
+    if (det) {
+      float* slot = reinterpret_cast<float*>(pb.dbias_ws) + (size_t)logical * W3_DTAB;          // logical = h * (nch * nqg) + (ch * nqg + qg)
+      for (int i = tid; i < 15 * 169; i += NWV * 64) slot[i] = dtab[i];
+    } else {
+      for (int i = tid; i < 15 * 169; i += NWV * 64) {
+        const float v = dtab[i];
+        if (v != 0.f) atomicAdd(pb.dbias_table + (size_t)i * heads + h, v);
+      }
     }
   }
+}
+
+// dbias_table[i][h] += sum over the per workgroups of head h of their partial tables, in slot order (the reproducible form above)
+__global__ __launch_bounds__(256) void w3_dbias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias_table, const int heads, const int per) {
+  const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (i >= 15 * 169) return;
+  const float* src = ws + (size_t)h * per * W3_DTAB + i;
+  float t = 0.f;
+  for (int s = 0; s < per; ++s) t += src[(size_t)s * W3_DTAB];
+  dbias_table[(size_t)i * heads + h] += t;
 }
 
 // ================================================================================================
@@ -911,9 +933,26 @@ __attribute__((visibility("hidden"))) int launch_dq(const vmvm_attn_bwd_desc* d,
     if (rc_) return rc_;                                                                                             \
     hipLaunchKernelGGL((attn_bwd_dq_win3_kernel<MASK, NS_>), dim3(base * nch), dim3(4 * NS_ * 64), smem, st, *d, nqg, nch); \
   } while (0)
+  vmvm_attn_bwd_desc dd = *d;
+  const int64_t need = (int64_t)base * nch * W3_DTAB * (int64_t)sizeof(float);
+  if (!dd.dbias_table || !dd.dbias_ws || dd.dbias_ws_bytes < need) dd.dbias_ws = nullptr;      // (atomics)
+  d = &dd;
   if (mask) W3_LAUNCH_DQ(true, 2); else W3_LAUNCH_DQ(false, 2);
   VMVM_CHECK_LAUNCH();
+  if (dd.dbias_ws) {
+    hipLaunchKernelGGL(w3_dbias_reduce_kernel, dim3((15 * 169 + 255) / 256, dd.f.heads), dim3(256), 0, st, reinterpret_cast<const float*>(dd.dbias_ws), dd.dbias_table,
+                       dd.f.heads, nqg * nch);
+    VMVM_CHECK_LAUNCH();
+  }
   return VMVM_OK;
+}
+
+// bytes of vmvm_attn_bwd_desc.dbias_ws for this problem (same plan as launch_dq)
+__attribute__((visibility("hidden"))) int64_t dbias_ws_size(const vmvm_attn_bwd_desc* d) {
+  const int nqg = 7, base = d->f.heads * nqg;
+  const int nwin = d->f.n_win > 0 ? d->f.n_win : 1;
+  const int nch = w3_chunks(base, d->f.nseq / nwin, nwin, 10.f);
+  return (int64_t)base * nch * W3_DTAB * (int64_t)sizeof(float);
 }
 
 __attribute__((visibility("hidden"))) int launch_dkv(const vmvm_attn_bwd_desc* d, hipStream_t st) {

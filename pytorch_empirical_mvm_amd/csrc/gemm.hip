@@ -16,7 +16,7 @@
 #include <vmvm_probe_hooks.h>
 #include "gemm_epi.h"
 
-int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* stream);      // misc.hip
+int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* ws, int64_t ws_bytes, void* stream);      // misc.hip
 int vmvm_gemm_pp(const vmvm_gemm_desc& d, int need, hipStream_t st);
 int vmvm_gemm_pp_fp8(const vmvm_gemm_desc& d, int need, hipStream_t st);      // gemm_pp.hip: 256x256 ping-pong main loop
 
@@ -317,53 +317,76 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const vmvm_gemm_desc p) {
   }
 }
 
-// C[m][n] += sum_s ws[s][m][n]   (float4 lanes; every slab element was written by exactly one block).  gridDim.y > 1: the slabs are
-// split over blockIdx.y and the partial sums land with f32 atomics -- small outputs with hundreds of slices (the 128 x 128 weight
-// gradient of Swin stage 1: 512 slabs, 16 workgroups' worth of output) otherwise sum their slabs one after the other on a handful of CUs
-// (122 us; the reduce of a gradient is upstream of the all-reduce, so the order of the partial sums does not have to be fixed).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int S) {
+// C[m][n] += sum_s ws[s][m][n]   (float4 lanes; every slab element was written by exactly one block), slabs summed in index order.
+// Small outputs with hundreds of slices (the 128 x 128 weight gradient of Swin stage 1: 512 slabs, 16 workgroups' worth of output)
+// would sum their slabs one after the other on a handful of CUs (122 us): the slabs are split over blockIdx.y.  Rounds 2-5 combined the
+// gridDim.y partial sums with f32 atomics; round 6 (run-to-run reproducibility): TWO PASSES -- pass 1 (PARTIAL = true) leaves the sum of
+// the slabs [y per, (y + 1) per) in slab y per (every thread reads all its slabs before it writes, and no other y touches them), pass 2
+// sums those `ny` slabs in order into C.  No atomics, one more ~3 us launch for the few small-output shapes that split over y.
+// Fused bias gradient (vmvm_gemm_desc.colsum) of a split problem: the GEMM units leave parts[slice][m] behind the slabs
+// (colsum_parts()), the first M threads of the final pass add them in slice order.
+template <bool PARTIAL>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int S, int sstep, int per,
+                                                            float* __restrict__ colsum, const float* __restrict__ parts, int S_parts) {
   const long n4 = N >> 2;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (!PARTIAL && colsum && i < M) {
+    float t = 0.f;
+    for (int s = 0; s < S_parts; ++s) t += parts[(size_t)s * M + i];
+    colsum[i] += t;
+  }
   if (i >= (long)M * n4) return;
   const long m = i / n4, c = (i - m * n4) * 4;
   const size_t slab = (size_t)M * N;
-  const int per = (S + gridDim.y - 1) / gridDim.y;
-  const int s0 = blockIdx.y * per, s1 = (s0 + per < S) ? s0 + per : S;
-  // Round 6: the slabs are read ONCE (non-temporal) and four at a time -- the loop body used to be one dependent load-add per slab, so a
-  // thread had 16 bytes in flight; the sum order stays s0, s0 + 1, ... (same bits as before).
+  const int s0 = PARTIAL ? blockIdx.y * per : 0, s1 = PARTIAL ? ((s0 + per < S) ? s0 + per : S) : S;
+  // the slabs are read ONCE (non-temporal) and four at a time -- the loop body used to be one dependent load-add per slab, so a
+  // thread had 16 bytes in flight; the sum order is the slab order
   typedef float v4f __attribute__((ext_vector_type(4)));
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* src = ws + m * N + c;
+  const size_t st_ = slab * (size_t)sstep;
   int s = s0;
   for (; s + 4 <= s1; s += 4) {
     v4f v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)(s + u) * slab));
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)(s + u) * st_));
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3]; }
   }
   for (; s < s1; ++s) {
-    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)s * slab));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)s * st_));
     a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3];
   }
-  float* o = C + m * ldc + c;
-  if (gridDim.y == 1) {
+  if (PARTIAL) {
+    if (s1 > s0) *reinterpret_cast<float4*>(ws + (size_t)s0 * slab + m * N + c) = a;
+  } else {
+    float* o = C + m * ldc + c;
     const float4 c0 = *reinterpret_cast<const float4*>(o);
     *reinterpret_cast<float4*>(o) = make_float4(c0.x + a.x, c0.y + a.y, c0.z + a.z, c0.w + a.w);
-  } else if (s1 > s0) {
-    atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
   }
 }
-static inline int launch_splitk_reduce(const void* ws, void* C, int M, int N, int ldc, int S, hipStream_t st) {
+static inline int launch_splitk_reduce(const vmvm_gemm_desc& d, int S, hipStream_t st) {
+  float* ws = reinterpret_cast<float*>(d.workspace);
+  float* C = reinterpret_cast<float*>(d.C);
+  const int M = d.M, N = d.N;
   const long n = (long)M * (N >> 2);
   const unsigned nbx = (unsigned)((n + 255) / 256);
   unsigned ny = 1;
   if (nbx <= 64 && S >= 16) {                            // a quarter of the CUs or fewer: spread the slabs too (from 256 workgroups of output on,
-    ny = (1024 + nbx - 1) / nbx;                         //  the atomics cost more than the sequential sum: 512 x 512, 32 slabs: 47 -> 63 us)
+    ny = (1024 + nbx - 1) / nbx;                         //  the second pass costs more than the sequential sum: 512 x 512, 32 slabs: 47 -> 63 us)
     if (ny > (unsigned)S / 4) ny = (unsigned)S / 4;
     if (ny < 1) ny = 1;
   }
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nbx, ny), dim3(256), 0, st, reinterpret_cast<const float*>(ws), reinterpret_cast<float*>(C), M, N, ldc, S);
+  float* parts = colsum_parts(d, S);
+  float* cs = parts ? d.colsum : nullptr;
+  if (ny > 1) {
+    const int per = (S + (int)ny - 1) / (int)ny;
+    const int ny_eff = (S + per - 1) / per;
+    hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3(nbx, ny_eff), dim3(256), 0, st, ws, C, M, N, d.ldc, S, 1, per, nullptr, nullptr, 0);
+    hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3(nbx, 1), dim3(256), 0, st, ws, C, M, N, d.ldc, ny_eff, per, 0, cs, parts, S);
+  } else {
+    hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3(nbx, 1), dim3(256), 0, st, ws, C, M, N, d.ldc, S, 1, 0, cs, parts, S);
+  }
   return 0;
 }
 
@@ -379,7 +402,7 @@ int launch(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<AK, BKM, TR, DIRECT>), dim3(nb), dim3(256), SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
+    launch_splitk_reduce(d, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -537,7 +560,7 @@ int launch_big(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_big_kernel<AK, BKM>), dim3(nb), dim3(512), BIG_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
+    launch_splitk_reduce(d, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -680,7 +703,7 @@ int launch_p3(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_p3_kernel<AK, BKM>), dim3(nb), dim3(512), P3_SMEM, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
+    launch_splitk_reduce(d, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -963,7 +986,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pers_kernel(const vmvm_gemm_desc 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r;
-        if (m < M) atomicAdd(p.colsum + m, p.colsum_scale != 0.f ? cs[i][0] * p.colsum_scale : cs[i][0]);
+        if (m < M) {
+          const float t = p.colsum_scale != 0.f ? cs[i][0] * p.colsum_scale : cs[i][0];
+          float* parts = colsum_parts(p, p.splitk);          // split problem with room behind the slabs: fixed-order sum in the reduce pass
+          if (parts) parts[(size_t)slice * M + m] = t; else atomicAdd(p.colsum + m, t);
+        }
       }
     }
     if constexpr ((F & EF_ARGMAX) != 0) {
@@ -1165,7 +1192,7 @@ int launch_pers_f(const vmvm_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_pers_kernel<AK, BKM, F>), dim3(grid), dim3(256), PERS_SMEM_BYTES, st, d);
   VMVM_CHECK_LAUNCH();
   if (d.splitk > 1 && d.workspace) {
-    launch_splitk_reduce(d.workspace, d.C, d.M, d.N, d.ldc, d.splitk, st);
+    launch_splitk_reduce(d, d.splitk, st);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;
@@ -1329,6 +1356,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
   if (d->row_scale && d->rows_per_scale <= 0) return VMVM_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool tr = d->variant != 1;
+  const vmvm_gemm_desc* d_in = d;                      // (the caller's workspace fields survive in here: the plan below may null dd.workspace)
   vmvm_gemm_desc dd = *d;
   d = &dd;
   // split-K: weight gradients have few output tiles and a very long reduction (tokens); spread the reduction over
@@ -1371,7 +1399,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
       if (s == 1) dp.workspace = nullptr;
       const int rc_ = vmvm_gemm_pp(dp, epi_need(dp) | (s > 1 ? EF_SPLIT : 0), st);
       if (rc_ == VMVM_OK && s > 1) {
-        launch_splitk_reduce(dp.workspace, dp.C, dp.M, dp.N, dp.ldc, s, st);
+        launch_splitk_reduce(dp, s, st);
         VMVM_CHECK_LAUNCH();
       }
       if (rc_ != VMVM_ENOSUPPORT) return rc_;
@@ -1403,7 +1431,7 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
     const bool plain_wgrad = !dd.b_kmajor && dd.out_fp32 && !dd.bias && !dd.col_scale_n && !dd.act && !dd.row_scale && dd.dropout_p <= 0.f &&
                              !dd.resid && !dd.row_map && !(dd.N & 7);
     if (!(pers && plain_wgrad)) {                        // not the fused build: one separate pass over A (= X of the column sum)
-      const int rc_ = vmvm_colsum_scaled(dd.A, dd.K, dd.M, dd.lda, dd.colsum_scale != 0.f ? dd.colsum_scale : 1.f, dd.colsum, stream);
+      const int rc_ = vmvm_colsum_scaled(dd.A, dd.K, dd.M, dd.lda, dd.colsum_scale != 0.f ? dd.colsum_scale : 1.f, dd.colsum, d_in->workspace, d_in->workspace_bytes, stream);
       if (rc_) return rc_;
       dd.colsum = nullptr;
     }
@@ -1518,7 +1546,7 @@ extern "C" int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d) {
   if (s >= 2) {
     const int per = (nk_all + s - 1) / s;
     s = (nk_all + per - 1) / per;
-    if (s >= 2) need = (int64_t)s * d->M * d->N * (int64_t)sizeof(float);
+    if (s >= 2) need = (int64_t)s * d->M * d->N * (int64_t)sizeof(float) + (d->colsum ? (int64_t)s * d->M * (int64_t)sizeof(float) : 0);     // (+ the bias-gradient partials, colsum_parts)
   }
   if (d->splitk == 0 && !d->a_kmajor && !d->b_kmajor && d->K % BK == 0 && d->K >= 4096 && d->M >= 256 && d->N >= 256 &&
       (long)d->M * d->N >= (1 << 20)) {                                                                                       // 256x256 plan
@@ -1527,7 +1555,7 @@ extern "C" int64_t vmvm_gemm_workspace_size(const vmvm_gemm_desc* d) {
     if (s2 >= 2) {
       const int per = (nk_all + s2 - 1) / s2;
       s2 = (nk_all + per - 1) / per;
-      const int64_t n2 = s2 >= 2 ? (int64_t)s2 * d->M * d->N * (int64_t)sizeof(float) : 0;
+      const int64_t n2 = s2 >= 2 ? (int64_t)s2 * d->M * d->N * (int64_t)sizeof(float) + (d->colsum ? (int64_t)s2 * d->M * (int64_t)sizeof(float) : 0) : 0;
       if (n2 > need) need = n2;
     }
   }

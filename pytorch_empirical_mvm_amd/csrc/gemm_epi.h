@@ -18,6 +18,13 @@ __device__ __forceinline__ void raster(int tile, int nbm, int nbn, int GM, int& 
   tn = in / gsize;
 }
 
+// where a split problem's units leave their bias-gradient partials: [S][M] floats BEHIND the S slabs, when the workspace holds them
+// (host and kernels evaluate this same predicate; nullptr: one f32 atomic per (unit, m) as before)
+__host__ __device__ inline float* colsum_parts(const vmvm_gemm_desc& d, int S) {
+  if (S <= 1 || !d.workspace || !d.colsum) return nullptr;
+  const size_t slabs = (size_t)S * d.M * d.N * sizeof(float), need = slabs + (size_t)S * d.M * sizeof(float);
+  return (size_t)d.workspace_bytes >= need ? reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + slabs) : nullptr;
+}
 // ---- fused epilogue for 4 consecutive output columns (n..n+3) of row m (see include/vmvm.h for the order) ----------
 struct EpiCtx { bool has_drop; uint32_t thr; float keep_scale; int S, slice, M, N; };
 __device__ __forceinline__ void epi_store(const vmvm_gemm_desc& p, const EpiCtx& e_, float (&v)[4], int m, long dst, int n, float rs) {

@@ -406,7 +406,10 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm_pp_kernel(const vmvm_gemm_de
         float t = csum[mb] + __shfl_xor(csum[mb], 32, 64);
         if (p.colsum_scale != 0.f) t *= p.colsum_scale;
         const int m = m0 + wr * 128 + mb * 32 + l31;
-        if (hh == 0 && m < M) atomicAdd(p.colsum + m, t);
+        if (hh == 0 && m < M) {
+          float* parts = colsum_parts(p, S);                 // (gemm.hip: [S][M] partials behind the slabs, summed in slice order by the reduce pass)
+          if (parts) parts[(size_t)slice * M + m] = t; else atomicAdd(p.colsum + m, t);
+        }
       }
     }
     bool rvalid[4]; long rdst[4]; float rrs[4];

@@ -94,19 +94,35 @@ __global__ void encvideo_assemble_bwd_kernel(const u16* __restrict__ dpre, u16* 
     const int pp = (int)(row % hw);
     const long bt = row / hw;
     *reinterpret_cast<uint4*>(dfc + row * Hd + ch * 8) = *reinterpret_cast<const uint4*>(dpre + (bt * P + pp + 1) * Hd + ch * 8);
-  } else if (mode == 1) {                                 // blockIdx.y = clip: T frames summed per thread, B atomics per output
-    if (i >= (long)P * Hd) return;
-    const int col = (int)(i % Hd), pp = (int)(i / Hd), b = blockIdx.y;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += bf2f(dpre[(((long)b * T + t) * P + pp) * Hd + col]);
-    atomicAdd(dpos + (long)pp * Hd + col, s);
-    if (pp == 0) atomicAdd(dcls + col, s);
-  } else {                                                // blockIdx.y = clip: the P rows of one (clip, frame) per thread (24 workgroups
-    if (i >= (long)T * Hd) return;                        //  walked all 19 MB one after the other before: 400 us)
-    const int col = (int)(i % Hd), t = (int)(i / Hd), b = blockIdx.y;
-    float s = 0.f;
-    for (int pp = 0; pp < P; ++pp) s += bf2f(dpre[(((long)b * T + t) * P + pp) * Hd + col]);
-    atomicAdd(dlen + (long)t * Hd + col, s);
+  }
+}
+// Round 6 (run-to-run reproducibility; rounds 2-5: one f32 atomic per clip and output).  A workgroup owns 64 columns of ONE output row
+// -- dpos[pp] (MODE 1: sum over the B * T (clip, frame) rows at position pp; pp == 0 also goes to dcls) or dlen[t] (MODE 2: sum over the
+// B * P rows of frame t) -- its four row lanes each sum a quarter of the terms in index order and lane 0 adds the four in order.
+template <int MODE>
+__global__ __launch_bounds__(256) void encvideo_embed_grad_kernel(const u16* __restrict__ dpre, float* __restrict__ dcls, float* __restrict__ dpos,
+                                                                  float* __restrict__ dlen, int B, int T, int hw, int Hd) {
+  __shared__ float part[4][64];
+  const int P = 1 + hw;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ncg = (Hd + 63) / 64;
+  const int o = blockIdx.x / ncg, col = (blockIdx.x % ncg) * 64 + cl;      // output row (pp or t), column
+  const int nterm = MODE == 1 ? B * T : B * P;
+  float acc = 0.f;
+  if (col < Hd) {
+    for (int k = rl; k < nterm; k += 4) {
+      long row;
+      if (MODE == 1) row = (long)k * P + o;                                  // k = b * T + t
+      else row = ((long)(k / P) * T + o) * P + (k % P);                      // k = b * P + pp
+      acc += bf2f(dpre[row * Hd + col]);
+    }
+  }
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && col < Hd) {
+    const float v = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    if (MODE == 1) { dpos[(long)o * Hd + col] += v; if (o == 0) dcls[col] += v; }
+    else dlen[(long)o * Hd + col] += v;
   }
 }
 
@@ -125,17 +141,52 @@ __global__ void bert_embed_kernel(const int64_t* __restrict__ txt, const float* 
   for (int e = 0; e < 8; ++e) v[e] = word[id * Hd + ch * 8 + e] + pos[(long)x * Hd + ch * 8 + e] + type0[ch * 8 + e];
   *reinterpret_cast<uint4*>(out + row * Hd + ch * 8) = pack_bf8(v);
 }
-__global__ void bert_embed_bwd_kernel(const int64_t* __restrict__ txt, const u16* __restrict__ dsum, float* __restrict__ dword,
-                                      float* __restrict__ dpos, float* __restrict__ dtype0, int B, int X, int Hd) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * X * Hd) return;
-  const int col = (int)(i % Hd);
-  const long row = i / Hd;
-  const int x = (int)(row % X);
-  const float g = bf2f(dsum[i]);
-  atomicAdd(dword + txt[row] * Hd + col, g);
-  atomicAdd(dpos + (long)x * Hd + col, g);
-  atomicAdd(dtype0 + col, g);
+// Round 6 (run-to-run reproducibility; rounds 1-5: three f32 atomics per (row, column)).  One workgroup per text row i = (b, x), the
+// token ids of the whole batch in LDS:
+//   dword[tok]: the row that holds the FIRST occurrence of its token sums every row with that token in row order (single writer);
+//   dpos[x]:    the b = 0 row of position x sums its B rows in order;
+//   dtype0:     row 0 sums ALL rows (B * X <= a few thousand; four row lanes x 64 columns per pass, lanes combined in order).
+__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const int64_t* __restrict__ txt, const u16* __restrict__ dsum, float* __restrict__ dword,
+                                                             float* __restrict__ dpos, float* __restrict__ dtype0, int B, int X, int Hd) {
+  extern __shared__ int ids[];                             // [B * X]
+  __shared__ int first;
+  __shared__ float part[4][64];
+  const int n = B * X, i = blockIdx.x;
+  for (int k = threadIdx.x; k < n; k += 256) ids[k] = (int)txt[k];
+  if (threadIdx.x == 0) first = 1;
+  __syncthreads();
+  const int tok = ids[i], x = i % X, b = i / X;
+  for (int k = threadIdx.x; k < i; k += 256)
+    if (ids[k] == tok) first = 0;                          // (benign race: every writer stores 0)
+  __syncthreads();
+  if (first) {
+    for (int col = threadIdx.x; col < Hd; col += 256) {
+      float t = 0.f;
+      for (int k = i; k < n; ++k)
+        if (ids[k] == tok) t += bf2f(dsum[(long)k * Hd + col]);
+      dword[(long)tok * Hd + col] += t;
+    }
+  }
+  if (b == 0) {
+    for (int col = threadIdx.x; col < Hd; col += 256) {
+      float t = 0.f;
+      for (int bb = 0; bb < B; ++bb) t += bf2f(dsum[((long)bb * X + x) * Hd + col]);
+      dpos[(long)x * Hd + col] += t;
+    }
+  }
+  if (i == 0) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < Hd; c0 += 64) {
+      const int col = c0 + cl;
+      float t = 0.f;
+      if (col < Hd)
+        for (int k = rl; k < n; k += 4) t += bf2f(dsum[(long)k * Hd + col]);
+      part[rl][cl] = t;
+      __syncthreads();
+      if (rl == 0 && col < Hd) dtype0[col] += ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+      __syncthreads();
+    }
+  }
 }
 
 // ---------------------------------------------------------------- cross entropy (ignore_index = -1)
@@ -429,8 +480,10 @@ __global__ void dropout_kernel(const u16* __restrict__ x, u16* __restrict__ y, l
 }
 
 // column sums: block = 8 column-chunks (64 cols) x 32 row lanes ; grid.y splits the rows
+// `part` != NULL (round 6, run-to-run reproducibility): block row y leaves its sums in part[y][N] and colsum_fin_kernel adds the
+// gridDim.y rows in order; NULL: one f32 atomic per (block row, column) into `out` as in rounds 1-5.
 __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, int M, int N, int ldx, const float* __restrict__ row_scale,
-                                                     int rows_per_scale, float all_scale, float* __restrict__ out) {
+                                                     int rows_per_scale, float all_scale, float* __restrict__ out, float* __restrict__ part) {
   __shared__ float sh[32][65];
   const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int col = blockIdx.x * 64 + cc * 8;
@@ -470,8 +523,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
 #pragma unroll 8
     for (int k = 0; k < 32; ++k) s += sh[k][threadIdx.x];
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < N) atomicAdd(out + c, s * all_scale);
+    if (c < N) {
+      if (part) part[(size_t)blockIdx.y * N + c] = s * all_scale; else atomicAdd(out + c, s * all_scale);
+    }
   }
+}
+__global__ __launch_bounds__(256) void colsum_fin_kernel(const float* __restrict__ part, int gy, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float t = 0.f;
+  for (int y = 0; y < gy; ++y) t += part[(size_t)y * N + c];
+  out[c] += t;
 }
 
 // ---------------------------------------------------------------- batched bf16 transpose (W [N][K] -> W^T [K][N])
@@ -883,8 +945,9 @@ extern "C" int vmvm_encvideo_assemble_bwd(const void* dpre, void* d_fc_out, floa
   const u16* dp = reinterpret_cast<const u16*>(dpre);
   u16* df = reinterpret_cast<u16*>(d_fc_out);
   hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)B * T * hw * (Hd / 8), 256)), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 0);
-  hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)(1 + hw) * Hd, 256), B), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 1);
-  hipLaunchKernelGGL(encvideo_assemble_bwd_kernel, dim3(nblk((long)T * Hd, 256), B), dim3(256), 0, ST, dp, df, dcls, dpos, dlen, B, T, hw, Hd, 2);
+  const int ncg = (Hd + 63) / 64;
+  hipLaunchKernelGGL((encvideo_embed_grad_kernel<1>), dim3((1 + hw) * ncg), dim3(256), 0, ST, dp, dcls, dpos, dlen, B, T, hw, Hd);
+  hipLaunchKernelGGL((encvideo_embed_grad_kernel<2>), dim3(T * ncg), dim3(256), 0, ST, dp, dcls, dpos, dlen, B, T, hw, Hd);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -898,7 +961,8 @@ extern "C" int vmvm_bert_embed(const int64_t* txt, const float* word, const floa
 extern "C" int vmvm_bert_embed_bwd(const int64_t* txt, const void* dsum, float* dword, float* dpos, float* dtype0,
                                    int32_t B, int32_t X, int32_t Hd, void* stream) {
   if (!txt || !dsum || !dword || !dpos || !dtype0) return VMVM_EINVAL;
-  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(nblk((long)B * X * Hd, 256)), dim3(256), 0, ST, txt, reinterpret_cast<const u16*>(dsum), dword, dpos, dtype0, B, X, Hd);
+  if ((long)B * X * 4 > 48 * 1024) return VMVM_ENOSUPPORT;      // the batch's token ids live in LDS
+  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(B * X), dim3(256), (size_t)B * X * sizeof(int), ST, txt, reinterpret_cast<const u16*>(dsum), dword, dpos, dtype0, B, X, Hd);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -1044,24 +1108,40 @@ extern "C" int vmvm_dropout_bf16(const void* x, void* y, int64_t n, float p, uin
   return VMVM_OK;
 }
 static int colsum_launch(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float all_scale, float* out,
-                         int32_t accumulate, void* stream) {
+                         int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
   if (!X || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return VMVM_EINVAL;
   if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, ST) != hipSuccess) return VMVM_EHIP;
   int gy = (M + 32 * 16 - 1) / (32 * 16);
   if (gy > 256) gy = 256;
   if (gy < 1) gy = 1;
+  float* part = (ws && ws_bytes >= (int64_t)gy * N * (int64_t)sizeof(float)) ? reinterpret_cast<float*>(ws) : nullptr;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, ST, reinterpret_cast<const u16*>(X), M, N, ldx, row_scale, rows_per_scale,
-                     all_scale, out);
+                     all_scale, out, part);
   VMVM_CHECK_LAUNCH();
+  if (part) {
+    hipLaunchKernelGGL(colsum_fin_kernel, dim3(nblk(N, 256)), dim3(256), 0, ST, part, gy, N, out);
+    VMVM_CHECK_LAUNCH();
+  }
   return VMVM_OK;
 }
 extern "C" int vmvm_colsum_bf16(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
                                 int32_t accumulate, void* stream) {
-  return colsum_launch(X, M, N, ldx, row_scale, rows_per_scale, 1.f, out, accumulate, stream);
+  return colsum_launch(X, M, N, ldx, row_scale, rows_per_scale, 1.f, out, accumulate, nullptr, 0, stream);
 }
-// out[n] += scale * sum_m X[m][n]: the separate-pass form of vmvm_gemm_desc.colsum / colsum_scale (gemm.hip, shapes off the fused build)
-int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* stream) {
-  return colsum_launch(X, M, N, ldx, nullptr, 0, scale, out, 1, stream);
+extern "C" int vmvm_colsum_bf16_ws(const void* X, int32_t M, int32_t N, int32_t ldx, const float* row_scale, int32_t rows_per_scale, float* out,
+                                   int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return colsum_launch(X, M, N, ldx, row_scale, rows_per_scale, 1.f, out, accumulate, workspace, workspace_bytes, stream);
+}
+extern "C" int64_t vmvm_colsum_workspace_size(int32_t M, int32_t N) {
+  if (M <= 0 || N <= 0) return VMVM_EINVAL;
+  int64_t gy = ((int64_t)M + 32 * 16 - 1) / (32 * 16);
+  if (gy > 256) gy = 256;
+  return gy * N * (int64_t)sizeof(float);
+}
+// out[n] += scale * sum_m X[m][n]: the separate-pass form of vmvm_gemm_desc.colsum / colsum_scale (gemm.hip, shapes off the fused build;
+// runs in front of that GEMM's own kernels, so it may use the GEMM's workspace for its partial rows)
+int vmvm_colsum_scaled(const void* X, int32_t M, int32_t N, int32_t ldx, float scale, float* out, void* ws, int64_t ws_bytes, void* stream) {
+  return colsum_launch(X, M, N, ldx, nullptr, 0, scale, out, 1, ws, ws_bytes, stream);
 }
 extern "C" int vmvm_transpose_batched_bf16(const void* src, void* dst, const int32_t* table, int32_t ntiles, void* stream) {
   if (!src || !dst || !table || ntiles <= 0) return VMVM_EINVAL;

@@ -134,7 +134,7 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         def wgrad(ws):
             gb_ = gbias
             if gb_ is not None and row_scale is not None and cs_scale is None:   # per-clip DropPath weights: separate pass (the fused form has ONE scale)
-                K.colsum(dy, gb_, row_scale, rows_per_scale, accumulate=True, M=M, N=N)
+                K.colsum(dy, gb_, row_scale, rows_per_scale, accumulate=True, M=M, N=N, workspace=ws)
                 gb_ = None
             # db = [cs_scale *] colsum(dy) rides on the weight-gradient GEMM (dy is its A operand)
             K.gemm(dy, x, a_kmajor=False, b_kmajor=False, M=N, N=w2.shape[1], K=M or dy.shape[0], out=gw2, accumulate=True, colsum=gb_,

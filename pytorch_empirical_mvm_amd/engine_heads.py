@@ -43,7 +43,7 @@ class HeadsMixin:
         gm = S.p(pm + "transform.LayerNorm.weight")
         Wdec = S.b(pm + "decoder.weight")
         def dec_wgrad(ws):
-            K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=n, N=Vpad)     # pad columns are zero and land in arena padding
+            K.colsum(hd["dlog"], S.g(pm + "bias"), accumulate=True, M=n, N=Vpad, workspace=ws)     # pad columns are zero and land in arena padding
             K.gemm(hd["dlog"], hd["tn"], a_kmajor=False, b_kmajor=False, M=Vv, N=Hd, K=n, out=S.g(pm + "decoder.weight"), accumulate=True, workspace=ws)
         self._wgrad_launch(dec_wgrad, (hd["dlog"], hd["tn"]))
         # d(tn) = dlog . W over K = the PADDED vocabulary when that is a whole number of 64-wide K tiles (30522 -> 30528): the GEMM

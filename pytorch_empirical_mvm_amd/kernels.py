@@ -125,11 +125,14 @@ def argmax_pairs(pairs, groups):
     return out
 
 
-def colsum(X, out, row_scale=None, rows_per_scale=0, accumulate=True, M=None, N=None):
+def colsum(X, out, row_scale=None, rows_per_scale=0, accumulate=True, M=None, N=None, workspace=None):
     M = X.shape[0] if M is None else M
     N = X.shape[1] if N is None else N
-    L.check(L.load().vmvm_colsum_bf16(X.data_ptr(), M, N, _ld(X), L.ptr(row_scale), rows_per_scale, out.data_ptr(),
-                                      int(accumulate), L.stream()), "colsum")
+    # row-block partials summed in a fixed order (reproducible; without scratch: f32 atomics).  `workspace`: the scratch of the STREAM
+    # this call is issued on -- the engine's weight-gradient closures run on its second stream and pass that stream's own buffer
+    ws = workspace if workspace is not None else _WORKSPACE.get(X.device)
+    L.check(L.load().vmvm_colsum_bf16_ws(X.data_ptr(), M, N, _ld(X), L.ptr(row_scale), rows_per_scale, out.data_ptr(),
+                                         int(accumulate), L.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, L.stream()), "colsum")
     return out
 
 
@@ -226,6 +229,8 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
                      keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, None, win_layout, drop_mask)
     b.dout, b.ld_dout, b.dqkv, b.ld_dqkv = dout.data_ptr(), _ld(dout), dqkv.data_ptr(), _ld(dqkv)
     b.dbias_table, b.delta = L.ptr(dbias_table), delta.data_ptr()
+    ws = _WORKSPACE.get(qkv.device) if dbias_table is not None else None      # reproducible table gradient: per-workgroup partial tables in the caller's scratch
+    b.dbias_ws, b.dbias_ws_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
     L.check(L.load().vmvm_attention_bwd(C.byref(b), L.stream()), "attention_bwd")
     return dqkv
 

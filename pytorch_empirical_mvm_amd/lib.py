@@ -67,7 +67,7 @@ class AttnFwdDesc(C.Structure):
 
 class AttnBwdDesc(C.Structure):
     _fields_ = [("f", AttnFwdDesc), ("dout", c_void_p), ("ld_dout", c_int), ("dqkv", c_void_p), ("ld_dqkv", c_int),
-                ("dbias_table", c_void_p), ("delta", c_void_p)]
+                ("dbias_table", c_void_p), ("delta", c_void_p), ("dbias_ws", c_void_p), ("dbias_ws_bytes", c_i64)]
 
 
 class AdamWDesc(C.Structure):
@@ -83,6 +83,8 @@ _PROTOS = {
     "vmvm_last_hip_error": ([], c_int),
     "vmvm_gemm_bf16": ([C.POINTER(GemmDesc), c_void_p], c_int),
     "vmvm_colsum_bf16": ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
+    "vmvm_colsum_bf16_ws": ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_i64, c_void_p], c_int),
+    "vmvm_colsum_workspace_size": ([c_int, c_int], c_i64),
     "vmvm_layernorm_fwd": ([C.POINTER(LnFwdDesc), c_void_p], c_int),
     "vmvm_layernorm_bwd": ([C.POINTER(LnBwdDesc), c_void_p], c_int),
     "vmvm_attention_fwd": ([C.POINTER(AttnFwdDesc), c_void_p], c_int),
@@ -129,6 +131,7 @@ _PROTOS = {
     "vmvm_layernorm_bwd_workspace_size": ([C.POINTER(LnBwdDesc)], c_i64),
     "vmvm_attention_bwd_workspace_size": ([C.POINTER(AttnBwdDesc)], c_i64),
     "vmvm_attention_drop_mask_size": ([C.POINTER(AttnFwdDesc)], c_i64),
+    "vmvm_attention_bwd_dbias_ws_size": ([C.POINTER(AttnBwdDesc)], c_i64),
     "vmvm_sumsq_workspace_size": ([c_i64], c_i64),
 }
 
