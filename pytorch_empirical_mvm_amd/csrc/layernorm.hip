@@ -429,30 +429,30 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
   }
 }
 
-// dgamma[c] += sum_rows ws[row][c], dbeta[c] += sum_rows ws[row][C + c] : 64 columns x 16 row lanes per workgroup, ONE workgroup per
+// dgamma[c] += sum_rows ws[row][c], dbeta[c] += sum_rows ws[row][C + c] : 32 columns x 32 row lanes per workgroup, ONE workgroup per
 // column group (round 6, run-to-run reproducibility: rounds 2-5 split the rows over blockIdx.y and combined the 8-32 partial sums of a
-// column with f32 atomics; here a row lane sums rows rl, rl + 16, ... in order and lane 0 adds the 16 lane sums in order -- the few
+// column with f32 atomics; here a row lane sums rows rl, rl + 32, ... in order and lane 0 adds the 32 lane sums in order -- the few
 // MB of partial rows are L2-resident, 5-7 us as before).
 __global__ __launch_bounds__(1024) void ln_colreduce_kernel(const float* ws, int rows, int C, float* dgamma, float* dbeta) {
-  __shared__ float part[16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  __shared__ float part[32][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;  // 32 columns x 32 row lanes
+  const int col = blockIdx.x * 32 + cl;
   float acc = 0.f;
   if (col < 2 * C) {
     int r = rl;
-    for (; r + 48 < rows; r += 64) {                     // four independent loads in flight
-      const float a0 = ws[(size_t)r * 2 * C + col], a1 = ws[(size_t)(r + 16) * 2 * C + col];
-      const float a2 = ws[(size_t)(r + 32) * 2 * C + col], a3 = ws[(size_t)(r + 48) * 2 * C + col];
+    for (; r + 96 < rows; r += 128) {                     // four independent loads in flight
+      const float a0 = ws[(size_t)r * 2 * C + col], a1 = ws[(size_t)(r + 32) * 2 * C + col];
+      const float a2 = ws[(size_t)(r + 64) * 2 * C + col], a3 = ws[(size_t)(r + 96) * 2 * C + col];
       acc += a0; acc += a1; acc += a2; acc += a3;
     }
-    for (; r < rows; r += 16) acc += ws[(size_t)r * 2 * C + col];
+    for (; r < rows; r += 32) acc += ws[(size_t)r * 2 * C + col];
   }
   part[rl][cl] = acc;
   __syncthreads();
   if (rl == 0 && col < 2 * C) {
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v += part[k][cl];
+    for (int k = 0; k < 32; ++k) v += part[k][cl];
     float* o = col < C ? dgamma + col : dbeta + (col - C);
     *o += v;                                              // single writer per column
   }
@@ -553,7 +553,7 @@ extern "C" int vmvm_layernorm_bwd(const vmvm_ln_bwd_desc* d, void* stream) {
   else LAUNCH_LNB(6, false);
   if (dd.workspace) {
     VMVM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * d->C + 63) / 64), dim3(1024), 0, st,
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * d->C + 31) / 32), dim3(1024), 0, st,
                        reinterpret_cast<const float*>(dd.workspace), grid, d->C, d->dgamma, d->dbeta);
   }
   VMVM_CHECK_LAUNCH();

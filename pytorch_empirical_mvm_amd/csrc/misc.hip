@@ -141,51 +141,63 @@ __global__ void bert_embed_kernel(const int64_t* __restrict__ txt, const float* 
   for (int e = 0; e < 8; ++e) v[e] = word[id * Hd + ch * 8 + e] + pos[(long)x * Hd + ch * 8 + e] + type0[ch * 8 + e];
   *reinterpret_cast<uint4*>(out + row * Hd + ch * 8) = pack_bf8(v);
 }
-// Round 6 (run-to-run reproducibility; rounds 1-5: three f32 atomics per (row, column)).  One workgroup per text row i = (b, x), the
-// token ids of the whole batch in LDS:
-//   dword[tok]: the row that holds the FIRST occurrence of its token sums every row with that token in row order (single writer);
-//   dpos[x]:    the b = 0 row of position x sums its B rows in order;
-//   dtype0:     row 0 sums ALL rows (B * X <= a few thousand; four row lanes x 64 columns per pass, lanes combined in order).
-__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const int64_t* __restrict__ txt, const u16* __restrict__ dsum, float* __restrict__ dword,
-                                                             float* __restrict__ dpos, float* __restrict__ dtype0, int B, int X, int Hd) {
+// Round 6 (run-to-run reproducibility; rounds 1-5: three f32 atomics per (row, column)).  1 024-thread workgroups, three kinds:
+//   blocks [0, n):                 text row i = (b, x), the token ids of the whole batch in LDS -- the row that holds the FIRST occurrence
+//                                  of its token sums every row with that token in row order into dword[tok] (single writer);
+//   blocks [n, n + X ncg):         dpos[x], 64 columns: 16 row lanes sum the B rows of position x (lane order), lane 0 adds the 16;
+//   blocks [n + X ncg, .. + ncg):  dtype0, 64 columns: 16 row lanes over ALL n rows, eight independent loads in flight per lane.
+__global__ __launch_bounds__(1024) void bert_embed_bwd_kernel(const int64_t* __restrict__ txt, const u16* __restrict__ dsum, float* __restrict__ dword,
+                                                              float* __restrict__ dpos, float* __restrict__ dtype0, int B, int X, int Hd) {
   extern __shared__ int ids[];                             // [B * X]
   __shared__ int first;
-  __shared__ float part[4][64];
-  const int n = B * X, i = blockIdx.x;
-  for (int k = threadIdx.x; k < n; k += 256) ids[k] = (int)txt[k];
-  if (threadIdx.x == 0) first = 1;
-  __syncthreads();
-  const int tok = ids[i], x = i % X, b = i / X;
-  for (int k = threadIdx.x; k < i; k += 256)
-    if (ids[k] == tok) first = 0;                          // (benign race: every writer stores 0)
-  __syncthreads();
-  if (first) {
-    for (int col = threadIdx.x; col < Hd; col += 256) {
+  __shared__ float part[16][64];
+  const int n = B * X, ncg = (Hd + 63) / 64;
+  const int blk = blockIdx.x;
+  if (blk < n) {
+    const int i = blk;
+    for (int k = threadIdx.x; k < n; k += 1024) ids[k] = (int)txt[k];
+    if (threadIdx.x == 0) first = 1;
+    __syncthreads();
+    const int tok = ids[i];
+    for (int k = threadIdx.x; k < i; k += 1024)
+      if (ids[k] == tok) first = 0;                        // (benign race: every writer stores 0)
+    __syncthreads();
+    if (!first) return;
+    for (int col = threadIdx.x; col < Hd; col += 1024) {
       float t = 0.f;
       for (int k = i; k < n; ++k)
         if (ids[k] == tok) t += bf2f(dsum[(long)k * Hd + col]);
       dword[(long)tok * Hd + col] += t;
     }
+    return;
   }
-  if (b == 0) {
-    for (int col = threadIdx.x; col < Hd; col += 256) {
-      float t = 0.f;
-      for (int bb = 0; bb < B; ++bb) t += bf2f(dsum[((long)bb * X + x) * Hd + col]);
-      dpos[(long)x * Hd + col] += t;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 64 columns x 16 row lanes
+  const bool is_pos = blk < n + X * ncg;
+  const int j = is_pos ? blk - n : blk - n - X * ncg;
+  const int x = is_pos ? j / ncg : 0, col = (is_pos ? j % ncg : j) * 64 + cl;
+  float t = 0.f;
+  if (col < Hd) {
+    if (is_pos) {
+      for (int bb = rl; bb < B; bb += 16) t += bf2f(dsum[((long)bb * X + x) * Hd + col]);
+    } else {
+      int k = rl;
+      for (; k + 7 * 16 < n; k += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = bf2f(dsum[(long)(k + u * 16) * Hd + col]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      for (; k < n; k += 16) t += bf2f(dsum[(long)k * Hd + col]);
     }
   }
-  if (i == 0) {
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < Hd; c0 += 64) {
-      const int col = c0 + cl;
-      float t = 0.f;
-      if (col < Hd)
-        for (int k = rl; k < n; k += 4) t += bf2f(dsum[(long)k * Hd + col]);
-      part[rl][cl] = t;
-      __syncthreads();
-      if (rl == 0 && col < Hd) dtype0[col] += ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
-      __syncthreads();
-    }
+  part[rl][cl] = t;
+  __syncthreads();
+  if (rl == 0 && col < Hd) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][cl];
+    if (is_pos) dpos[(long)x * Hd + col] += v; else dtype0[col] += v;
   }
 }
 
@@ -528,12 +540,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, 
     }
   }
 }
-__global__ __launch_bounds__(256) void colsum_fin_kernel(const float* __restrict__ part, int gy, int N, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
+__global__ __launch_bounds__(1024) void colsum_fin_kernel(const float* __restrict__ part, int gy, int N, float* __restrict__ out) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 64 columns x 16 row lanes, lanes combined in order
+  const int c = blockIdx.x * 64 + cl;
   float t = 0.f;
-  for (int y = 0; y < gy; ++y) t += part[(size_t)y * N + c];
-  out[c] += t;
+  if (c < N)
+    for (int y = rl; y < gy; y += 16) t += part[(size_t)y * N + c];
+  sh[rl][cl] = t;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += sh[k][cl];
+    out[c] += v;
+  }
 }
 
 // ---------------------------------------------------------------- batched bf16 transpose (W [N][K] -> W^T [K][N])
@@ -962,7 +983,8 @@ extern "C" int vmvm_bert_embed_bwd(const int64_t* txt, const void* dsum, float* 
                                    int32_t B, int32_t X, int32_t Hd, void* stream) {
   if (!txt || !dsum || !dword || !dpos || !dtype0) return VMVM_EINVAL;
   if ((long)B * X * 4 > 48 * 1024) return VMVM_ENOSUPPORT;      // the batch's token ids live in LDS
-  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(B * X), dim3(256), (size_t)B * X * sizeof(int), ST, txt, reinterpret_cast<const u16*>(dsum), dword, dpos, dtype0, B, X, Hd);
+  const int ncg = (Hd + 63) / 64;
+  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(B * X + X * ncg + ncg), dim3(1024), (size_t)B * X * sizeof(int), ST, txt, reinterpret_cast<const u16*>(dsum), dword, dpos, dtype0, B, X, Hd);
   VMVM_CHECK_LAUNCH();
   return VMVM_OK;
 }
@@ -1119,7 +1141,7 @@ static int colsum_launch(const void* X, int32_t M, int32_t N, int32_t ldx, const
                      all_scale, out, part);
   VMVM_CHECK_LAUNCH();
   if (part) {
-    hipLaunchKernelGGL(colsum_fin_kernel, dim3(nblk(N, 256)), dim3(256), 0, ST, part, gy, N, out);
+    hipLaunchKernelGGL(colsum_fin_kernel, dim3(nblk(N, 64)), dim3(1024), 0, ST, part, gy, N, out);
     VMVM_CHECK_LAUNCH();
   }
   return VMVM_OK;

@@ -115,7 +115,8 @@ class VIOLET_Pretrain(torch.nn.Module):
                     node.add_module(p, _Node())
                 node = getattr(node, p)
             prm = torch.nn.Parameter(store.p(name), requires_grad=name not in store.FROZEN or True)
-            prm.grad = store.g(name)
+            if name not in store.FROZEN:        # (emb_odr / emb_task never receive a gradient: `.grad` stays None as in the reference, so a
+                prm.grad = store.g(name)        #  torch optimizer skips them instead of applying weight decay to a zero gradient)
             node.register_parameter(parts[-1], prm)
         # the heads the reference's AGENT calls itself (calc_mvm_loss): callable over the same arena-view parameters
         for hname, ups in (("decoder_pixel", args.size_patch), ("decoder_hog", args.size_patch), ("decoder_vq", max(1, args.size_patch // 8))):
@@ -305,8 +306,8 @@ class VIOLET_Pretrain(torch.nn.Module):
     def _arena_params(self):
         lst = getattr(self, "_arena_param_list", None)
         if lst is None:
-            idx = self.engine.store.index
-            lst = self._arena_param_list = [(n, p_) for n, p_ in self.named_parameters() if n in idx]
+            S = self.engine.store
+            lst = self._arena_param_list = [(n, p_) for n, p_ in self.named_parameters() if n in S.index and n not in S.FROZEN]
         return lst
 
     def forward(self, batch, negatives=None, dp_all=None):
