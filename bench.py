@@ -194,11 +194,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--cpu-timed", type=int, default=2)
     ap.add_argument("--cpu-warmup", type=int, default=1)
-    ap.add_argument("--fp8", action="store_true", help=argparse.SUPPRESS)       # rounds 1-4; kept only to say where it went
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 5's fp8 MFMA path: fusion qkv / FFN-in forward GEMMs on e4m3 operands (opt-in; never the headline: C2 is bf16)")
     a = ap.parse_args()
-    if a.fp8:
-        sys.exit("bench.py: --fp8 (the opt-in e4m3 forward of rounds 1-4) was removed in round 5 -- it never moved config 5 (22.0 vs 21.8 clips/s); "
-                 "DESIGN.md section 7.  The e4m3 GEMM builds remain in libvmvm (vmvm_gemm_desc.in_fp8).")
     if a.cpu_baseline_worker:
         cpu_baseline_worker(a.size, a.frames, a.threads, timed=a.cpu_timed, warmup=a.cpu_warmup)
         return
@@ -223,7 +220,7 @@ def main():
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     args = CFG.get_args(vis_backbone_size=a.size, size_frame=a.frames, max_size_frame=max(a.frames, 6), size_img=a.img, size_txt=32,
-                        mvm_target=[a.mvm_target], max_iter=10000, seed=88 + rank)
+                        mvm_target=[a.mvm_target], max_iter=10000, seed=88 + rank, fp8_forward=a.fp8)
     model = VIOLET_Pretrain(args, None, device=device)
     agent = Agent_Pretrain(args, model)
     agent.prepare_dist_model()
@@ -303,13 +300,14 @@ def main():
         label = {"pixel": "C2", "vq": "C4 (1 GPU; frozen dVAE tokenizer on implicit-GEMM fp16 convolutions, random weights)"}.get(
             a.mvm_target, f"C2 shapes with the {a.mvm_target} target (frozen Swin-B teacher on the same kernels, random weights)")
     elif a.size == "large" and a.img == 384 and a.frames == 16:
-        label = "C5 geometry at bf16 (the opt-in e4m3 forward of rounds 1-4 never moved this number and was removed in round 5, DESIGN 7); streaming attention kernels"
+        label = ("C5 geometry, fp8 (e4m3) forward GEMMs in the fusion encoder's qkv / FFN-in, everything else bf16" if a.fp8 else
+                 "C5 geometry at bf16 (--fp8 switches the fusion qkv / FFN-in forward GEMMs to e4m3)") + "; streaming attention kernels"
     else:
         label = "non-headline shape"
     out = {
         "metric": "pretrain clips/sec (Swin-B, 8x224^2, 32 txt tok)" if headline else f"pretrain clips/sec (Swin-{a.size}, {a.frames}x{a.img}^2, 32 txt tok)", "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "host_issue_ms_per_step": round(t_first * 1e3, 3), "host_loop_ms_per_step": round(dt_host / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16+fp8" if a.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{label}: VIOLETv2 pretrain step, Swin-{a.size} patch(2,4,4) window{window}, {a.frames}x{a.img}^2 frames, 32 text tokens, "
                                f"mvm_target={a.mvm_target}, MLM+VTM(O=4)+MVM, train mode (dropout/DropPath on), AdamW+clip, "
                                f"{'device-side rm/bm masking inside the timed step' if mask_in_step else 'masking before the timed region'}",

@@ -320,7 +320,7 @@ class Agent_Pretrain:
                                 beta1=0.9, beta2=0.98, eps=1e-8, step=self.opt_step, sumsq_t=self._sumsq, max_grad_norm=float(self.args.max_grad_norm),
                                 grad_scale=gscale)
         eng = self.engine
-        split = getattr(eng, "wstream", None) is not None and eng.sw.opt_overlap and not z1
+        split = getattr(eng, "wstream", None) is not None and eng.sw.opt_overlap and not z1 and getattr(S, "shadow8", None) is None
         if split:
             # The next forward starts with the Video-Swin backbone, which reads Swin parameters only: the update of the other 137 M parameters
             # (fusion encoder, heads, embeddings), their W^T copies and the zeroing of their gradients run on the engine's second stream
@@ -351,6 +351,7 @@ class Agent_Pretrain:
                 for sa, se in self.comm.gather_params(S.flat):
                     K.cast_bf16(S.flat[sa:se], S.shadow[sa:se])
             S.refresh_transposed()
+            S.refresh_fp8()                              # (opt-in fp8 forward: the e4m3 weight copy follows the updated bf16 copy)
             S.grad.zero_()
         self.sched_step += 1
 

@@ -76,6 +76,7 @@ def model_cfg(args):
     cfg["pretrain_tasks"] = tuple(args.get("pretrain_tasks", ("vtm", "mlm", "mvm")))      # "smtm" adds the seq2seq MLM pass
     cfg["task"] = args.get("task", "pretrain")
     cfg["size_vocab"] = args.get("size_vocab", 0)        # open-ended QA answer vocabulary (main_qaoe.py:47)
+    cfg["fp8_forward"] = bool(args.get("fp8_forward", False))     # config 5 ("fp8 MFMA path"): e4m3 forward GEMMs of the fusion qkv / FFN-in, opt-in
     return cfg
 
 

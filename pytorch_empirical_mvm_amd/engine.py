@@ -46,9 +46,15 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
         self.on_swin_tail_ready = None      # data-parallel hook (dist.GradReducer.reduce_swin_tail)
         self.on_fusion_mid_ready = None     # data-parallel hook (dist.GradReducer.reduce_other_early): the backward has left fusion layer n // 2
         self.dpr = np.linspace(0, CFG.DROP_PATH_RATE, sum(cfg["depths"])).tolist()     # video_swin.py:447
-        # (BASELINE config 5's "fp8 MFMA path": rounds 1-4 carried an opt-in e4m3 forward for the fusion qkv / FFN-in GEMMs; it never
-        # moved that config's number -- 21.8 vs 22.0 clips/s, 58 % of the step is streaming attention -- and was removed in round 5,
-        # DESIGN 7.  The e4m3 GEMM itself stays in the library: vmvm_gemm_desc.in_fp8, tools/gpu_check.py check_gemm_fp8.)
+        # BASELINE config 5 ("fp8 MFMA path"), OPT-IN (`fp8_forward`, bench.py --fp8): the forward GEMMs of the fusion encoder's qkv and
+        # FFN-in projections on e4m3 operands (per-tensor static power-of-two scales, v_mfma_scale_f32_16x16x128_f8f6f4 / 32x32x64);
+        # the backward stays bf16 on the bf16 activations.  Rounds 1-4 carried it, round 5 removed it because it never moved that
+        # config's number (58 % of the step is streaming attention), round 6 restores it as what the config names -- measured beside
+        # the bf16 line, never the headline.
+        self.fp8 = bool(cfg.get("fp8_forward", False)) and self.device.type == "cuda"
+        self.A8_SCALE = 16.0               # activations entering those GEMMs are LayerNorm outputs / the gathered pool: |x| < 28 before e4m3 saturates
+        if self.fp8:
+            self.store.enable_fp8()
         self.sw = Switches.from_env()       # every VMVM_* switch of the step path, read once (switches.py)
         self.store_drop_mask = self.sw.drop_mask      # fusion attention: the backward reads the forward's dropout decisions (44.8 MB per layer at C2) instead of re-evaluating Philox twice
         self.gelu_code8 = bool(cfg.get("gelu_code8", self.sw.gelu_code8))         # Swin MLPs keep GELU' as an 8-bit code

@@ -99,7 +99,11 @@ class FusionMixin:
         p_a = CFG.BERT["attn_dropout"] if train else 0.0
         M = nseq * Lq
         x = xv.t
-        qkv = K.gemm(x, Wqkv, bias=bqkv)
+        a8 = 1.0 / (self.A8_SCALE * S.W8_SCALE)
+        if self.fp8:
+            qkv = K.gemm(K.cast_fp8(x, self.A8_SCALE), S.fused8(qn, (3 * Hd, Hd)), bias=bqkv, fp8=True, alpha=a8)
+        else:
+            qkv = K.gemm(x, Wqkv, bias=bqkv)
         o_att = self._next_offset(nseq * nh * Lq * Lq)
         akw = dict(q_off=0, k_off=Hd, v_off=2 * Hd, keymask=keymask, dropout_p=p_a, seed=self.seed, offset=o_att, causal_from=causal_from)
         if p_a > 0 and self.store_drop_mask:                     # the forward's keep / drop decisions, read back by both backward kernels
@@ -112,7 +116,11 @@ class FusionMixin:
         x1, mean1, rstd1 = K.layernorm_fwd(a, g1, b1, CFG.BERT["eps"])
         c8 = self.gelu_code8                                     # GELU' saved as an 8-bit code (as in the Swin MLPs)
         u = torch.empty((M, CFG.BERT["ffn"]), device=dev, dtype=torch.uint8 if c8 else BF16)
-        h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u, code8=c8)
+        if self.fp8:
+            h = K.gemm(K.cast_fp8(x1, self.A8_SCALE), S.b8(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"),
+                       act=1, out_preact=u, fp8=True, alpha=a8, code8=c8)
+        else:
+            h = K.gemm(x1, S.b(pre + "intermediate.dense.weight"), bias=S.p(pre + "intermediate.dense.bias"), act=1, out_preact=u, code8=c8)
         o2 = self._next_offset(M * Hd)
         f = K.gemm(h, S.b(pre + "output.dense.weight"), bias=S.p(pre + "output.dense.bias"), resid=x1, dropout_p=p_h, seed=self.seed, offset=o2)
         g2, b2 = S.p(pre + "output.LayerNorm.weight"), S.p(pre + "output.LayerNorm.bias")

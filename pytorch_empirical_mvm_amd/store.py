@@ -114,10 +114,32 @@ class ParamStore:
             o += self.index[n][1]
         return buf[o0:o].view(shape)
 
+    W8_SCALE = 512.0        # static per-tensor scale of the e4m3 weight copy (|w| up to 0.875 before e4m3 saturates at 448)
+
     def refresh_shadow(self):
         self.sync_pending()
         K.cast_bf16(self.flat[:self.total], self.shadow[:self.total])
         self.refresh_transposed()
+        self.refresh_fp8()
+
+    # ---- e4m3 copy of the arena (BASELINE config 5's "fp8 MFMA path": opt-in forward GEMMs of the fusion qkv / FFN-in projections)
+    def enable_fp8(self):
+        self.sync_pending()
+        if getattr(self, "shadow8", None) is None and self.device.type == "cuda":
+            self.total8 = -(-self.total // 8) * 8
+            self.shadow8 = torch.zeros(self.total8 + self.TAIL, device=self.device, dtype=torch.uint8)
+            self.refresh_fp8()
+
+    def refresh_fp8(self):
+        """the e4m3 copy follows the bf16 compute copy (after every optimizer step / load)"""
+        if getattr(self, "shadow8", None) is not None:
+            K.cast_fp8(self.shadow[:self.total8], self.W8_SCALE, out=self.shadow8[:self.total8])
+
+    def b8(self, n, shape=None):
+        return self._view(self.shadow8, n, shape)
+
+    def fused8(self, names, shape):
+        return self.fused(self.shadow8, names, shape)
         self._shadow_version = self.flat._version        # (model._sync_param_surface: a torch-side in-place update of a parameter view bumps it)
 
     # ---- W^T copies (bf16) of every Linear weight: dgrad dX = dY W then runs as a k-major x k-major GEMM
