@@ -122,7 +122,7 @@ class InStepTimers:
         return (sum(g) / len(g) if g else None), len(g), ad, n
 
 
-def cpu_baseline_worker(size, frames, threads, B=4, timed=2, warmup=1):
+def cpu_baseline_worker(size, frames, threads, B=4, timed=3, warmup=1):
     """CPU oracle ('port' of the reference algorithm, validated against the reference's own outputs) on this host: full train
     steps (fwd + loss + bwd + clip + AdamW, fp32) on a BOUNDED sample of the same workload: B = 4 clips (so that every clip runs its
     1 + O = 5 fusion sequences as at B = 32), one warm-up step + `timed` timed steps, `threads` torch threads."""
@@ -150,9 +150,9 @@ def cpu_baseline_worker(size, frames, threads, B=4, timed=2, warmup=1):
                                  f"{dt:.1f} s/step")), flush=True)
 
 
-def cpu_baseline(size, frames, timeout_s=420):
+def cpu_baseline(size, frames, timeout_s=600):
     """Runs the worker in CHILD processes (bounded by a timeout so the default bench run stays within minutes): the figure at up to 32
-    threads (1 warm-up + 2 timed steps) and, beside it, ONE timed step at 8 threads -- the thread count of the survey's probe of the
+    threads (1 warm-up + 3 timed steps) and, beside it, one warmed-up timed step at 8 threads -- the thread count of the survey's probe of the
     reference itself (SURVEY 8d / BASELINE.md 3: 0.047 clips/s on 8 cores)."""
     import subprocess
 
@@ -167,7 +167,7 @@ def cpu_baseline(size, frames, timeout_s=420):
             return {"value": None, "unit": "clips/s", "cores": threads, "kind": "port", "sample": f"not completed within {timeout_s}s: {type(e).__name__}"}
     res = run(min(os.cpu_count() or 1, 32), [])
     if (os.cpu_count() or 1) > 8:
-        r8 = run(8, ["--cpu-timed", "1", "--cpu-warmup", "0"])
+        r8 = run(8, ["--cpu-timed", "1", "--cpu-warmup", "1"])
         res["threads_8"] = {k: r8.get(k) for k in ("value", "unit", "cores", "s_per_step", "sample")}
     return res
 
@@ -192,7 +192,7 @@ def main():
                     "default: frozen HF Swin-B teacher) or 3d_feature (frozen VideoSwin-B teacher)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--cpu-timed", type=int, default=2)
+    ap.add_argument("--cpu-timed", type=int, default=3)
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5's fp8 MFMA path: fusion qkv / FFN-in forward GEMMs on e4m3 operands (opt-in; never the headline: C2 is bf16)")
     a = ap.parse_args()

@@ -337,6 +337,9 @@ def _worker_early(rank, world, port, q, zero1):
             ok &= bool(torch.allclose(got[lo:hi], want[lo:hi], atol=1e-5))
         ok &= bool(torch.equal(S.grad[S.n_trainable:S.total], gens[rank][S.n_trainable:S.total]))       # the frozen segment is left alone
         ok &= red.collectives > n0 and not red.early_done
+    dsc = red.describe()                                 # what bench.py prints as the line's "rccl" object
+    ok &= dsc["backend"] == "gloo" and dsc["world"] == world and dsc["zero1"] == zero1 and dsc["phases"]["mid_layer"] == 2
+    ok &= dsc["collectives_issued"] == red.collectives and dsc["wire_bytes_issued"] > 0 and dsc["main_stream_wait_ms"] == []
     q.put((rank, bool(ok)))
     D.barrier()
     torch.distributed.destroy_process_group()
