@@ -36,6 +36,7 @@ def test_two_ranks_gradient_mean_and_identical_replicas(wire, cus):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "replicas identical=True" in p.stdout and f"wire={wire} " in p.stdout and f"reserve_cus={cus} " in p.stdout, p.stdout[-2000:]
     assert "concat-batch rel err" in p.stdout                    # SURVEY 8 a17's pin: DP-2 == one process on the concatenated batch (same negatives)
+    assert "autograd-step rel err" in p.stdout                   # round 6: model(batch) ... loss.backward() drives the same exchange phases
 
 
 @pytest.mark.timeout(900)

@@ -120,6 +120,40 @@ def main():
     from pytorch_empirical_mvm_amd import kernels as K
     assert K.RESERVE_CUS == 0 and K.RESERVE_EVENT is None     # back to the whole chip once the reductions have been waited for
     concat_err = concat_check(agent, model, mb, world, rank, dev)
+    # Round 6: the AUTOGRAD-driven step under data parallel -- out = model(batch); a torch loss; loss.backward() -- must start the same
+    # exchange phases from inside its backward node (model._OpenStep installs the reducer's hooks) and leave the same reduced gradient
+    # as the engine-driven step on the same batch, draws and Philox offsets.  The loss here is a fixed linear functional of the three
+    # outputs (the same on both paths: what is compared is the exchange, not a loss function).
+    eng.rng_offset = off0
+    S.grad.zero_()
+    model.train()
+    rb = dict(img=b["img"], cov=b["cov"], unmask_img=b["img"], txt=b["txt"], mask=b["mask"], ans_mtm=b["ans_mtm"])
+    n0 = agent.comm.collectives
+    out = model(rb, negatives=neg, dp_all=dp)
+    wm = torch.linspace(-1, 1, out["out_mtm"].shape[-1], device=dev) * 1e-3
+    loss = (out["out_mtm"] * wm).sum() + out["out_mvm"].float().mean() + out["out_vtm"].sum() * 0.1
+    loss.backward()
+    agent.comm.reduce_swin_and_wait()
+    torch.cuda.synchronize()
+    g_auto = cat_own(S.grad).clone()
+    phases_auto = agent.comm.collectives - n0
+    # the same functional through the engine's open step with explicit hooks
+    eng.rng_offset = off0
+    S.grad.zero_()
+    n0 = agent.comm.collectives
+    eng.on_swin_tail_ready, eng.on_fusion_mid_ready = agent.comm.reduce_swin_tail, agent.comm.reduce_other_early
+    outs, tr = eng.forward_open(dict(img=b["img"], cov=b["cov"], txt=b["txt"], mask=b["mask"]), negatives=neg, train=True, dp_all=dp)
+    d_mtm = wm.expand_as(outs["out_mtm"]).contiguous()
+    d_mvm = torch.full_like(outs["out_mvm"], 1.0 / outs["out_mvm"].numel())
+    d_vtm = torch.full_like(outs["out_vtm"], 0.1)
+    eng.backward_open(tr, d_mtm, d_mvm, d_vtm, on_other_grads_ready=agent.comm.reduce_other)
+    eng.on_swin_tail_ready = eng.on_fusion_mid_ready = None
+    agent.comm.reduce_swin_and_wait()
+    torch.cuda.synchronize()
+    g_eng = cat_own(S.grad).clone()
+    auto_err = float((g_auto - g_eng).abs().max() / (g_eng.abs().max() + 1e-12))
+    assert float(g_eng.abs().max()) > 0 and auto_err < 1e-3 and phases_auto == agent.comm.collectives - n0, (auto_err, phases_auto, agent.comm.collectives - n0)
+    S.grad.zero_()
     wb0, nc0 = agent.comm.wire_bytes, agent.comm.collectives
     S.grad.zero_()
     for _ in range(3):
@@ -140,7 +174,7 @@ def main():
         per_step = (agent.comm.wire_bytes - wb0) / 3 / S.n_trainable
         print(f"dp_check world={world} backend={dist.get_backend()} wire={wire} zero1={int(agent.comm.zero1)} wire-bytes/element/step {per_step:.2f} "
               f"reserve_cus={agent.comm.reserve_cus} grad-mean rel err {err:.2e} "
-              f"concat-batch rel err {concat_err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
+              f"concat-batch rel err {concat_err:.2e} autograd-step rel err {auto_err:.2e} replicas identical={int(t.item()) == world} losses {r}", flush=True)
     assert int(t.item()) == world
     dist.barrier()
     dist.destroy_process_group()
