@@ -437,6 +437,51 @@ int vmvm_attn_query_row_bwd(const void* dout, int32_t ld_dout, const void* q, in
                             const float* probs, const float* probs_drop, void* dq, int32_t ld_dq, void* dkv, int32_t ld_dkv, int32_t nseq, int32_t L,
                             int32_t heads, int32_t head_dim, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Block-level entry points (round 6).  One call = every launch of one HF BertLayer of the fusion encoder
+ * (model.py:204-214 via transformers BertLayer: self-attention with key mask + attention dropout, BertSelfOutput, BertIntermediate
+ * (GELU), BertOutput; post-LayerNorm), forward or backward -- the same kernels through the same descriptors the per-kernel entry points
+ * above take (which stay: the tests pin the two forms against each other bit for bit), but ONE descriptor fill and ONE foreign call
+ * per layer and direction instead of ~10 / ~22.  Every buffer is the caller's (activations that the backward re-reads are OUTPUTS of
+ * the forward call); nothing is allocated, nothing synchronises the host.
+ *
+ * Backward and the second stream: the four weight-gradient GEMMs (+ their fused bias column sums and split-K reduces) feed nothing
+ * downstream, so vmvm_bert_layer_bwd enqueues them on `side_stream` behind `fork_event` records on `stream` (one event handle, re-
+ * recorded in front of each of the four: a record / wait pair is consumed in stream order) while the input-gradient chain stays on
+ * `stream` (DESIGN 5 "Two streams").  side_stream == NULL: everything on `stream`.  The caller joins the streams before it reads the
+ * gradients, and keeps every buffer alive until the side stream has passed.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t nseq, L, hidden, heads, ffn;           /* M = nseq * L rows; head_dim = hidden / heads (64) */
+  /* parameters: bf16 compute copies, k-major [out][in]; optional transposed copies [in][out] for the input-gradient GEMMs (NULL: the
+   * m/n-major form on the un-transposed weight); f32 biases and LayerNorm parameters */
+  const void *Wqkv, *Wo, *W1, *W2;               /* [3H][H], [H][H], [F][H], [H][F] */
+  const void *WqkvT, *WoT, *W1T, *W2T;
+  const float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  float ln_eps;
+  /* f32 gradient accumulators (backward) */
+  float *gWqkv, *gWo, *gW1, *gW2, *gbqkv, *gbo, *gb1, *gb2, *gln1_g, *gln1_b, *gln2_g, *gln2_b;
+  /* forward: x in; everything else out (bf16 unless noted) */
+  const void* x;                                 /* [M][H] */
+  void* qkv;                                     /* [M][3H] */
+  void* ctx; float* lse;                         /* [M][H], f32 [nseq][heads][L] */
+  void* a; void* x1; float *mean1, *rstd1;       /* attention block: dense + dropout + residual, its LayerNorm */
+  void* u; int32_t code8;                        /* saved for the GELU backward: uint8 GELU' codes (code8 = 1) or the bf16 pre-activation, [M][F] */
+  void* h; void* f; void* x2; float *mean2, *rstd2;   /* FFN: GELU(fc1) [M][F], fc2 + dropout + residual, output LayerNorm = the layer's output */
+  const uint8_t* keymask; int32_t causal_from; float* att_colsum; void* drop_mask;      /* as vmvm_attn_fwd_desc */
+  float p_hidden, p_attn; uint64_t seed, off_attn, off_1, off_2;                        /* dropout (0 = off) and Philox offsets */
+  int32_t in_fp8; const void *Wqkv8, *W18; void *x8, *x18; float a8_scale, w8_scale;    /* opt-in e4m3 forward of the qkv / fc1 GEMMs (x8 / x18: e4m3 scratch [M][H]) */
+  /* backward: d_out in; d_x out (the FIRST gradient of x: written, not accumulated); the rest is scratch */
+  const void* d_out; void* d_x;
+  void *df, *dfm, *du, *dx1, *da, *dam, *dctx, *dqkv;   /* dfm / dam only with p_hidden > 0 (else unused) */
+  float* delta;                                  /* f32 [nseq][heads][L] */
+  void* ws_main; int64_t ws_main_bytes;          /* scratch of `stream` (LayerNorm partial rows) */
+  void* ws_side; int64_t ws_side_bytes;          /* scratch of `side_stream` (split-K slabs + bias-gradient partials) */
+  int32_t reserve_cus;
+} vmvm_bert_layer;
+int vmvm_bert_layer_fwd(const vmvm_bert_layer* l, void* stream);
+int vmvm_bert_layer_bwd(const vmvm_bert_layer* l, void* stream, void* side_stream, void* fork_event);
+
 /* hardware probe used by tests: dumps the lane mapping of ds_read_b64_tr_b16 (out: 64*4 int32) */
 int vmvm_probe_tr16(int32_t* out, void* stream);
 

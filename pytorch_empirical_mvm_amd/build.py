@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvmvm.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "layernorm.hip", "attention.hip", "attention_win3.hip", "attention_win4.hip", "misc.hip", "dvae.hip", "patch_embed.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "layernorm.hip", "attention.hip", "attention_win3.hip", "attention_win4.hip", "misc.hip", "dvae.hip", "patch_embed.hip", "blocks.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 

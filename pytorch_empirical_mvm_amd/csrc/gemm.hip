@@ -1387,6 +1387,9 @@ extern "C" int vmvm_gemm_bf16(const vmvm_gemm_desc* d, void* stream) {
       dd.K >= 4096 && dd.M >= 256 && dd.N >= 256 && !(dd.M & 7) && !(dd.N & 7) &&
       ((long)dd.M * dd.N >= (1 << 20) || dd.variant == 7)) {       // measured: +7..25 % from 2048x512 up, a loss below (the slabs of a one-round plan are 67 MB whatever the shape)
     const int t256 = ((dd.M + 255) / 256) * ((dd.N + 255) / 256);
+    // (round 6, measured and left alone: 192 or 128 target units -- the weight gradient on three quarters / half of the CUs for
+    //  proportionally longer, 4/7 of the slab bytes -- give the same step, 105.2-105.7 ms at all three: the second stream has slack,
+    //  the step is the main stream's chain)
     int s = 256 / t256;
     if (s > nk_all_ / 4) s = nk_all_ / 4;
     if (s < 1) s = 1;

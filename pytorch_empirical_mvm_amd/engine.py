@@ -115,6 +115,27 @@ class VioletEngine(SwinMixin, FusionMixin, HeadsMixin, DownstreamMixin):
                     t.record_stream(self.wstream)
         self._wpending = True
 
+    def _whold(self, operands):
+        """weight-gradient launches were just enqueued on the side stream by a block-level call (vmvm_bert_layer_bwd): keep their operands
+        alive until the side stream has passed them (the FIFO of `_wgrad_launch`)"""
+        if self.wstream is None:
+            return
+        ev = self._wev_pool.pop() if self._wev_pool else torch.cuda.Event()
+        ev.record(self.wstream)
+        held = self._wheld
+        held.append((ev, operands))
+        while held and held[0][0].query():
+            self._wev_pool.append(held.popleft()[0])
+        self._wpending = True
+
+    def _fork_event(self):
+        """raw handle of the event vmvm_bert_layer_bwd records on the main stream in front of each side-stream launch"""
+        ev = getattr(self, "_fork_ev", None)
+        if ev is None:
+            ev = self._fork_ev = torch.cuda.Event()
+            ev.record()                      # (the handle exists from the first record on)
+        return ev.cuda_event
+
     def _wgrad_join(self):
         """the main stream waits for the weight gradients in flight (before the gradient exchange / norm / AdamW read them)"""
         if self.wstream is not None and self._wpending:

@@ -88,6 +88,99 @@ class FusionMixin:
 
     # -------------------------------------------------------------- fusion encoder
     def _bert_layer(self, xv, nseq, Lq, keymask, l, train, causal_from=0, att_out=None):
+        if self.sw.block_abi and self.device.type == "cuda":
+            return self._bert_layer_block(xv, nseq, Lq, keymask, l, train, causal_from, att_out)
+        return self._bert_layer_calls(xv, nseq, Lq, keymask, l, train, causal_from, att_out)
+
+    def _bert_layer_block(self, xv, nseq, Lq, keymask, l, train, causal_from=0, att_out=None):
+        """HF BertLayer `l` through the block-level C ABI (include/vmvm.h vmvm_bert_layer; csrc/blocks.hip fills the same per-kernel
+        descriptors as `_bert_layer_calls` below, which stays as the statement of the layer and as the other side of the bit-for-bit
+        test): one descriptor + one foreign call for the forward (10 launches) and one for the backward (22 launches, the four weight
+        gradients on the engine's second stream).  This function only allocates and names buffers."""
+        from . import lib as L
+        import ctypes as C
+        S, dev = self.store, self.device
+        pre = f"trsfr.layer.{l}."
+        Hd, nh, F = self.cfg["hidden"], CFG.BERT["heads"], CFG.BERT["ffn"]
+        qn = [pre + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+        bn = [pre + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+        M = nseq * Lq
+        x = xv.t
+        p_h = CFG.BERT["hidden_dropout"] if train else 0.0
+        p_a = CFG.BERT["attn_dropout"] if train else 0.0
+        c8 = self.gelu_code8
+        d = L.BertLayer()
+        d.nseq, d.L, d.hidden, d.heads, d.ffn = nseq, Lq, Hd, nh, F
+        wo, w1, w2 = pre + "attention.output.dense.weight", pre + "intermediate.dense.weight", pre + "output.dense.weight"
+        d.Wqkv, d.Wo, d.W1, d.W2 = S.fused(S.shadow, qn, (3 * Hd, Hd)).data_ptr(), S.b(wo).data_ptr(), S.b(w1).data_ptr(), S.b(w2).data_ptr()
+        wqt = S.bt(qn[0])                                   # the fused [H, 3H] transposed copy (query | key | value adjacent), or none
+        d.WqkvT = L.ptr(wqt if (wqt is not None and tuple(wqt.shape) == (Hd, 3 * Hd)) else None)
+        d.WoT, d.W1T, d.W2T = (L.ptr(S.bt(n_)) for n_ in (wo, w1, w2))
+        d.bqkv = S.fused(S.flat, bn, (3 * Hd,)).data_ptr()
+        d.bo, d.b1, d.b2 = (S.p(pre + n_).data_ptr() for n_ in ("attention.output.dense.bias", "intermediate.dense.bias", "output.dense.bias"))
+        d.ln1_g, d.ln1_b = S.p(pre + "attention.output.LayerNorm.weight").data_ptr(), S.p(pre + "attention.output.LayerNorm.bias").data_ptr()
+        d.ln2_g, d.ln2_b = S.p(pre + "output.LayerNorm.weight").data_ptr(), S.p(pre + "output.LayerNorm.bias").data_ptr()
+        d.ln_eps = CFG.BERT["eps"]
+        if not S.frozen:
+            d.gWqkv, d.gbqkv = S.fused(S.grad, qn, (3 * Hd, Hd)).data_ptr(), S.fused(S.grad, bn, (3 * Hd,)).data_ptr()
+            d.gWo, d.gW1, d.gW2 = S.g(wo).data_ptr(), S.g(w1).data_ptr(), S.g(w2).data_ptr()
+            d.gbo, d.gb1, d.gb2 = (S.g(pre + n_).data_ptr() for n_ in ("attention.output.dense.bias", "intermediate.dense.bias", "output.dense.bias"))
+            d.gln1_g, d.gln1_b = S.g(pre + "attention.output.LayerNorm.weight").data_ptr(), S.g(pre + "attention.output.LayerNorm.bias").data_ptr()
+            d.gln2_g, d.gln2_b = S.g(pre + "output.LayerNorm.weight").data_ptr(), S.g(pre + "output.LayerNorm.bias").data_ptr()
+        e = torch.empty
+        qkv, ctx, lse = e((M, 3 * Hd), device=dev, dtype=BF16), e((M, Hd), device=dev, dtype=BF16), e((nseq, nh, Lq), device=dev, dtype=F32)
+        a, x1, mean1, rstd1 = e((M, Hd), device=dev, dtype=BF16), e((M, Hd), device=dev, dtype=BF16), e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
+        u, h = e((M, F), device=dev, dtype=torch.uint8 if c8 else BF16), e((M, F), device=dev, dtype=BF16)
+        f, x2, mean2, rstd2 = e((M, Hd), device=dev, dtype=BF16), e((M, Hd), device=dev, dtype=BF16), e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
+        d.x, d.qkv, d.ctx, d.lse, d.a, d.x1, d.mean1, d.rstd1 = (t_.data_ptr() for t_ in (x, qkv, ctx, lse, a, x1, mean1, rstd1))
+        d.u, d.code8, d.h, d.f, d.x2, d.mean2, d.rstd2 = u.data_ptr(), int(c8), h.data_ptr(), f.data_ptr(), x2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr()
+        d.keymask, d.causal_from, d.att_colsum = L.ptr(keymask), causal_from, L.ptr(att_out)
+        # Philox offsets in the order `_bert_layer_calls` draws them
+        d.off_attn = self._next_offset(nseq * nh * Lq * Lq)
+        dmask = None
+        if p_a > 0 and self.store_drop_mask:
+            dmask = K.attention_drop_mask(nseq, Lq, nh, Hd // nh, 1, p_a, dev, causal_from=causal_from, att_colsum=att_out)
+        d.drop_mask = L.ptr(dmask)
+        d.off_1 = self._next_offset(M * Hd)
+        d.off_2 = self._next_offset(M * Hd)
+        d.p_hidden, d.p_attn, d.seed = p_h, p_a, self.seed
+        x8 = x18 = None
+        if self.fp8:
+            x8, x18 = e((M, Hd), device=dev, dtype=torch.uint8), e((M, Hd), device=dev, dtype=torch.uint8)
+            d.in_fp8, d.Wqkv8, d.W18 = 1, S.fused8(qn, (3 * Hd, Hd)).data_ptr(), S.b8(w1).data_ptr()
+            d.x8, d.x18, d.a8_scale, d.w8_scale = x8.data_ptr(), x18.data_ptr(), self.A8_SCALE, S.W8_SCALE
+        d.reserve_cus = K.reserve_cus()
+        lib = L.load()
+        L.check(lib.vmvm_bert_layer_fwd(C.byref(d), L.stream()), "bert_layer_fwd")
+        out = V(x2)
+        # the descriptor holds raw addresses: every forward buffer the backward re-reads must stay referenced until the closure has run
+        saved = (x, qkv, ctx, lse, a, x1, mean1, rstd1, u, h, f, mean2, rstd2, dmask, keymask)
+
+        def bwd():
+            assert saved is not None
+            dg = out.g
+            df, du, dx1, da = e((M, Hd), device=dev, dtype=BF16), e((M, F), device=dev, dtype=BF16), e((M, Hd), device=dev, dtype=BF16), e((M, Hd), device=dev, dtype=BF16)
+            dfm = e((M, Hd), device=dev, dtype=BF16) if p_h > 0 else None
+            dam = e((M, Hd), device=dev, dtype=BF16) if p_h > 0 else None
+            dctx, dqkv, delta = e((M, Hd), device=dev, dtype=BF16), e((M, 3 * Hd), device=dev, dtype=BF16), e((nseq, nh, Lq), device=dev, dtype=F32)
+            dx = _gout(xv)
+            dx = e((M, Hd), device=dev, dtype=BF16) if dx is None else dx
+            d.d_out, d.d_x = dg.data_ptr(), dx.data_ptr()
+            d.df, d.dfm, d.du, d.dx1, d.da, d.dam, d.dctx, d.dqkv, d.delta = (L.ptr(t_) for t_ in (df, dfm, du, dx1, da, dam, dctx, dqkv, delta))
+            wsm = K._WORKSPACE.get(x.device)
+            d.ws_main, d.ws_main_bytes = L.ptr(wsm), (wsm.numel() if wsm is not None else 0)
+            side = self.wstream
+            d.ws_side, d.ws_side_bytes = (self.workspace_w.data_ptr(), self.workspace_w.numel()) if side is not None else (0, 0)
+            d.reserve_cus = K.reserve_cus()
+            L.check(lib.vmvm_bert_layer_bwd(C.byref(d), L.stream(), side.cuda_stream if side is not None else None,
+                                            self._fork_event() if side is not None else None), "bert_layer_bwd")
+            # the side stream reads these until it has passed the four weight gradients (the main-stream buffers die with this closure)
+            self._whold((dfm if dfm is not None else df, h, du, x1, dam if dam is not None else da, ctx, dqkv, x))
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out
+
+    def _bert_layer_calls(self, xv, nseq, Lq, keymask, l, train, causal_from=0, att_out=None):
         S, dev = self.store, self.device
         pre = f"trsfr.layer.{l}."
         Hd, nh = self.cfg["hidden"], CFG.BERT["heads"]

@@ -70,6 +70,24 @@ class AttnBwdDesc(C.Structure):
                 ("dbias_table", c_void_p), ("delta", c_void_p), ("dbias_ws", c_void_p), ("dbias_ws_bytes", c_i64)]
 
 
+class BertLayer(C.Structure):
+    """vmvm_bert_layer (include/vmvm.h): one fusion-encoder layer, forward or backward, per foreign call"""
+    _fields_ = [("nseq", c_int), ("L", c_int), ("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("Wqkv", c_void_p), ("Wo", c_void_p),
+                ("W1", c_void_p), ("W2", c_void_p), ("WqkvT", c_void_p), ("WoT", c_void_p), ("W1T", c_void_p), ("W2T", c_void_p), ("bqkv", c_void_p),
+                ("bo", c_void_p), ("b1", c_void_p), ("b2", c_void_p), ("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p),
+                ("ln2_b", c_void_p), ("ln_eps", c_float), ("gWqkv", c_void_p), ("gWo", c_void_p), ("gW1", c_void_p), ("gW2", c_void_p),
+                ("gbqkv", c_void_p), ("gbo", c_void_p), ("gb1", c_void_p), ("gb2", c_void_p), ("gln1_g", c_void_p), ("gln1_b", c_void_p),
+                ("gln2_g", c_void_p), ("gln2_b", c_void_p), ("x", c_void_p), ("qkv", c_void_p), ("ctx", c_void_p), ("lse", c_void_p),
+                ("a", c_void_p), ("x1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("u", c_void_p), ("code8", c_int), ("h", c_void_p),
+                ("f", c_void_p), ("x2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p), ("keymask", c_void_p), ("causal_from", c_int),
+                ("att_colsum", c_void_p), ("drop_mask", c_void_p), ("p_hidden", c_float), ("p_attn", c_float), ("seed", c_u64), ("off_attn", c_u64),
+                ("off_1", c_u64), ("off_2", c_u64), ("in_fp8", c_int), ("Wqkv8", c_void_p), ("W18", c_void_p), ("x8", c_void_p), ("x18", c_void_p),
+                ("a8_scale", c_float), ("w8_scale", c_float), ("d_out", c_void_p), ("d_x", c_void_p), ("df", c_void_p), ("dfm", c_void_p),
+                ("du", c_void_p), ("dx1", c_void_p), ("da", c_void_p), ("dam", c_void_p), ("dctx", c_void_p), ("dqkv", c_void_p),
+                ("delta", c_void_p), ("ws_main", c_void_p), ("ws_main_bytes", c_i64), ("ws_side", c_void_p), ("ws_side_bytes", c_i64),
+                ("reserve_cus", c_int)]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("param_bf16", c_void_p),
                 ("n", c_i64),
@@ -125,6 +143,8 @@ _PROTOS = {
     "vmvm_transpose_batched_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p, c_u64, c_void_p], c_int),
     "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
+    "vmvm_bert_layer_fwd": ([C.POINTER(BertLayer), c_void_p], c_int),
+    "vmvm_bert_layer_bwd": ([C.POINTER(BertLayer), c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),
     # workspace-size queries: the caller owns every buffer, scratch included
     "vmvm_gemm_workspace_size": ([C.POINTER(GemmDesc)], c_i64),

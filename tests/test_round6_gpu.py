@@ -479,3 +479,48 @@ def test_full_width_c5_step_with_fp8_forward():
     for k in ("mtm", "mvm"):
         assert abs(res[True][k] - res[False][k]) <= 5e-2 * abs(res[False][k]), res
     assert abs(res[True]["vtm"] - res[False]["vtm"]) <= 5e-2 * abs(res[False]["vtm"]) + 5e-2, res
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# block-level C ABI: vmvm_bert_layer_fwd / _bwd against the per-kernel entry points
+# ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_block_level_bert_layer_equals_the_per_kernel_calls_bit_for_bit(train):
+    """One fused step at the C2 shapes (B = 2) with the fusion-encoder layers issued through `vmvm_bert_layer_fwd / _bwd` (one foreign call
+    per layer and direction, csrc/blocks.hip) and through the per-kernel entry points (`_bert_layer_calls`): the same kernels with the same
+    descriptors, so losses, outputs and the whole gradient arena must be IDENTICAL bit for bit (the gradient path of these shapes has no
+    atomics).  Train mode: hidden + attention dropout on (recorded decisions), fixed DropPath draws."""
+    from oracle import violet_ref as R
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8))
+    cfg = R.make_cfg("base", T=8)
+    model.load_state_dict(R.make_state_dict(cfg))
+    img, txt, mask = R.make_batch(cfg, 2)
+    mb = R.default_masking(cfg, img, txt, mask, seed=6)
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).contiguous()
+    batch = dict(img=img.cuda(), cov=cov.cuda(), txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+    neg = R.vtm_negatives_default(2)
+    eng, S = model.engine, model.engine.store
+    from pytorch_empirical_mvm_amd import lib as L
+    calls = {"fwd": 0, "bwd": 0}
+    real = L.load()
+    res = {}
+    saved = eng.sw.block_abi
+    try:
+        for mode in (True, False):
+            eng.sw.block_abi = mode
+            eng.rng_offset = 0
+            np.random.seed(77)
+            S.grad.zero_()
+            losses, outs = eng.forward_backward(batch, negatives=neg, train=train, want_outputs=True, backward=True)
+            torch.cuda.synchronize()
+            res[mode] = ({k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}, outs["out_mvm"].clone(), outs["out_vtm"].clone(), S.grad[:S.n_trainable].clone())
+    finally:
+        eng.sw.block_abi = saved
+    (la, ma, va, ga), (lb, mb_, vb, gb) = res[True], res[False]
+    for k in la:                                        # (the loss VALUES' own sums still use f32 atomics: equal to rounding, not bit for bit)
+        assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]), (la, lb)
+    assert torch.equal(ma, mb_) and torch.equal(va, vb)
+    nd = int((ga != gb).sum())
+    print(f"\n[block ABI, train={train}] losses {la}; gradient entries that differ: {nd} of {ga.numel()}")
+    assert float(ga.abs().max()) > 0 and nd == 0, nd
