@@ -482,6 +482,42 @@ typedef struct {
 int vmvm_bert_layer_fwd(const vmvm_bert_layer* l, void* stream);
 int vmvm_bert_layer_bwd(const vmvm_bert_layer* l, void* stream, void* side_stream, void* fork_event);
 
+/* One Video-Swin block (SwinTransformerBlock3D.forward video_swin.py:206-263: norm1 -> shift / pad / window partition -> WindowAttention3D
+ * -> reverse -> DropPath residual; norm2 -> Mlp -> DropPath residual), forward or backward, per call.  The caller decides the schedule
+ * (which clips each branch runs on: DropPath draws are host-side, DESIGN 5 "Dead clips of DropPath") and owns every buffer; this call
+ * issues the launches -- the same kernels through the same descriptors as the per-kernel entry points (pinned bit for bit).
+ *   attention branch:  has_attn = 0: every clip dropped, x1 = x.  compact_a = 1: the branch runs on the Bk clips of `kept_a` (padding
+ *     entries -1) through the absolute row map src_k = expand(src, kept_a) (written by the forward, re-read by the backward); the nd_a
+ *     clips of `drop_a` are copied.  compact_a = 0: all B clips, per-clip scales `scale_a` (NULL: no DropPath).
+ *   MLP branch: the same with has_mlp / compact_m / Bm / kept_m / drop_m / nd_m / scale_m and the identity map `idm` -> map_m.
+ *   bias gradients: cs_mode = 0: plain fused column sum; 1: fused, times cs_scale (one DropPath scale for every row); 2: separate pass
+ *     weighted by the per-clip scales.
+ *   backward form: dx1_window = 1 (both branches on every clip, un-padded windows): norm2's backward writes d(x1) in window order through
+ *     `inv` (vmvm_ln_bwd_desc.dx_map) and norm1's backward takes it by output row; else the gathered form, with the source-major
+ *     LayerNorm walk when src_major = 1 (`inv`, or inv_k = invert(src_k) in the compact case). */
+typedef struct {
+  int32_t B, L, Lp, N, nW, C, heads; float qscale; int32_t win_layout, rc0, table_len, code8;
+  int32_t has_attn, compact_a, Bk, nd_a, cs_mode_a; float cs_scale_a;
+  const float* scale_a; const int32_t* kept_a; const int32_t* drop_a;      /* scale_a: [Bk] kept-clip scales (compact) or [B] per-clip scales */
+  int32_t has_mlp, compact_m, Bm, nd_m, cs_mode_m; float cs_scale_m;
+  const float* scale_m; const int32_t* kept_m; const int32_t* drop_m;
+  int32_t dx1_window, src_major;
+  const int32_t *src, *inv, *idm, *rc; const uint8_t* region;              /* [Lp], [L], [L], [N], [nW][N] or NULL */
+  const void *Wqkv, *Wproj, *W1, *W2, *WqkvT, *WprojT, *W1T, *W2T;          /* bf16 [3C][C], [C][C], [4C][C], [C][4C]; transposed copies or NULL */
+  const float *bqkv, *bproj, *b1, *b2, *n1_g, *n1_b, *n2_g, *n2_b, *table;  /* table: f32 [table_len][heads] */
+  float *gWqkv, *gWproj, *gW1, *gW2, *gbqkv, *gbproj, *gb1, *gb2, *gn1_g, *gn1_b, *gn2_g, *gn2_b, *gtable;
+  const void* x;                                                            /* bf16 [B*L][C] */
+  void* xw; float *mean1, *rstd1; void* qkv; void* ao; float* lse; int32_t* src_k;   /* attention branch, rows = (compact_a ? Bk : B) * Lp */
+  void* x1;                                                                 /* [B*L][C] (= x when has_attn = 0: pass the same pointer) */
+  void* y2; float *mean2, *rstd2; void* u; void* h; int32_t* map_m;         /* MLP branch, rows = (compact_m ? Bm : B) * L; u: uint8 codes or bf16, NULL = not saved */
+  void* x2;                                                                 /* [B*L][C] (= x1 when has_mlp = 0) */
+  const void* d_out; void* d_x;                                             /* backward: d(x2) in, d(x) out (written) */
+  void *dx2c, *du, *dy2, *dx1, *dx1w, *dao, *dqkv, *dxw; float* delta; int32_t* inv_k;
+  void* ws_main; int64_t ws_main_bytes; void* ws_side; int64_t ws_side_bytes; int32_t reserve_cus;
+} vmvm_swin_block;
+int vmvm_swin_block_fwd(const vmvm_swin_block* b, void* stream);
+int vmvm_swin_block_bwd(const vmvm_swin_block* b, void* stream, void* side_stream, void* fork_event);
+
 /* hardware probe used by tests: dumps the lane mapping of ds_read_b64_tr_b16 (out: 64*4 int32) */
 int vmvm_probe_tr16(int32_t* out, void* stream);
 

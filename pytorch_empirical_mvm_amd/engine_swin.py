@@ -36,6 +36,167 @@ class SwinMixin:
         return out
 
     def _swin_block(self, xv, B, dims, C, nh, pre, shifted, dp):
+        if self.sw.block_abi and self.device.type == "cuda" and not self.store.frozen:
+            return self._swin_block_block(xv, B, dims, C, nh, pre, shifted, dp)
+        return self._swin_block_calls(xv, B, dims, C, nh, pre, shifted, dp)
+
+    def _swin_block_block(self, xv, B, dims, C, nh, pre, shifted, dp):
+        """SwinTransformerBlock3D through the block-level C ABI (include/vmvm.h vmvm_swin_block; csrc/blocks.hip issues the launches of
+        `_swin_block_calls` below through the same per-kernel descriptors -- that function stays as the statement of the block and as the
+        other side of the bit-for-bit test).  Here: the schedule (which clips each branch runs on), the index tables, the buffers."""
+        from . import lib as L
+        import ctypes as Ct
+        S, cfg = self.store, self.cfg
+        D, H, W = dims
+        L_ = D * H * W
+        win = tuple(cfg["window"])
+        ws, ss = SI.get_window_size(dims, win, tuple(i // 2 for i in win) if shifted else (0, 0, 0))
+        wm, (Dp, Hp, Wp) = SI.window_map(D, H, W, ws, ss)
+        N = ws[0] * ws[1] * ws[2]
+        Lp = wm.size
+        nW = Lp // N
+        dev = self.device
+        reg_np = SI.region_ids(Dp, Hp, Wp, ws, ss)
+        rc_np, rc0 = SI.rc_codes(N, win)
+        w3 = 1 if (SI.win3_ok(ws, ss) and self.sw.win_layout) else 0
+        pm = SI.win3_perm() if w3 else None
+        src = self._cached(("wm", dims, ws, ss, w3), lambda: _dev_i32(wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm, dev))
+
+        def _inv_host():
+            sm = wm.reshape(nW, N)[:, pm].reshape(-1) if w3 else wm
+            inv = np.full(L_, -1, dtype=np.int32)
+            ok = np.flatnonzero(sm >= 0)
+            inv[sm[ok]] = ok
+            return _dev_i32(inv, dev)
+        src_major = C <= 256 and self.sw.ln_src_major
+        reg = None if reg_np is None else self._cached(("reg", Dp, Hp, Wp, ws, ss, w3), lambda: torch.from_numpy(np.ascontiguousarray(reg_np[:, pm]) if w3 else reg_np).to(dev))
+        rc = self._cached(("rc", N, win, w3), lambda: _dev_i32(rc_np[pm] if w3 else rc_np, dev))
+        scale = 32 ** -0.5 if C // nh == 32 else (C // nh) ** -0.5
+        dp, dp2 = (dp if isinstance(dp, (tuple, list)) else (dp, dp))
+        ds = dp if (isinstance(dp, DropScale) or dp is None) else DropScale(dp)
+        ds2 = dp2 if (isinstance(dp2, DropScale) or dp2 is None) else DropScale(dp2)
+        # ---- the schedule, exactly as `_swin_block_calls` decides it
+        Bk, compact = B, False
+        if ds is not None and self.sw.droppath_dce != "0":
+            Bk, kept_a, dpk_a = ds.take(math.gcd(L_, Lp), B)
+            compact = Bk < B and ds.scale is not None
+            if not compact:
+                Bk = B
+        has_attn = not (compact and Bk == 0)
+        Bm, compact2 = B, False
+        if ds2 is not None and self.sw.droppath_dce not in ("0", "attn"):
+            Bm, kept_m, dpk_m = ds2.take(L_, B)
+            compact2 = Bm < B and ds2.scale is not None
+            if not compact2:
+                Bm = B
+        has_mlp = not (compact2 and Bm == 0)
+        c8 = getattr(self, "gelu_code8", True) and C % 64 == 0
+        win_dx1 = self.sw.dx1_window and not compact and not compact2 and Lp == L_
+
+        def cs(d_, comp):                              # bias-gradient form of a branch (engine._linear_bwd): (mode, scale)
+            if d_ is None:
+                return 0, 0.0                          # no DropPath scales at all: plain fused column sum
+            if comp or d_.n_kept == B:
+                return (1, float(d_.scale)) if d_.scale is not None else (2, 0.0)
+            return 2, 0.0
+        b = L.SwinBlock()
+        b.B, b.L, b.Lp, b.N, b.nW, b.C, b.heads, b.qscale = B, L_, Lp, N, nW, C, nh, scale
+        b.win_layout, b.rc0, b.code8 = w3, rc0, int(c8)
+        table = S.p(pre + "attn.relative_position_bias_table")
+        b.table_len = table.shape[0]
+        b.has_attn, b.compact_a, b.Bk = int(has_attn), int(compact), (Bk if compact else B)
+        b.has_mlp, b.compact_m, b.Bm = int(has_mlp), int(compact2), (Bm if compact2 else B)
+        b.cs_mode_a, b.cs_scale_a = cs(ds, compact)
+        b.cs_mode_m, b.cs_scale_m = cs(ds2, compact2)
+        sa = (dpk_a if compact else (None if ds is None else ds.dev))
+        sm_ = (dpk_m if compact2 else (None if ds2 is None else ds2.dev))
+        b.scale_a, b.scale_m = L.ptr(sa), L.ptr(sm_)
+        if compact:
+            b.kept_a, b.drop_a, b.nd_a = kept_a.data_ptr(), ds.dropped.data_ptr(), B - ds.n_kept
+        if compact2:
+            b.kept_m, b.drop_m, b.nd_m = kept_m.data_ptr(), ds2.dropped.data_ptr(), B - ds2.n_kept
+        b.dx1_window, b.src_major = int(win_dx1), int(src_major)
+        inv = self._cached(("wminv", dims, ws, ss, w3), _inv_host) if (win_dx1 or (src_major and not compact)) else None
+        idm = self._cached(("idmap", L_), lambda: _dev_i32(np.arange(L_), dev)) if compact2 else None
+        b.src, b.inv, b.idm, b.rc, b.region = src.data_ptr(), L.ptr(inv), L.ptr(idm), rc.data_ptr(), L.ptr(reg)
+        names = dict(Wqkv="attn.qkv.weight", Wproj="attn.proj.weight", W1="mlp.fc1.weight", W2="mlp.fc2.weight")
+        for k_, n_ in names.items():
+            w_, wt = S.b(pre + n_), S.bt(pre + n_)
+            setattr(b, k_, w_.data_ptr())
+            setattr(b, k_ + "T", L.ptr(wt if (wt is not None and wt.shape[1] == w_.shape[0]) else None))      # (engine._linear_bwd's choice)
+            setattr(b, "g" + k_, S.g(pre + n_).data_ptr())
+        for k_, n_ in dict(bqkv="attn.qkv.bias", bproj="attn.proj.bias", b1="mlp.fc1.bias", b2="mlp.fc2.bias", n1_g="norm1.weight", n1_b="norm1.bias",
+                           n2_g="norm2.weight", n2_b="norm2.bias", table="attn.relative_position_bias_table").items():
+            setattr(b, k_, S.p(pre + n_).data_ptr())
+            setattr(b, "g" + k_, S.g(pre + n_).data_ptr())
+        e = torch.empty
+        x = xv.t
+        Ma, Mm = (Bk if compact else B) * Lp, (Bm if compact2 else B) * L_
+        keep = [x, src, rc, reg, inv, idm, sa, sm_, ds, ds2]
+        b.x = x.data_ptr()
+        if has_attn:
+            xw, mean1, rstd1 = e((Ma, C), device=dev, dtype=BF16), e(Ma, device=dev, dtype=F32), e(Ma, device=dev, dtype=F32)
+            qkv, ao, lse = e((Ma, 3 * C), device=dev, dtype=BF16), e((Ma, C), device=dev, dtype=BF16), e((Ma // N, nh, N), device=dev, dtype=F32)
+            x1 = e((B * L_, C), device=dev, dtype=BF16)
+            src_k = e((Ma,), device=dev, dtype=torch.int32) if compact else None
+            b.xw, b.mean1, b.rstd1, b.qkv, b.ao, b.lse, b.src_k = (L.ptr(t_) for t_ in (xw, mean1, rstd1, qkv, ao, lse, src_k))
+            keep += [xw, mean1, rstd1, qkv, ao, lse, src_k]
+        else:
+            x1 = x
+        b.x1 = x1.data_ptr()
+        if has_mlp:
+            y2, mean2, rstd2 = e((Mm, C), device=dev, dtype=BF16), e(Mm, device=dev, dtype=F32), e(Mm, device=dev, dtype=F32)
+            u, h = e((Mm, 4 * C), device=dev, dtype=torch.uint8 if c8 else BF16), e((Mm, 4 * C), device=dev, dtype=BF16)
+            x2 = e((B * L_, C), device=dev, dtype=BF16)
+            map_m = e((Mm,), device=dev, dtype=torch.int32) if compact2 else None
+            b.y2, b.mean2, b.rstd2, b.u, b.h, b.map_m = (L.ptr(t_) for t_ in (y2, mean2, rstd2, u, h, map_m))
+            keep += [x1, y2, mean2, rstd2, u, h, map_m]
+        else:
+            x2 = x1
+        b.x2 = x2.data_ptr()
+        b.reserve_cus = K.reserve_cus()
+        lib = L.load()
+        L.check(lib.vmvm_swin_block_fwd(Ct.byref(b), L.stream()), "swin_block_fwd")
+        out = V(x2)
+
+        def bwd():
+            assert keep is not None                    # (the descriptor holds raw addresses: the forward buffers live until this has run)
+            dx2 = out.g
+            held = []
+            b.d_out = dx2.data_ptr()
+            dx1_t = dx2
+            if has_mlp:
+                dx2c = e((Mm, C), device=dev, dtype=BF16) if compact2 else None
+                du, dy2 = e((Mm, 4 * C), device=dev, dtype=BF16), e((Mm, C), device=dev, dtype=BF16)
+                b.dx2c, b.du, b.dy2 = L.ptr(dx2c), du.data_ptr(), dy2.data_ptr()
+                if not win_dx1:
+                    dx1_t = e((B * L_, C), device=dev, dtype=BF16)
+                    b.dx1 = dx1_t.data_ptr()
+                held += [dx2c if compact2 else dx2, h, du, y2]
+            if has_attn:
+                dx1w = e((Ma, C), device=dev, dtype=BF16)
+                dao, dqkv, dxw = e((Ma, C), device=dev, dtype=BF16), e((Ma, 3 * C), device=dev, dtype=BF16), e((Ma, C), device=dev, dtype=BF16)
+                delta = e((Ma // N, nh, N), device=dev, dtype=F32)
+                dx = e((B * L_, C), device=dev, dtype=BF16)
+                inv_k = e((B * L_,), device=dev, dtype=torch.int32) if (compact and src_major) else None
+                b.dx1w, b.dao, b.dqkv, b.dxw, b.delta, b.d_x, b.inv_k = (L.ptr(t_) for t_ in (dx1w, dao, dqkv, dxw, delta, dx, inv_k))
+                held += [dx1w, ao, dqkv, xw]
+            else:
+                dx = dx1_t                             # every clip of the attention branch dropped: d(x) = d(x1)
+                b.d_x = dx.data_ptr()
+            wsm = K._WORKSPACE.get(x.device)
+            b.ws_main, b.ws_main_bytes = L.ptr(wsm), (wsm.numel() if wsm is not None else 0)
+            side = self.wstream
+            b.ws_side, b.ws_side_bytes = (self.workspace_w.data_ptr(), self.workspace_w.numel()) if side is not None else (0, 0)
+            b.reserve_cus = K.reserve_cus()
+            L.check(lib.vmvm_swin_block_bwd(Ct.byref(b), L.stream(), side.cuda_stream if side is not None else None,
+                                            self._fork_event() if side is not None else None), "swin_block_bwd")
+            self._whold(tuple(held) + (sa, sm_))
+            _acc(xv, dx)
+        self.tape.append(bwd)
+        return out
+
+    def _swin_block_calls(self, xv, B, dims, C, nh, pre, shifted, dp):
         S, cfg = self.store, self.cfg
         D, H, W = dims
         L = D * H * W

@@ -88,6 +88,27 @@ class BertLayer(C.Structure):
                 ("reserve_cus", c_int)]
 
 
+class SwinBlock(C.Structure):
+    """vmvm_swin_block (include/vmvm.h): one Video-Swin block, forward or backward, per foreign call"""
+    _fields_ = [("B", c_int), ("L", c_int), ("Lp", c_int), ("N", c_int), ("nW", c_int), ("C", c_int), ("heads", c_int), ("qscale", c_float),
+                ("win_layout", c_int), ("rc0", c_int), ("table_len", c_int), ("code8", c_int), ("has_attn", c_int), ("compact_a", c_int),
+                ("Bk", c_int), ("nd_a", c_int), ("cs_mode_a", c_int), ("cs_scale_a", c_float), ("scale_a", c_void_p), ("kept_a", c_void_p),
+                ("drop_a", c_void_p), ("has_mlp", c_int), ("compact_m", c_int), ("Bm", c_int), ("nd_m", c_int), ("cs_mode_m", c_int),
+                ("cs_scale_m", c_float), ("scale_m", c_void_p), ("kept_m", c_void_p), ("drop_m", c_void_p), ("dx1_window", c_int),
+                ("src_major", c_int), ("src", c_void_p), ("inv", c_void_p), ("idm", c_void_p), ("rc", c_void_p), ("region", c_void_p),
+                ("Wqkv", c_void_p), ("Wproj", c_void_p), ("W1", c_void_p), ("W2", c_void_p), ("WqkvT", c_void_p), ("WprojT", c_void_p),
+                ("W1T", c_void_p), ("W2T", c_void_p), ("bqkv", c_void_p), ("bproj", c_void_p), ("b1", c_void_p), ("b2", c_void_p),
+                ("n1_g", c_void_p), ("n1_b", c_void_p), ("n2_g", c_void_p), ("n2_b", c_void_p), ("table", c_void_p), ("gWqkv", c_void_p),
+                ("gWproj", c_void_p), ("gW1", c_void_p), ("gW2", c_void_p), ("gbqkv", c_void_p), ("gbproj", c_void_p), ("gb1", c_void_p),
+                ("gb2", c_void_p), ("gn1_g", c_void_p), ("gn1_b", c_void_p), ("gn2_g", c_void_p), ("gn2_b", c_void_p), ("gtable", c_void_p),
+                ("x", c_void_p), ("xw", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("qkv", c_void_p), ("ao", c_void_p), ("lse", c_void_p),
+                ("src_k", c_void_p), ("x1", c_void_p), ("y2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p), ("u", c_void_p), ("h", c_void_p),
+                ("map_m", c_void_p), ("x2", c_void_p), ("d_out", c_void_p), ("d_x", c_void_p), ("dx2c", c_void_p), ("du", c_void_p),
+                ("dy2", c_void_p), ("dx1", c_void_p), ("dx1w", c_void_p), ("dao", c_void_p), ("dqkv", c_void_p), ("dxw", c_void_p),
+                ("delta", c_void_p), ("inv_k", c_void_p), ("ws_main", c_void_p), ("ws_main_bytes", c_i64), ("ws_side", c_void_p),
+                ("ws_side_bytes", c_i64), ("reserve_cus", c_int)]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("param_bf16", c_void_p),
                 ("n", c_i64),
@@ -143,6 +164,8 @@ _PROTOS = {
     "vmvm_transpose_batched_bf16": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "vmvm_sumsq_f32": ([c_void_p, c_i64, c_void_p, c_void_p, c_u64, c_void_p], c_int),
     "vmvm_adamw": ([C.POINTER(AdamWDesc), c_void_p], c_int),
+    "vmvm_swin_block_fwd": ([C.POINTER(SwinBlock), c_void_p], c_int),
+    "vmvm_swin_block_bwd": ([C.POINTER(SwinBlock), c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_bert_layer_fwd": ([C.POINTER(BertLayer), c_void_p], c_int),
     "vmvm_bert_layer_bwd": ([C.POINTER(BertLayer), c_void_p, c_void_p, c_void_p], c_int),
     "vmvm_probe_tr16": ([c_void_p, c_void_p], c_int),

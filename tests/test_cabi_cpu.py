@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("cname,pyname", [("vmvm_gemm_desc", "GemmDesc"), ("vmvm_ln_fwd_desc", "LnFwdDesc"), ("vmvm_ln_bwd_desc", "LnBwdDesc"),
-                                          ("vmvm_attn_fwd_desc", "AttnFwdDesc"), ("vmvm_attn_bwd_desc", "AttnBwdDesc"), ("vmvm_adamw_desc", "AdamWDesc"), ("vmvm_bert_layer", "BertLayer")])
+                                          ("vmvm_attn_fwd_desc", "AttnFwdDesc"), ("vmvm_attn_bwd_desc", "AttnBwdDesc"), ("vmvm_adamw_desc", "AdamWDesc"), ("vmvm_bert_layer", "BertLayer"), ("vmvm_swin_block", "SwinBlock")])
 def test_ctypes_structs_follow_header_field_order(cname, pyname):
     from pytorch_empirical_mvm_amd import lib
     m = re.search(r"typedef struct \{([^}]*)\} " + cname + ";", _header())

@@ -230,8 +230,10 @@ def test_droppath_dead_clip_elimination_equals_the_scaled_path(monkeypatch):
     res = {}
     # (the engine reads every VMVM_* switch ONCE at construction -- setting the environment here would compare the compacted
     # path with itself.  The switch is flipped on the live engine, and the two runs must have taken different paths: the compacted one
-    # launches vmvm_expand_batch_map / vmvm_copy_batches_bf16 (counted through the kernels module), the scaled one does not.)
-    from pytorch_empirical_mvm_amd import kernels as K
+    # builds compact row maps and copies the dropped clips' rows, the scaled one does not.  Counted where the product path issues them:
+    # the compact_a / compact_m flags of the block-level descriptor (vmvm_swin_block_fwd, round 6), or -- with VMVM_BLOCK_ABI=0 -- the
+    # vmvm_expand_batch_map / vmvm_copy_batches_bf16 calls of the kernels module.)
+    from pytorch_empirical_mvm_amd import kernels as K, lib as L
     calls = {}
     real_expand, real_copy = K.expand_batch_map, K.copy_batches
 
@@ -242,6 +244,16 @@ def test_droppath_dead_clip_elimination_equals_the_scaled_path(monkeypatch):
         return w
     monkeypatch.setattr(K, "expand_batch_map", counted("expand", real_expand))
     monkeypatch.setattr(K, "copy_batches", counted("copy", real_copy))
+    so = L.load()
+    real_blk = so.vmvm_swin_block_fwd
+
+    def blk_fwd(desc, stream):
+        n = int(desc._obj.compact_a) + int(desc._obj.compact_m)
+        if n:
+            calls["expand"] = calls.get("expand", 0) + n
+            calls["copy"] = calls.get("copy", 0) + n
+        return real_blk(desc, stream)
+    monkeypatch.setattr(so, "vmvm_swin_block_fwd", blk_fwd)
     saved = eng.sw.droppath_dce
     launches = {}
     try:

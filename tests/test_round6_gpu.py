@@ -524,3 +524,71 @@ def test_block_level_bert_layer_equals_the_per_kernel_calls_bit_for_bit(train):
     nd = int((ga != gb).sum())
     print(f"\n[block ABI, train={train}] losses {la}; gradient entries that differ: {nd} of {ga.numel()}")
     assert float(ga.abs().max()) > 0 and nd == 0, nd
+
+
+@pytest.mark.timeout(900)
+def test_block_level_swin_block_equals_the_per_kernel_calls_bit_for_bit():
+    """`vmvm_swin_block_fwd / _bwd` (one foreign call per Video-Swin block and direction) against `_swin_block_calls` on EVERY schedule a
+    block can take: B = 5 clips with explicit DropPath draws up to rate 0.5 -- branches compacted onto 1..4 kept clips (padded to whole K
+    tiles), all-kept branches (one fused bias-gradient scale), an attention branch and an MLP branch with every clip dropped, per-clip
+    weighted bias gradients where the elimination does not apply -- plus block 0 (no drop: the window-order d(x1) path).  Same kernels,
+    same descriptors: the gradient arena must be identical bit for bit."""
+    from oracle import violet_ref as R
+    B = 5
+    cfg = R.make_cfg("base", T=8, temp=1.0)
+    model, args = _engine(dict(vis_backbone_size="base", size_frame=8, max_size_frame=8, temp=1.0))
+    model.load_state_dict(R.make_state_dict(cfg))
+    eng, S = model.engine, model.engine.store
+    img, txt, mask = R.make_batch(cfg, B)
+    mb = R.default_masking(cfg, img, txt, mask, seed=5)
+    neg = R.vtm_negatives_default(B)
+    rng = np.random.RandomState(11)
+    n_blk = sum(cfg["depths"])
+    dpr = np.linspace(0, 0.5, n_blk)
+    scales = np.ones((n_blk, 2, B), np.float32)
+    for blk in range(1, n_blk):
+        keep = 1.0 - dpr[blk]
+        scales[blk] = np.floor(keep + rng.rand(2, B)) / keep
+    scales[9, 0] = 0.0
+    scales[12, 1] = 0.0
+    scales[3, 0, :] = (1.5, 1.0, 1.0, 2.0, 1.0)                # kept clips with DIFFERENT scales: no single scale -> the separate weighted column-sum pass
+    kept = (scales != 0).sum(-1)
+    assert {1, 3} & set(kept[4:22].flatten().tolist()) and 0 in kept and B in kept[1:]
+    dp_dev = [(torch.from_numpy(scales[i, 0]).cuda(), torch.from_numpy(scales[i, 1]).cuda()) for i in range(n_blk)]
+    cov = mb["mvm_mask"][:, :, 0, ::32, ::32].to(torch.uint8).cuda().contiguous()
+    batch = dict(img=img.cuda(), cov=cov, txt=mb["txt"].cuda(), mask=mask.cuda(), ans_mtm=mb["ans_mtm"].cuda())
+    from pytorch_empirical_mvm_amd import lib as L
+    so = L.load()
+    real_f = so.vmvm_swin_block_fwd
+    seen = set()
+
+    def fwd(desc, stream):
+        d = desc._obj
+        seen.add((int(d.has_attn), int(d.compact_a), int(d.cs_mode_a), int(d.has_mlp), int(d.compact_m), int(d.cs_mode_m), int(d.dx1_window)))
+        return real_f(desc, stream)
+    so.vmvm_swin_block_fwd = fwd
+    res = {}
+    saved = eng.sw.block_abi
+    try:
+        for mode in (True, False):
+            eng.sw.block_abi = mode
+            eng.rng_offset = 0
+            S.grad.zero_()
+            losses, outs = eng.forward_backward(batch, negatives=neg, train=True, dp_all=dp_dev, dropout=False, backward=True, want_outputs=True)
+            torch.cuda.synchronize()
+            res[mode] = ({k: float(losses[k].item()) for k in ("mtm", "vtm", "mvm")}, outs["out_mvm"].clone(), S.grad[:S.n_trainable].clone())
+    finally:
+        eng.sw.block_abi = saved
+        so.vmvm_swin_block_fwd = real_f
+    # the schedules the block-level run went through: (has_attn, compact_a, cs_mode_a, has_mlp, compact_m, cs_mode_m, dx1_window)
+    # (a branch with EVERY clip dropped has no kept scale: it is not compacted but runs scaled by 0, through the weighted column-sum form)
+    assert any(s_[1] == 1 for s_ in seen) and any(s_[4] == 1 for s_ in seen), seen            # compacted branches
+    assert any(s_[2] == 2 for s_ in seen) and any(s_[2] == 1 for s_ in seen), seen            # weighted / one-scale bias gradients
+    assert any(s_[6] == 1 for s_ in seen) and any(s_[6] == 0 for s_ in seen), seen            # window-order d(x1) and the gathered form
+    (la, ma, ga), (lb, mb_, gb) = res[True], res[False]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]), (la, lb)
+    assert torch.equal(ma, mb_)
+    nd = int((ga != gb).sum())
+    print(f"\n[swin block ABI] schedules {sorted(seen)}; losses {la}; gradient entries that differ: {nd} of {ga.numel()}")
+    assert float(ga.abs().max()) > 0 and nd == 0, nd

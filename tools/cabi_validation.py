@@ -146,6 +146,54 @@ def main(verbose=True):
     expect("gelu_bwd: null", l.vmvm_gelu_bwd_bf16(z, z, z, 8, z), EINVAL)
     expect("dropout: null", l.vmvm_dropout_bf16(z, z, 8, 0.1, 0, 0, z), EINVAL)
     expect("transpose_batched: null", l.vmvm_transpose_batched_bf16(z, z, z, 1, z), EINVAL)
+    # ---- block-level calls (csrc/blocks.hip): refused before the first per-kernel call is made
+    bl = lib.BertLayer()
+    for nm in ("vmvm_bert_layer_fwd", "vmvm_bert_layer_bwd"):
+        fn = getattr(l, nm)
+        args = (None,) if nm.endswith("fwd") else (None, None, None)
+        expect(f"{nm}: null descriptor", fn(None, *args), EINVAL)
+        expect(f"{nm}: zeroed descriptor", fn(C.byref(bl), *args), EINVAL)
+    bl.nseq, bl.L, bl.hidden, bl.heads, bl.ffn = 2, 64, 768, 12, 3072
+    expect("bert_layer_fwd: sizes but no buffers", l.vmvm_bert_layer_fwd(C.byref(bl), None), EINVAL)
+    expect("bert_layer_bwd: sizes but no buffers", l.vmvm_bert_layer_bwd(C.byref(bl), None, None, None), EINVAL)
+    bl.hidden = 770
+    expect("bert_layer_fwd: hidden not a multiple of the head count", l.vmvm_bert_layer_fwd(C.byref(bl), None), EINVAL)
+    sb = lib.SwinBlock()
+    for nm in ("vmvm_swin_block_fwd", "vmvm_swin_block_bwd"):
+        fn = getattr(l, nm)
+        args = (None,) if nm.endswith("fwd") else (None, None, None)
+        expect(f"{nm}: null descriptor", fn(None, *args), EINVAL)
+        expect(f"{nm}: zeroed descriptor", fn(C.byref(sb), *args), EINVAL)
+    sb.B, sb.L, sb.Lp, sb.N, sb.nW, sb.C, sb.heads = 2, 6272, 6272, 392, 16, 128, 4
+    sb.has_attn = sb.has_mlp = 1
+    expect("swin_block_fwd: sizes but no buffers", l.vmvm_swin_block_fwd(C.byref(sb), None), EINVAL)
+    for f_ in ("x", "x1", "x2", "src", "rc", "xw", "mean1", "rstd1", "qkv", "ao", "lse", "Wqkv", "Wproj", "bqkv", "bproj", "n1_g", "n1_b", "table",
+               "y2", "mean2", "rstd2", "h", "W1", "W2", "b1", "b2", "n2_g", "n2_b"):
+        setattr(sb, f_, p)
+    sb.Lp = 6000
+    expect("swin_block_fwd: Lp != nW * N", l.vmvm_swin_block_fwd(C.byref(sb), None), EINVAL)
+    sb.Lp, sb.compact_a = 6272, 1
+    expect("swin_block_fwd: compacted branch without its clip lists", l.vmvm_swin_block_fwd(C.byref(sb), None), EINVAL)
+    sb.compact_a = 0
+    expect("swin_block_bwd: no incoming gradient", l.vmvm_swin_block_bwd(C.byref(sb), None, None, None), EINVAL)
+    sb.d_out = sb.d_x = p
+    expect("swin_block_bwd: side stream without a fork event", l.vmvm_swin_block_bwd(C.byref(sb), None, p, None), EINVAL)
+    expect("swin_block_bwd: no backward buffers", l.vmvm_swin_block_bwd(C.byref(sb), None, None, None), EINVAL)
+    sb.B = 1 << 20
+    expect("swin_block_fwd: row count beyond 32-bit indexing", l.vmvm_swin_block_fwd(C.byref(sb), None), EINVAL)
+    expect("colsum_ws: null", l.vmvm_colsum_bf16_ws(z, 8, 8, 8, z, 0, z, 0, z, 0, z), EINVAL)
+    expect("colsum workspace: 69120 x 3072", 0 if l.vmvm_colsum_workspace_size(69120, 3072) > 0 else -1, 0)
+    expect("colsum workspace: negative", 0 if l.vmvm_colsum_workspace_size(-1, 8) <= 0 else -1, 0)
+    expect("attention_bwd_dbias_ws_size: null", 0 if l.vmvm_attention_bwd_dbias_ws_size(None) <= 0 else -1, 0)
+    ab = lib.AttnBwdDesc()
+    ab.f.nseq, ab.f.heads, ab.f.L, ab.f.head_dim, ab.f.win_layout = 512, 4, 392, 32, 1
+    expect("attention_bwd_dbias_ws_size: a window problem", 0 if l.vmvm_attention_bwd_dbias_ws_size(C.byref(ab)) >= 0 else -1, 0)
+    expect("probe_tr16: null", l.vmvm_probe_tr16(z, z), EINVAL)
+    expect("last_hip_error: no HIP call was made", l.vmvm_last_hip_error(), 0)
+    # ---- the sweep names every exported entry point (a new one without a case fails here)
+    src = open(os.path.abspath(__file__)).read()
+    for nm in lib.exported_symbols():
+        expect(f"sweep covers {nm}", 0 if (nm in src or nm.replace("vmvm_", "") in src) else -99, 0)
     return bad
 
 
