@@ -283,10 +283,17 @@ typedef struct {
    * one after the other), and a second small kernel sums the partial tables of a head in a fixed order.  Size:
    * vmvm_attention_bwd_dbias_ws_size().  NULL / too small / another kernel family: f32 atomics, run-to-run differences in the last bits. */
   void* dbias_ws; int64_t dbias_ws_bytes;
+  /* Which launches this call makes (round 6).  The streaming window kernels (L > 448: config 5's (8,12,12) windows) compute the table
+   * gradient in a launch of its own that nothing on the input-gradient chain waits for, so a caller with a second stream runs it
+   * there, beside the GEMMs that follow: 0 = everything (default); 1 = everything EXCEPT that launch; 2 = ONLY that launch (needs the
+   * delta a phase-1 call wrote).  vmvm_attention_bwd_table_is_separate() says whether the problem has such a launch -- when it has
+   * not, phase 1 is the whole backward and phase 2 does nothing. */
+  int32_t table_phase;
 } vmvm_attn_bwd_desc;
 int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream);
 int64_t vmvm_attention_bwd_workspace_size(const vmvm_attn_bwd_desc* d); /* bytes of the `delta` scratch */
 int64_t vmvm_attention_bwd_dbias_ws_size(const vmvm_attn_bwd_desc* d);  /* bytes of `dbias_ws` (0: this problem has no reproducible build) */
+int vmvm_attention_bwd_table_is_separate(const vmvm_attn_bwd_desc* d);  /* 1: the table gradient is a launch of its own (table_phase above), 0: it is not / no table */
 
 /* ------------------------------------------------------------------------------------------
  * Small fused kernels
@@ -514,6 +521,7 @@ typedef struct {
   const void* d_out; void* d_x;                                             /* backward: d(x2) in, d(x) out (written) */
   void *dx2c, *du, *dy2, *dx1, *dx1w, *dao, *dqkv, *dxw; float* delta; int32_t* inv_k;
   void* ws_main; int64_t ws_main_bytes; void* ws_side; int64_t ws_side_bytes; int32_t reserve_cus;
+  int32_t table_side;          /* 1: a table-gradient launch of its own (vmvm_attn_bwd_desc.table_phase) goes to the side stream; the caller keeps dao / qkv / lse / delta alive for it */
 } vmvm_swin_block;
 int vmvm_swin_block_fwd(const vmvm_swin_block* b, void* stream);
 int vmvm_swin_block_bwd(const vmvm_swin_block* b, void* stream, void* side_stream, void* fork_event);

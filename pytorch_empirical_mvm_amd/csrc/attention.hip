@@ -2466,10 +2466,15 @@ extern "C" int vmvm_attention_fwd(const vmvm_attn_fwd_desc* d, void* stream) {
     VMVM_CHECK_LAUNCH();                                                                     \
   } while (0)
 
+extern "C" int vmvm_attention_bwd_table_is_separate(const vmvm_attn_bwd_desc* d) {
+  return (d && d->f.mode == 0 && d->dbias_table && d->f.L > 0 && use_stream(&d->f)) ? 1 : 0;
+}
+
 extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
   if (!d) return VMVM_EINVAL;
   int rc = check_desc(&d->f);
   if (rc) return rc;
+  if (d->table_phase < 0 || d->table_phase > 2) return VMVM_EINVAL;
   if (!d->dout || !d->dqkv || !d->delta || (d->ld_dout & 7) || (d->ld_dqkv & 7)) return VMVM_EINVAL;
   if (!vmvm_hook::W4_TIMELINE_BUILD && d->f.drop_mask && !drop_mask_ok(&d->f)) return VMVM_ENOSUPPORT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -2495,31 +2500,35 @@ extern "C" int vmvm_attention_bwd(const vmvm_attn_bwd_desc* d, void* stream) {
       hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<HD, MODE, NWS, KCS, MASK>), dim3(d->f.nseq * d->f.heads * nkb), dim3(NWS * 64), sb.total, st, *d, nkb); \
       VMVM_CHECK_LAUNCH();                                                                                           \
     } while (0)
-    if (d->f.mode == 0) { if (d->f.region) LAUNCH_BWD_S(32, 0, true); else LAUNCH_BWD_S(32, 0, false); }
-    else LAUNCH_BWD_S(64, 1, false);
-    if (d->f.mode == 0 && d->dbias_table) {
-      const int nkc = (d->f.L + KCS - 1) / KCS;
+    if (d->table_phase != 2) {
+      if (d->f.mode == 0) { if (d->f.region) LAUNCH_BWD_S(32, 0, true); else LAUNCH_BWD_S(32, 0, false); }
+      else LAUNCH_BWD_S(64, 1, false);
+    }
+    if (d->f.mode == 0 && d->dbias_table && d->table_phase != 1) {
+      // workgroup block of this kernel: NWB waves x 16 queries against KCB keys (two 16 x KCB register blocks per wave: the running dS
+      // sums and the bias + mask block)
+      constexpr int NWB = 4, KCB = 128;
+      const int nkc = (d->f.L + KCB - 1) / KCB;
+      const int nqbb = (nt_ + NWB - 1) / NWB;
       // window positions (the bias + mask block is per position); without a region map every sequence shares one block
       int nwin = d->f.region ? ((d->f.n_win > 0 && d->f.nseq % d->f.n_win == 0) ? d->f.n_win : d->f.nseq) : 1;
-      int ncb = 2048 / (d->f.heads * nqb * 2 * nkc);
+      int ncb = (8192 / NWB) / (d->f.heads * nqbb * nkc);
       if (ncb < 1) ncb = 1;
       if (!d->f.region && ncb > 1) {                  // no mask: split the sequences themselves to fill the chip
         nwin = ncb < d->f.nseq ? ncb : d->f.nseq;
         while (d->f.nseq % nwin) --nwin;
       }
       if (ncb > nwin) ncb = nwin;
-      // 4-wave workgroups here: the kernel holds two 16 x 128 blocks per wave in registers (3 waves per SIMD), and what hides the
-      // per-sequence load latency is the number of workgroups in flight per CU (3 at this size, 1 with 8 waves)
-      constexpr int NWB = 4;
-      const int nqbb = (nt_ + NWB - 1) / NWB;
-      const int sm_db = sa.total + 2 * KCS * 32 * 2;                    // second (K chunk, V chunk) buffer of the pipelined clip loop
-      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWB, KCS>, sm_db);
+      const SmemS sd = smem_stream(d->f.L, 32, 0, d->f.table_len, 0, KCB);
+      const int sm_db = sd.total + 2 * KCB * 32 * 2;                    // second (K chunk, V chunk) buffer of the pipelined clip loop
+      int rc_ = set_smem(attn_bwd_dbias_stream_kernel<NWB, KCB>, sm_db);
       if (rc_) return rc_;
-      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWB, KCS>), dim3(ncb * d->f.heads * nqbb * nkc), dim3(NWB * 64), sm_db, st, *d, ncb, nqbb, nwin);
+      hipLaunchKernelGGL((attn_bwd_dbias_stream_kernel<NWB, KCB>), dim3(ncb * d->f.heads * nqbb * nkc), dim3(NWB * 64), sm_db, st, *d, ncb, nqbb, nwin);
       VMVM_CHECK_LAUNCH();
     }
     return VMVM_OK;
   }
+  if (d->table_phase == 2) return VMVM_OK;           // no separate table launch for this problem: phase 1 did everything
   const int nb = d->f.nseq * d->f.heads;
   // dq: persistent workgroups, ~3 per CU (mode 0) so the per-workgroup bias-table flush is amortised over many windows
   int nchunks = d->f.nseq;

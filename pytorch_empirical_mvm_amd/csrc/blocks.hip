@@ -423,7 +423,14 @@ extern "C" int vmvm_swin_block_bwd(const vmvm_swin_block* b, void* stream, void*
     a.dout = b->dao; a.ld_dout = C; a.dqkv = b->dqkv; a.ld_dqkv = 3 * C;
     a.dbias_table = b->gtable; a.delta = b->delta;
     a.dbias_ws = b->ws_main; a.dbias_ws_bytes = b->ws_main_bytes;
+    // streaming windows: the table gradient is a launch of its own that no input gradient waits for -> beside the GEMMs that follow
+    a.table_phase = (side && b->table_side && vmvm_attention_bwd_table_is_separate(&a)) ? 1 : 0;
     RC(vmvm_attention_bwd(&a, stream));
+    if (a.table_phase == 1) {
+      if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) return VMVM_EHIP;
+      a.table_phase = 2;
+      RC(vmvm_attention_bwd(&a, side_stream));
+    }
   }
   RC(swin_wgrad(b, b->dqkv, 3 * C, b->xw, C, b->gWqkv, b->gbqkv, 3 * C, C, p.Ma, 0, 0.f, nullptr, 0, st, side, ev));
   {

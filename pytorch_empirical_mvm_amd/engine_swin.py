@@ -35,6 +35,16 @@ class SwinMixin:
         self.tape.append(bwd)
         return out
 
+    def _window_attention_bwd(self, dao, qkv, ao, lse, nseq, N, nh, hd, scale, gtable, akw):
+        """window-attention backward; a table gradient that is a launch of its own (streaming windows: vmvm_attn_bwd_desc.table_phase)
+        goes to the second stream, beside the GEMMs that follow -- nothing on the input-gradient chain reads it"""
+        if self.wstream is not None and self.sw.table_side and self._cached(("tabsep", N), lambda: K.attention_table_separate(N, 0)):
+            dqkv, delta = K.attention_bwd(dao, qkv, ao, lse, nseq, N, nh, hd, 0, scale, dbias_table=gtable, table_phase=1, **akw)
+            self._wgrad_launch(lambda ws: K.attention_bwd(dao, qkv, ao, lse, nseq, N, nh, hd, 0, scale, dbias_table=gtable, table_phase=2,
+                                                          dqkv=dqkv, delta=delta, **akw), (dao, qkv, ao, lse, dqkv, delta, akw.get("seq_scale")))
+            return dqkv
+        return K.attention_bwd(dao, qkv, ao, lse, nseq, N, nh, hd, 0, scale, dbias_table=gtable, **akw)
+
     def _swin_block(self, xv, B, dims, C, nh, pre, shifted, dp):
         if self.sw.block_abi and self.device.type == "cuda" and not self.store.frozen:
             return self._swin_block_block(xv, B, dims, C, nh, pre, shifted, dp)
@@ -189,6 +199,9 @@ class SwinMixin:
             side = self.wstream
             b.ws_side, b.ws_side_bytes = (self.workspace_w.data_ptr(), self.workspace_w.numel()) if side is not None else (0, 0)
             b.reserve_cus = K.reserve_cus()
+            b.table_side = int(side is not None and self.sw.table_side)
+            if has_attn and b.table_side and self._cached(("tabsep", N), lambda: K.attention_table_separate(N, 0)):
+                held += [dao, qkv, lse, delta]         # (its table-gradient launch reads these on the side stream)
             L.check(lib.vmvm_swin_block_bwd(Ct.byref(b), L.stream(), side.cuda_stream if side is not None else None,
                                             self._fork_event() if side is not None else None), "swin_block_bwd")
             self._whold(tuple(held) + (sa, sm_))
@@ -317,8 +330,7 @@ class SwinMixin:
                 dx1w, _ = K.layernorm_bwd(dy2, x1, g2, mean2, rstd2, S.g(pre + "norm2.weight"), S.g(pre + "norm2.bias"), dX_add=dx2, dx_map=inv_map)
                 dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp,
                                        cs_scale=ds.scale if (ds is not None and ds.n_kept == B) else None)
-                dqkv = K.attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, 0, scale,
-                                       dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
+                dqkv = self._window_attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, scale, S.g(pre + "attn.relative_position_bias_table"), akw)
                 dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
                 dx, _ = K.layernorm_bwd(dxw, x, g1, mean1, rstd1, S.g(pre + "norm1.weight"), S.g(pre + "norm1.bias"), rows_in=B * L, nseg=1,
                                         pad_mode=0, dX_add=dx1w, add_by_out=True, src=src, rows_out_per_batch=Lp, rows_in_per_batch=L)
@@ -344,8 +356,7 @@ class SwinMixin:
             dx1w = K.gather_rows(dx1, src_k, Bk * Lp) if compact else K.gather_rows(dx1, src, B * Lp, Lp, L)
             dao = self._linear_bwd(dx1w, ao, pre + "attn.proj.weight", pre + "attn.proj.bias", row_scale=dpk, rows_per_scale=Lp,
                                    cs_scale=ds.scale if (compact or (ds is not None and ds.n_kept == B)) else None)      # (every clip kept: one scale as well)
-            dqkv = K.attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, 0, scale,
-                                   dbias_table=S.g(pre + "attn.relative_position_bias_table"), **akw)
+            dqkv = self._window_attention_bwd(dao, qkv, ao, lse, Bk * nW, N, nh, C // nh, scale, S.g(pre + "attn.relative_position_bias_table"), akw)
             dxw = self._linear_bwd(dqkv, xw, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
             bkw = dict(src=src_k, rows_out_per_batch=Bk * Lp, rows_in_per_batch=B * L) if compact else dict(src=src, rows_out_per_batch=Lp, rows_in_per_batch=L)
             if src_major:                                     # x / d(x1) / d(x) in order, only dY looked up through the (inverse) map

@@ -221,9 +221,11 @@ def attention_fwd(qkv, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off,
 
 def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_off, k_off, v_off, bias_table=None, rc=None, rc0=0,
                   region=None, n_win=1, keymask=None, dropout_p=0.0, seed=0, offset=0, seq_scale=None, seqs_per_scale=0,
-                  dbias_table=None, stream_min_len=0, causal_from=0, win_layout=0, drop_mask=None):
-    dqkv = torch.empty_like(qkv)
-    delta = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32)
+                  dbias_table=None, stream_min_len=0, causal_from=0, win_layout=0, drop_mask=None, table_phase=0, dqkv=None, delta=None):
+    """table_phase (vmvm_attn_bwd_desc.table_phase): 1 = all but a separate table-gradient launch, returns (dqkv, delta) for the
+    phase-2 call (`dqkv=`, `delta=`: the same buffers), which makes only that launch -- on whichever stream is current."""
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    delta = torch.empty((nseq, heads, Lq), device=qkv.device, dtype=F32) if delta is None else delta
     b = L.AttnBwdDesc()
     b.f = _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_off, bias_table, rc, rc0, region, n_win,
                      keymask, dropout_p, seed, offset, seq_scale, seqs_per_scale, stream_min_len, causal_from, None, win_layout, drop_mask)
@@ -231,8 +233,17 @@ def attention_bwd(dout, qkv, out, lse, nseq, Lq, heads, hd, mode, scale, *, q_of
     b.dbias_table, b.delta = L.ptr(dbias_table), delta.data_ptr()
     ws = _WORKSPACE.get(qkv.device) if dbias_table is not None else None      # reproducible table gradient: per-workgroup partial tables in the caller's scratch
     b.dbias_ws, b.dbias_ws_bytes = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
+    b.table_phase = table_phase
     L.check(L.load().vmvm_attention_bwd(C.byref(b), L.stream()), "attention_bwd")
-    return dqkv
+    return (dqkv, delta) if table_phase == 1 else dqkv
+
+
+def attention_table_separate(Lq, mode, stream_min_len=0):
+    """does the backward of this problem compute its bias-table gradient in a launch of its own (vmvm_attention_bwd_table_is_separate)?"""
+    b = L.AttnBwdDesc()
+    b.f.L, b.f.mode, b.f.stream_min_len = Lq, mode, stream_min_len
+    b.dbias_table = 1                                   # (only tested for NULL)
+    return bool(L.load().vmvm_attention_bwd_table_is_separate(C.byref(b)))
 
 
 def invert_map(src, n_out):

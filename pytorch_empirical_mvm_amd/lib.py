@@ -67,7 +67,7 @@ class AttnFwdDesc(C.Structure):
 
 class AttnBwdDesc(C.Structure):
     _fields_ = [("f", AttnFwdDesc), ("dout", c_void_p), ("ld_dout", c_int), ("dqkv", c_void_p), ("ld_dqkv", c_int),
-                ("dbias_table", c_void_p), ("delta", c_void_p), ("dbias_ws", c_void_p), ("dbias_ws_bytes", c_i64)]
+                ("dbias_table", c_void_p), ("delta", c_void_p), ("dbias_ws", c_void_p), ("dbias_ws_bytes", c_i64), ("table_phase", c_int)]
 
 
 class BertLayer(C.Structure):
@@ -106,7 +106,7 @@ class SwinBlock(C.Structure):
                 ("map_m", c_void_p), ("x2", c_void_p), ("d_out", c_void_p), ("d_x", c_void_p), ("dx2c", c_void_p), ("du", c_void_p),
                 ("dy2", c_void_p), ("dx1", c_void_p), ("dx1w", c_void_p), ("dao", c_void_p), ("dqkv", c_void_p), ("dxw", c_void_p),
                 ("delta", c_void_p), ("inv_k", c_void_p), ("ws_main", c_void_p), ("ws_main_bytes", c_i64), ("ws_side", c_void_p),
-                ("ws_side_bytes", c_i64), ("reserve_cus", c_int)]
+                ("ws_side_bytes", c_i64), ("reserve_cus", c_int), ("table_side", c_int)]
 
 
 class AdamWDesc(C.Structure):
@@ -175,6 +175,7 @@ _PROTOS = {
     "vmvm_attention_bwd_workspace_size": ([C.POINTER(AttnBwdDesc)], c_i64),
     "vmvm_attention_drop_mask_size": ([C.POINTER(AttnFwdDesc)], c_i64),
     "vmvm_attention_bwd_dbias_ws_size": ([C.POINTER(AttnBwdDesc)], c_i64),
+    "vmvm_attention_bwd_table_is_separate": ([C.POINTER(AttnBwdDesc)], c_int),
     "vmvm_sumsq_workspace_size": ([c_i64], c_i64),
 }
 

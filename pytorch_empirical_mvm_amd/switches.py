@@ -24,7 +24,8 @@ class Switches:
     drop_mask: bool = True         # VMVM_DROP_MASK: fusion attention forward records its dropout decisions for the backward
     gelu_code8: bool = True        # VMVM_GELU_CODE8: GELU' saved as an 8-bit code
     wgrad_stream: bool = True      # VMVM_WGRAD_STREAM: weight gradients on a second HIP stream
-    block_abi: bool = True         # VMVM_BLOCK_ABI: a fusion-encoder layer = ONE foreign call per direction (vmvm_bert_layer_fwd / _bwd) instead of ~10 / ~22
+    block_abi: bool = True         # VMVM_BLOCK_ABI: a fusion-encoder layer / Video-Swin block = ONE foreign call per direction (vmvm_bert_layer_*, vmvm_swin_block_*) instead of ~10 / ~22
+    table_side: bool = False       # VMVM_TABLE_SIDE: a bias-table gradient that is a launch of its own (streaming windows, config 5) runs on the second stream (measured: config-5 step +1.4 .. +3 %, the chip is saturated either way -- opt-in)
     wgrad_hold: bool = True        # VMVM_WGRAD_HOLD: side-stream operands kept alive by a polled event FIFO (0: torch record_stream, rounds 4-5)
     opt_overlap: bool = True       # VMVM_OPT_OVERLAP: optimizer tail of the non-Swin groups beside the next forward
     zero1: bool = False            # VMVM_ZERO1: ZeRO-1 shape of the data-parallel step
@@ -47,6 +48,7 @@ class Switches:
         s.wgrad_stream = _flag(env, "VMVM_WGRAD_STREAM", True)
         s.wgrad_hold = _flag(env, "VMVM_WGRAD_HOLD", True)
         s.block_abi = _flag(env, "VMVM_BLOCK_ABI", True)
+        s.table_side = _flag(env, "VMVM_TABLE_SIDE", False)
         s.opt_overlap = _flag(env, "VMVM_OPT_OVERLAP", True)
         s.zero1 = env.get("VMVM_ZERO1", "0") == "1"
         w = env.get("VMVM_GRAD_WIRE", "bf16").lower()

@@ -188,6 +188,13 @@ def main(verbose=True):
     ab = lib.AttnBwdDesc()
     ab.f.nseq, ab.f.heads, ab.f.L, ab.f.head_dim, ab.f.win_layout = 512, 4, 392, 32, 1
     expect("attention_bwd_dbias_ws_size: a window problem", 0 if l.vmvm_attention_bwd_dbias_ws_size(C.byref(ab)) >= 0 else -1, 0)
+    ab.dbias_table, ab.f.mode, ab.f.L = p, 0, 1152
+    expect("attention_bwd_table_is_separate: streaming windows", l.vmvm_attention_bwd_table_is_separate(C.byref(ab)), 1)
+    ab.f.L = 392
+    expect("attention_bwd_table_is_separate: (8,7,7) windows", l.vmvm_attention_bwd_table_is_separate(C.byref(ab)), 0)
+    expect("attention_bwd_table_is_separate: null", l.vmvm_attention_bwd_table_is_separate(None), 0)
+    ab.table_phase = 7
+    expect("attention_bwd: unknown table_phase", l.vmvm_attention_bwd(C.byref(ab), None), EINVAL)
     expect("probe_tr16: null", l.vmvm_probe_tr16(z, z), EINVAL)
     expect("last_hip_error: no HIP call was made", l.vmvm_last_hip_error(), 0)
     # ---- the sweep names every exported entry point (a new one without a case fails here)
