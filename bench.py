@@ -25,7 +25,7 @@ TRAIN_FLOP_PER_CLIP = 2.060e12        # 686.7 GFLOP fwd x
 EXECUTED_FLOP_PER_CLIP = 2.060e12 - 0.068e12 - 0.09 * 3 * 281.3e9      # minus the VTM pass' dead query rows and ~9 % of the Swin blocks (DropPath draws of 0): 1.916e12
 PEAK_BF16 = 2.5e15                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_roofline_gemm.txt")     # written by tools/pmc_roofline.sh (separate --pmc passes)
 
 
 def pmc_traffic_bytes():
@@ -275,8 +275,16 @@ def main():
     if agent.comm is not None:
         agent.comm.timing = []
         c0, w0 = agent.comm.collectives, agent.comm.wire_bytes
-    with InStepTimers(B * (1 + O) * Lq) as tm:
-        one_step(a.steps)
+    # (the timed steps issue a fusion layer / Swin block as ONE block-level foreign call; this step issues the same launches through the
+    #  per-kernel entry points -- same kernels, same descriptors, bit-identical results: tests/test_round6_gpu.py::test_block_level_* --
+    #  so that the events can sit around the one GEMM)
+    blk = model.engine.sw.block_abi
+    model.engine.sw.block_abi = False
+    try:
+        with InStepTimers(B * (1 + O) * Lq) as tm:
+            one_step(a.steps)
+    finally:
+        model.engine.sw.block_abi = blk
     torch.cuda.synchronize()
     if agent.comm is not None:
         # the exchange of ONE step, for the first run on a real node to check itself against: group / backend as torch.distributed sees

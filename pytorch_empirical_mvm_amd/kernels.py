@@ -200,12 +200,18 @@ def _attn_desc(qkv, out, lse, nseq, Lq, heads, hd, mode, scale, q_off, k_off, v_
     return d
 
 
+_DROP_MASK_BYTES = {}
+
+
 def attention_drop_mask(nseq, Lq, heads, hd, mode, dropout_p, device, stream_min_len=0, causal_from=0, att_colsum=None):
     """buffer for the forward's dropout decisions (vmvm_attn_fwd_desc.drop_mask) when this problem has a stored-decision build, else None"""
-    d = L.AttnFwdDesc()
-    d.nseq, d.L, d.heads, d.head_dim, d.mode, d.dropout_p = nseq, Lq, heads, hd, mode, dropout_p
-    d.stream_min_len, d.causal_from, d.att_colsum = stream_min_len, causal_from, L.ptr(att_colsum)
-    n = L.load().vmvm_attention_drop_mask_size(C.byref(d))
+    key = (nseq, Lq, heads, hd, mode, dropout_p > 0, stream_min_len, causal_from, att_colsum is not None)
+    n = _DROP_MASK_BYTES.get(key)
+    if n is None:                                       # (pure host arithmetic in the library: asked once per problem shape)
+        d = L.AttnFwdDesc()
+        d.nseq, d.L, d.heads, d.head_dim, d.mode, d.dropout_p = nseq, Lq, heads, hd, mode, dropout_p
+        d.stream_min_len, d.causal_from, d.att_colsum = stream_min_len, causal_from, L.ptr(att_colsum)
+        n = _DROP_MASK_BYTES[key] = L.load().vmvm_attention_drop_mask_size(C.byref(d))
     return torch.empty((n // 4,), device=device, dtype=torch.int32) if n > 0 else None
 
 

@@ -22,6 +22,7 @@ args = CFG.get_args(vis_backbone_size="base", size_frame=8, max_size_frame=8, si
 model = VIOLET_Pretrain(args, None, device=dev)
 agent = Agent_Pretrain(args, model)
 agent.sched_step = 500
+model.engine.sw.block_abi = False      # per-kernel entry points: the GEMMs of a fusion layer / Swin block are then visible to the K.gemm hook (same launches as the block-level calls)
 img, txt, mask = bench.synth_batch(args, B, dev, 88)
 mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
 for _ in range(2):

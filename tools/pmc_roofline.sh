@@ -1,9 +1,9 @@
 #!/bin/bash
 # Counter passes (separate --pmc runs, only --kernel-trace beside them) + kernel trace of the roofline kernels of bench.py:
 # the fusion FFN fc1 GEMM (bias + GELU + saved 8-bit GELU' code, M = 69120, N = 3072, K = 768) and AdamW over a 225 M parameter arena.
-#   gpurun -- tools/pmc_roofline.sh      -> gpurun_out/r05_pmc_roofline_gemm.txt  (copy to profiles/)
+#   gpurun -- tools/pmc_roofline.sh      -> gpurun_out/r06_pmc_roofline_gemm.txt  (copy to profiles/)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_pmc_roofline_gemm.txt; mkdir -p $R/gpurun_out
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_pmc_roofline_gemm.txt; mkdir -p $R/gpurun_out
 : > $O
 run() { local n=$1; shift; rm -rf /tmp/pr_$n; rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pr_$n -- python3 $R/tools/pmc_roofline.py > /tmp/pr_$n.log 2>&1
         echo "--- pass $n: $*" >> $O; python3 $R/tools/pmc_summary.py $(find /tmp/pr_$n -name "*.db" | head -1) >> $O 2>&1; }
