@@ -16,9 +16,16 @@ args = CFG.get_args(vis_backbone_size="base", size_img=224, size_frame=8, max_si
 torch.manual_seed(88)
 model = VIOLET_Pretrain(args, None, device=dev)
 eng = model.engine
+from pytorch_empirical_mvm_amd.agent import Agent_Pretrain
+agent = Agent_Pretrain(args, model)
 img, txt, mask = bench.synth_batch(args, B, dev, 88)
-img = img.float().contiguous()
-cov = torch.zeros((B, 8, 7, 7), device=dev, dtype=torch.uint8)
+mb = agent.prepare_batch(agent.masking(img, txt, mask, None))
+for _ in range(2):
+    agent.step(mb, is_train=True, sync=False)
+torch.cuda.synchronize()
+img = mb["unmask_img"].to(dev, torch.float32).contiguous()
+cov = mb["cov"].to(dev).contiguous()
+print("img", tuple(img.shape), img.dtype, "cov", tuple(cov.shape), cov.dtype, flush=True)
 
 
 def fwd(x, c):
@@ -56,7 +63,7 @@ def run_two(xa, ca, xb, cb, s1, s2):
             tb[n - 1 - i]()
     cur.wait_stream(s1); cur.wait_stream(s2)
     eng._wgrad_join()
-    return oa, ob, ta, tb
+    return None
 
 
 def timed(fn, reps=5):
@@ -65,15 +72,18 @@ def timed(fn, reps=5):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    keep = [fn() for _ in range(reps)]
+    for _ in range(reps):
+        fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
 with L.pin_current():
     t_full = timed(lambda: run_one(img, cov))
+    print("one chain", t_full, flush=True)
     h = B // 2
-    t_half_seq = timed(lambda: (run_one(img[:h], cov[:h]), run_one(img[h:], cov[h:])))
+    t_half_seq = timed(lambda: (run_one(img[:h].contiguous(), cov[:h].contiguous()), run_one(img[h:].contiguous(), cov[h:].contiguous())))
+    print("halves in sequence", t_half_seq, flush=True)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     xa, xb, ca, cb = img[:h].contiguous(), img[h:].contiguous(), cov[:h].contiguous(), cov[h:].contiguous()
     t_two = timed(lambda: run_two(xa, ca, xb, cb, s1, s2))
