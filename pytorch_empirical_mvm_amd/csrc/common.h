@@ -74,6 +74,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// 16-byte streaming accesses: a tensor that is read once / written once per launch (LayerNorm rows, ...) should not displace the GEMM
+// operand panels that live in L2 / the Infinity Cache between launches.  Round 6, measured in the step with every LayerNorm kernel on
+// these (tools/scratch/build_ln_nt_variant.sh): 106.02 -> 105.56 ms (three interleaved pairs); alone the kernels are unchanged when
+// their operands are cold and slower when a micro-benchmark keeps them resident -- which a training step never does.
+typedef unsigned v4u_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt16(const void* p) {
+  const v4u_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4u_nt*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt16(void* p, const uint4 x) {
+  const v4u_nt v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4u_nt*>(p));
+}
+
 // erf-GELU (video_swin.py:66 nn.GELU ; HF hidden_act="gelu") and its derivative.  These run in GEMM epilogues on every
 // output element, where VALU time is not hidden by MFMA work, so erf is an odd minimax polynomial on |z| <= 3 (clamped to
 // +-1 beyond; max abs error 9e-5, i.e. <= 2e-4 absolute on GELU -- below the bf16 rounding of the stored activation) with

@@ -21,7 +21,7 @@ __device__ __forceinline__ void load_x8(const void* X, size_t elem_off, float* f
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
   } else {
-    unpack_bf8(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(X) + elem_off), f);
+    unpack_bf8(ld_nt16(reinterpret_cast<const u16*>(X) + elem_off), f);
   }
 }
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const vmvm_ln_fwd_desc p) {
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (x[i][e] - mean) * rstd * gg[e] + bb[e];
-      *reinterpret_cast<uint4*>(Y + col) = pack_bf8(o);
+      st_nt16(Y + col, pack_bf8(o));
     }
   }
 }
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const v
         if (XF32) {
           if (srow[i] >= 0) load_x8<XF32>(p.X, (size_t)srow[i] * p.ldx + within[i], xv);
         } else {
-          if (srow[i] >= 0) xraw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(p.X) + (size_t)srow[i] * p.ldx + within[i]);
+          if (srow[i] >= 0) xraw[i] = ld_nt16(reinterpret_cast<const u16*>(p.X) + (size_t)srow[i] * p.ldx + within[i]);
           unpack_bf8(xraw[i], xv);
         }
         addv[i] = make_uint4(0, 0, 0, 0);
-        if (ADD && srow[i] >= 0) addv[i] = *reinterpret_cast<const uint4*>(ADD + (p.add_by_out ? (size_t)m * p.ldadd + col : (size_t)srow[i] * p.ldadd + within[i]));
-        dyraw[i] = *reinterpret_cast<const uint4*>(dY + (size_t)m * p.lddy + col);
+        if (ADD && srow[i] >= 0) addv[i] = ld_nt16(ADD + (p.add_by_out ? (size_t)m * p.ldadd + col : (size_t)srow[i] * p.ldadd + within[i]));
+        dyraw[i] = ld_nt16(dY + (size_t)m * p.lddy + col);
         unpack_bf8(dyraw[i], dyv);
         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + col), g1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const v
         }
         long drow = srow[i];
         if (p.dx_map) { const long bb = m / p.dx_map_len; drow = (long)p.dx_map[m - bb * p.dx_map_len] + bb * p.dx_map_len; }     // (identity walk: srow = m)
-        *reinterpret_cast<uint4*>(dX + (size_t)drow * p.lddx + within[i]) = pack_bf8(o);
+        st_nt16(dX + (size_t)drow * p.lddx + within[i], pack_bf8(o));
         if (dX2) {
           if (has_drop) {
             uint32_t bits[8];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, (NCH == 2 ? 4 : 1)) void ln_bwd_kernel(const v
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
           }
-          *reinterpret_cast<uint4*>(dX2 + (size_t)m * p.lddx2 + c * 8) = pack_bf8(o);
+          st_nt16(dX2 + (size_t)m * p.lddx2 + c * 8, pack_bf8(o));
         }
       }
     }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void ln_fwd_pk_kernel(const vmvm_ln_fwd_desc p
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (x[e] - mean) * rstd * gg[e] + bb[e];
-    *reinterpret_cast<uint4*>(Y + col) = pack_bf8(o);
+    st_nt16(Y + col, pack_bf8(o));
   }
 }
 
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
       }
       float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dyv[8];
       if (srow >= 0) load_x8<XF32>(p.X, (size_t)srow * p.ldx + within, xv);
-      if (ADD && srow >= 0) addv = *reinterpret_cast<const uint4*>(ADD + (p.add_by_out ? (size_t)mm * p.ldadd + col : (size_t)srow * p.ldadd + within));
-      unpack_bf8(*reinterpret_cast<const uint4*>(dY + (size_t)mm * p.lddy + col), dyv);
+      if (ADD && srow >= 0) addv = ld_nt16(ADD + (p.add_by_out ? (size_t)mm * p.ldadd + col : (size_t)srow * p.ldadd + within));
+      unpack_bf8(ld_nt16(dY + (size_t)mm * p.lddy + col), dyv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         xh[e] = (xv[e] - mean) * rstd;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
       }
       long drow = srow;
       if (p.dx_map) { const long bb = mm / p.dx_map_len; drow = (long)p.dx_map[mm - bb * p.dx_map_len] + bb * p.dx_map_len; }     // (identity walk: srow = mm)
-      *reinterpret_cast<uint4*>(dX + (size_t)drow * p.lddx + within) = pack_bf8(o);
+      st_nt16(dX + (size_t)drow * p.lddx + within, pack_bf8(o));
       if (dX2) {
         if (has_drop) {
           uint32_t bits[8];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pk_kernel(const vmvm_ln_bwd_desc p
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = bits[e] < thr ? 0.f : o[e] * keep_scale;
         }
-        *reinterpret_cast<uint4*>(dX2 + (size_t)mm * p.lddx2 + col) = pack_bf8(o);
+        st_nt16(dX2 + (size_t)mm * p.lddx2 + col, pack_bf8(o));
       }
     }
   }

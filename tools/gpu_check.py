@@ -368,6 +368,24 @@ def check_gemm_round_split():
         ref2 = (acc + bias2 * rsr if sbo else (acc + bias2) * rsr) + r2.float()
         rep(f"gemm round split with per-clip row scales (scale_bias_only={sbo}) vs fp32", got, ref2)
         rep(f"gemm round split with per-clip row scales (scale_bias_only={sbo}) vs the 128x128 kernel", got, K.gemm(A2, B2, variant=6, **kw2).float(), tol=1e-2)          # (two kernels: one bf16 ulp of the largest outputs)
+    # round 6: the ABSOLUTE row-map form (a DropPath-compacted Swin fc2: the rows of the kept clips scatter into the full tensor, padding
+    # clips carry -1; residual read through the same map).  28 kept clips of 32 (+ 2 padding clips) -> 30 x 1 568 rows.  (Measured on
+    # this shape and not kept: the ping-pong kernel + whole-round split with the map moving with the rows -- 141.6 us against the 128x128
+    # kernel's 125.5.)
+    Bt = 32
+    kept = torch.randperm(Bt, device=dev)[:28].sort().values
+    lst = torch.cat([kept, torch.full((2,), -1, device=dev, dtype=kept.dtype)]).to(torch.int32)
+    amap = torch.where(lst[:, None] >= 0, lst[:, None] * Lc + torch.arange(Lc, device=dev, dtype=torch.int32)[None, :], torch.full((1, 1), -1, device=dev, dtype=torch.int32)).reshape(-1).contiguous().to(torch.int32)
+    x1 = rnd(Bt * Lc, N2)
+    rs3 = torch.cat([torch.full((28,), 1.0 / 0.9, device=dev), torch.zeros(2, device=dev)])
+    kw3 = dict(bias=bias2, resid=x1, row_scale=rs3, rows_per_scale=Lc, scale_bias_only=True, row_map=amap, map_len=Bc * Lc, map_stride=0, out_rows=Bt * Lc)
+    got3 = K.gemm(A2, B2, **kw3)
+    old3 = K.gemm(A2, B2, variant=6, **kw3)
+    rows = amap[amap >= 0].long()
+    src_rows = torch.nonzero(amap >= 0).squeeze(1)
+    ref3 = (A2[src_rows].float() @ B2.float().t() + bias2 / 0.9) + x1[rows].float()
+    rep("gemm absolute row map (compacted fc2: bias x scale + residual through the map) vs fp32", got3[rows], ref3)
+    rep("gemm absolute row map: auto dispatch vs the 128x128 kernel", got3[rows], old3[rows].float(), tol=1e-2)
 
 
 # ------------------------------------------------------------------ layernorm
