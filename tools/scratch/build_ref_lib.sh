@@ -8,7 +8,7 @@ tmp=$(mktemp -d)
 git -C "$root" archive "$rev" pytorch_empirical_mvm_amd/csrc include | tar -x -C "$tmp"
 mkdir -p "$root/tools/scratch/abl"
 cd "$tmp/pytorch_empirical_mvm_amd/csrc"
-for f in gemm gemm_pp layernorm attention attention_win3 attention_win4 misc dvae patch_embed; do
+for f in gemm gemm_pp layernorm attention attention_win3 attention_win4 misc dvae patch_embed blocks; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -I hooks -c $f.hip -o $f.o &
 done
 wait
