@@ -216,6 +216,14 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio into fd 1 (it came out AFTER the JSON line, at
+    # exit, in the world-1 RCCL run of round 6): in a distributed run everything that is not the JSON line goes to stderr -- fd 1 is
+    # pointed at fd 2 for the life of the process and the line is written to a duplicate of the original stdout.
+    json_out = sys.stdout
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("VMVM_FORCE_DIST"):
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     rank, world, local = D.init_from_env("nccl")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -354,7 +362,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.size, a.frames)
     if kt is None:
         out["roofline"]["kernel"] += " (not launched at this configuration)"
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         torch.distributed.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
