@@ -49,6 +49,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world < 2 and not os.environ.get("VMVM_FORCE_DIST"):
         return 0, 1, 0
+    # dmabuf IPC (the pool's host driver supports nothing else: without it RCCL's first peer-to-peer set-up fails with
+    # `hipIpcGetMemHandle: invalid argument`).  The launcher's environment already carries it; this only covers a bare environment, and
+    # only helps when nothing has initialised the HSA runtime yet.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("VMVM_DIST_BACKEND"):            # test hook: e.g. gloo with several ranks sharing one GPU (see VMVM_SHARE_GPU)
         backend = os.environ["VMVM_DIST_BACKEND"]
